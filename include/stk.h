@@ -1,0 +1,198 @@
+/*
+ * stk.h -- C ABI of libstk: the MI355X (gfx950) kernels behind the Soft-Truncation
+ * score-network training step and sampling loop.
+ *
+ * Every entry point is a plain-C function: raw device pointers, sizes, scalars and a
+ * HIP stream (passed as void* so that the header needs no HIP include).  No entry
+ * allocates, frees or synchronises; every launch goes to the given stream; the caller
+ * owns all memory.  Return value: 0 on success, a negative STK_E* code otherwise
+ * (stk_strerror() names it).  All tensors are fp32, contiguous, NCHW unless stated.
+ *
+ * Two libraries implement this header bit-for-bit at the interface level:
+ *   - soft-truncation_amd/csrc  -> libstk.so      (hand-written HIP for gfx950, the product)
+ *   - oracle/stk_ref.c          -> libstk_ref.so  (plain-C CPU restatement, test-only checker;
+ *                                                  `stream` is ignored, pointers are host pointers)
+ *
+ * What each entry replaces in the reference (paths relative to /root/reference):
+ *   stk_upfirdn2d_f32        op/upfirdn2d.cpp:12-19 (pybind `upfirdn2d`), op/upfirdn2d_kernel.cu:209-369
+ *   stk_fused_bias_act_f32   op/fused_bias_act.cpp:11-17 (pybind `fused_bias_act`), op/fused_bias_act_kernel.cu:52-99
+ *   stk_gn_*                 nn.GroupNorm + nn.SiLU (+ nn.Dropout) call sites, models/layerspp.py:256,277-278,90; models/ncsnpp.py:378-422
+ *   stk_conv2d_*             nn.Conv2d / NIN call sites, models/layerspp.py:273-282, models/layers.py:100-124,546-555
+ *   stk_gemm_f32             NIN / Linear / attention einsums, models/layerspp.py:95-99, models/ncsnpp.py:288-292
+ *   stk_softmax_*            F.softmax in AttnBlockpp, models/layerspp.py:97
+ *   stk_resample_naive_f32   naive_upsample_2d / naive_downsample_2d, models/up_or_down_sampling.py:59-69
+ *   stk_*embedding_f32       layers.get_timestep_embedding (models/layers.py:515-529), GaussianFourierProjection (models/layerspp.py:52-54)
+ *   stk_perturb_f32 / stk_sm_loss_*   losses.py:116-132
+ *   stk_grad_sumsq/adam/ema  losses.py:47-56 (clip_grad_norm_ + Adam), models/ema.py:43-51
+ */
+#ifndef STK_H
+#define STK_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STK_OK 0
+#define STK_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported combination) */
+#define STK_ELAUNCH (-2)   /* hipLaunchKernel / hipGetLastError reported a failure */
+#define STK_EUNSUPPORTED (-3)
+
+const char* stk_strerror(int code);
+/* "hip-gfx950" for the product library, "cpu-ref" for the oracle restatement. */
+const char* stk_backend(void);
+int stk_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * FIR resampling: pad -> zero-upsample -> FIR -> decimate, input viewed as
+ * [major, in_h, in_w, minor].  out_h = (in_h*up_y + pad_y0 + pad_y1 - kh)/down_y + 1.
+ * Same argument order as the reference pybind (op/upfirdn2d.cpp:12-14).
+ * `stk_upfirdn2d_acc_f32` computes out = beta*out + result (used by the backward pass).
+ * ------------------------------------------------------------------------------------------ */
+int stk_upfirdn2d_f32(const float* input, const float* kernel, float* out,
+                      int major, int in_h, int in_w, int minor, int kh, int kw,
+                      int up_x, int up_y, int down_x, int down_y,
+                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+int stk_upfirdn2d_acc_f32(const float* input, const float* kernel, float* out, float beta,
+                          int major, int in_h, int in_w, int minor, int kh, int kw,
+                          int up_x, int up_y, int down_x, int down_y,
+                          int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* out[i] = act(x[i] + b[(i/step_b) % size_b]) * scale;  act*10+grad: 10/11 linear, 12 zero,
+ * 30 lrelu, 31 lrelu-grad through `ref`, 32 zero (fused_bias_act_kernel.cu:36-47).
+ * b == NULL: no bias; ref == NULL: reference value 0. */
+int stk_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* out,
+                           long size_x, int step_b, int size_b, int act, int grad,
+                           float alpha, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm (+SiLU) (+dropout).  The input is the channel-concat of x1 [N,C1,HW] and
+ * x2 [N,C2,HW] (x2 NULL / C2 = 0 for a single source); C = C1 + C2, G groups, biased variance.
+ *   u = gamma_c * (x - mean_ng) * rstd_ng + beta_c ;  y = act ? u*sigmoid(u) : u ;
+ *   drop_p > 0:  y = keep(seed, flat index) ? y / (1 - drop_p) : 0      (stk_rng below)
+ * The effective dropout seed is seed + (seed_dev ? *seed_dev : 0): seed_dev lets a captured
+ * hipGraph draw a fresh mask on every replay (the by-value seed is frozen at capture time).
+ * mean/rstd [N*G] are written by fwd and read by bwd.
+ * bwd: dx = dx_beta*dx + grad wrt x (split into dx1/dx2 like the input), dgamma/dbeta are
+ * accumulated (+=).  ws: >= 2*N*C floats of scratch.
+ * ------------------------------------------------------------------------------------------ */
+int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2,
+                   const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                   int N, int HW, int G, float eps, int act, float drop_p,
+                   unsigned long long seed, const unsigned long long* seed_dev, void* stream);
+int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, int C2,
+                   const float* gamma, const float* beta, const float* mean, const float* rstd,
+                   float* dx1, float dx1_beta, float* dx2, float dx2_beta,
+                   float* dgamma, float* dbeta, float* ws,
+                   int N, int HW, int G, int act, float drop_p,
+                   unsigned long long seed, const unsigned long long* seed_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on the fp32 MFMA path.  Input = concat(x1[N,C1,H,W], x2[N,C2,H,W]).
+ * w_layout 0: w[Cout][Cin][KH][KW] (nn.Conv2d);  w_layout 1: w[Cin][Cout] (NIN, KH=KW=1).
+ * Any input coordinate outside [0,H)x[0,W) reads as zero, so OH/OW together with `pad`
+ * (top/left) also express asymmetric padding.
+ *   fwd:   y = (conv(x,w) + bias[co] + temb[n*temb_stride + co] + res[n,co,oy,ox]) / out_div
+ *          (bias, temb, res may be NULL; out_div = 1 disables it; like torch's tensor / python-scalar the
+ *          division is evaluated as a multiplication by the f32 reciprocal 1.f/out_div)
+ *   dgrad: dx{1,2} = beta{1,2}*dx{1,2} + alpha * conv_transpose(dy, w)   (dx split by channel)
+ *   wgrad: dw += alpha * sum_{n,oy,ox} dy * x        (same layout as w)
+ *          ws: scratch of stk_conv2d_wgrad_ws_bytes(...) bytes for the split-K partial slabs.
+ * ------------------------------------------------------------------------------------------ */
+int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2,
+                       const float* w, int w_layout, const float* bias,
+                       const float* temb, int temb_stride, const float* res, float out_div,
+                       float* y, int N, int H, int W, int Cout, int OH, int OW,
+                       int KH, int KW, int stride, int pad, void* stream);
+int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout,
+                         float* dx1, int C1, float beta1, float* dx2, int C2, float beta2,
+                         float alpha, int N, int H, int W, int Cout, int OH, int OW,
+                         int KH, int KW, int stride, int pad, void* stream);
+long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW);
+int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const float* dy,
+                         float* dw, int w_layout, float alpha, float* ws, long ws_bytes,
+                         int N, int H, int W, int Cout, int OH, int OW,
+                         int KH, int KW, int stride, int pad, void* stream);
+/* dtemb[n*temb_stride + c] = alpha * sum_hw dy[n,c,:]  (written; may be NULL);
+ * dbias[c] += alpha * sum_{n,hw} dy[n,c,:]              (accumulated; may be NULL).
+ * ws: >= N*C floats of scratch (only used when dtemb is NULL). */
+int stk_bias_grad_f32(const float* dy, int N, int C, int HW, float alpha,
+                      float* dtemb, int temb_stride, float* dbias, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched strided GEMM on the fp32 MFMA path:
+ *   C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][k][n] + bias + beta * C[b][m][n]
+ * with element (b,m,k) of A at A + b*sab + m*sam + k*sak (likewise B, C).
+ * bias_mode 0: none; 1: bias[m]; 2: bias[n].
+ * ------------------------------------------------------------------------------------------ */
+int stk_gemm_f32(const float* A, long sam, long sak, long sab,
+                 const float* B, long sbk, long sbn, long sbb,
+                 float* C, long scm, long scn, long scb,
+                 const float* bias, int bias_mode,
+                 int M, int N, int K, int batch, float alpha, float beta, void* stream);
+
+/* y[r,:] = softmax(scale * x[r,:]);   dx[r,:] = scale * y * (dy - sum(y*dy)) */
+int stk_softmax_fwd_f32(const float* x, float* y, long rows, int cols, float scale, void* stream);
+int stk_softmax_bwd_f32(const float* y, const float* dy, float* dx, long rows, int cols,
+                        float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise and small helpers.
+ * ------------------------------------------------------------------------------------------ */
+/* y = x*sigmoid(x);  dx = beta*dx + dy * sig(x)*(1 + x*(1-sig(x))) */
+int stk_silu_fwd_f32(const float* x, float* y, long n, void* stream);
+int stk_silu_bwd_f32(const float* x, const float* dy, float* dx, float beta, long n, void* stream);
+/* out = alpha*a + beta*b   (b may be NULL -> treated as 0; out may alias a or b) */
+int stk_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out, long n, void* stream);
+/* out = (a + b) * (1.f/div)  -- the skip_rescale combine (x + h)/sqrt(2), models/layerspp.py:104,287 */
+int stk_add_div_f32(const float* a, const float* b, float div, float* out, long n, void* stream);
+/* out = a*x + b */
+int stk_affine_f32(const float* x, float a, float b, float* out, long n, void* stream);
+/* mode 0: out[p,2y+i,2x+j] = alpha*in[p,y,x] (+ beta*out)   (naive_upsample_2d, in [planes,H,W])
+ * mode 1: out[p,y,x] = alpha*mean_{i,j} in[p,2y+i,2x+j] (+ beta*out) (naive_downsample_2d, in [planes,H,W]) */
+int stk_resample_naive_f32(const float* in, float* out, long planes, int H, int W, int mode,
+                           float alpha, float beta, void* stream);
+/* out[n, :] = mode==0 ? x[n,:]*s[n] : x[n,:]/s[n]   (scale_by_sigma, models/ncsnpp.py:428-430) */
+int stk_rowscale_f32(const float* x, const float* s, float* out, int N, long inner, int mode, void* stream);
+/* positional embedding: out[b, j] = sin(t_b f_j), out[b, half + j] = cos(t_b f_j),
+ * f_j = exp(-j ln(max_positions)/(half-1)); dim odd -> last column 0 (models/layers.py:515-529) */
+int stk_timestep_embedding_f32(const float* t, float* out, int B, int dim, float max_positions, void* stream);
+/* Gaussian Fourier features: p = x_b * W_j * 2 * pi; out[b,j] = sin p, out[b,nf+j] = cos p */
+int stk_fourier_embedding_f32(const float* x, const float* W, float* out, int B, int nf, void* stream);
+/* out[n,:] = a[n]*x[n,:] + s[n]*z[n,:]   (perturbation kernel x_t = mean + std*z, losses.py:118-119) */
+int stk_perturb_f32(const float* x, const float* z, const float* a, const float* s, float* out,
+                    int N, long inner, void* stream);
+/* Per-sample score-matching loss (losses.py:122-132) from the raw network output `net`:
+ *   score = vp ? -net/std[n] : net ;  r = score*std[n] + z           (mode 0)
+ *                                      r = score + z/std[n]           (mode 1, likelihood weighting)
+ *   loss[n] = wgt[n] * red * sum(r^2),  red = reduce_mean ? 1/inner : 0.5
+ * bwd: dnet = dloss[n] * d loss[n] / d net  (written). */
+int stk_sm_loss_fwd_f32(const float* net, const float* z, const float* std, const float* wgt,
+                        float* loss, int N, long inner, int vp, int mode, int reduce_mean, void* stream);
+int stk_sm_loss_bwd_f32(const float* net, const float* z, const float* std, const float* wgt,
+                        const float* dloss, float* dnet, int N, long inner, int vp, int mode,
+                        int reduce_mean, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer side (flat fp32 buffers of n elements).
+ *   stk_sumsq_f32:  out[0] = sum x^2 (deterministic two-stage; ws >= 1024 floats)
+ *   stk_adam_f32:   torch.optim.Adam/AdamW single-tensor update (losses.py:29-41,47-56) with the
+ *                   clip_grad_norm_ coefficient min(1, max_norm/(sqrt(*sumsq)+1e-6)) applied to g on
+ *                   the fly when sumsq != NULL and max_norm >= 0; g itself is rescaled in place
+ *                   (as clip_grad_norm_ does).  bc1 = 1-b1^t, bc2 = 1-b2^t.
+ *   stk_ema_f32:    s -= one_minus_decay * (s - p)      (models/ema.py:50-51)
+ * ------------------------------------------------------------------------------------------ */
+int stk_sumsq_f32(const float* x, long n, float* out, float* ws, void* stream);
+int stk_adam_f32(float* p, float* g, float* m, float* v, long n,
+                 float lr, float b1, float b2, float eps, float weight_decay, int adamw,
+                 float bc1, float bc2, const float* sumsq, float max_norm, void* stream);
+int stk_ema_f32(float* shadow, const float* p, long n, float one_minus_decay, void* stream);
+
+/* Counter-based RNG shared by both libraries so dropout masks are reproducible across them:
+ * u(seed, i) in [0,1) from a 64-bit mix of (seed, i); keep iff u >= p.
+ * stk_dropout_mask_f32 materialises mask[i] = keep ? 1/(1-p) : 0 (debug / oracle use). */
+int stk_dropout_mask_f32(float* mask, long n, float p, unsigned long long seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STK_H */

@@ -1,0 +1,33 @@
+/*
+ * stk_rng.h -- the counter-based RNG shared by libstk (HIP) and the oracle's C restatement.
+ *
+ * u(seed, i) = top 24 bits of a splitmix64-style finaliser of (seed, i), scaled to [0,1).
+ * Dropout keeps element i iff u(seed, i) >= p.  Because both libraries use this exact integer
+ * function, a dropout mask is a pure function of (seed, flat element index) and the HIP path and
+ * the CPU checker agree bit-for-bit on which elements are dropped.
+ * (The reference uses torch's Philox-based nn.Dropout, models/layerspp.py:245,278; CPU and GPU
+ * streams of torch differ from each other as well, so parity on masks can only be statistical
+ * against the reference and exact between our two libraries.)
+ */
+#ifndef STK_RNG_H
+#define STK_RNG_H
+
+#if defined(__HIPCC__)
+#define STK_HD __host__ __device__ __forceinline__
+#else
+#define STK_HD static inline
+#endif
+
+STK_HD unsigned long long stk_mix64(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (i + 1ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return z;
+}
+
+STK_HD float stk_uniform(unsigned long long seed, unsigned long long i) {
+  return (float)(stk_mix64(seed, i) >> 40) * (1.0f / 16777216.0f);
+}
+
+#endif /* STK_RNG_H */

@@ -1,0 +1,103 @@
+"""Data parallelism: one process per GPU, one bucketed gradient all-reduce per step over RCCL/xGMI.
+
+The reference's only multi-GPU mechanism is ``torch.nn.DataParallel`` (models/utils.py:94):
+every forward re-broadcasts all 247 MB of parameters from GPU 0 and every backward reduces the
+gradients back to GPU 0 from Python threads.  MI355X-first design instead:
+
+* each rank owns a full replica and a disjoint slice of the global batch; GroupNorm is
+  per-sample, so the only exchange in a step is the gradient average;
+* gradients already live in ONE flat fp32 buffer (engine/flat.py), so the exchange is a few large
+  contiguous all-reduces (``bucket_mb`` each, default 64 MB: with 7 point-to-point xGMI links per
+  GPU the ring is per-link bound, so few large messages beat many small ones), issued
+  asynchronously and waited once before the clip/Adam kernels;
+* ``t_min`` is one host scalar per step drawn from numpy's global stream (losses.py:284), so all
+  ranks seed numpy identically (``seed_everything``) and use the same truncation bound, as the
+  replicas of DataParallel did; torch's generators (t, z, dropout) are seeded per rank.
+
+Works with any backend ``torch.distributed`` offers: "nccl" (= RCCL on ROCm) on GPUs, "gloo"
+for the CPU tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+  return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+  return dist.get_world_size() if is_distributed() else 1
+
+
+def rank():
+  return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def seed_everything(seed):
+  """numpy: identical on all ranks (shared t_min stream); torch: offset by rank."""
+  np.random.seed(seed)
+  torch.manual_seed(seed + rank())
+  if torch.cuda.is_available():
+    torch.cuda.manual_seed(seed + rank())
+
+
+def bucket_ranges(n, bucket_elems):
+  """Split [0, n) into contiguous buckets of at most ``bucket_elems`` elements."""
+  bucket_elems = max(int(bucket_elems), 1)
+  return [(s, min(s + bucket_elems, n)) for s in range(0, n, bucket_elems)]
+
+
+def allreduce_flat_(flat_grad, n, bucket_mb=64.0, average=True, group=None):
+  """In-place sum (or mean) of ``flat_grad[:n]`` across ranks, bucketed and asynchronous."""
+  if not is_distributed():
+    return 0
+  ws = dist.get_world_size(group)
+  handles = []
+  ranges = bucket_ranges(n, int(bucket_mb * (1 << 20) / 4))
+  for s, e in ranges:
+    handles.append(dist.all_reduce(flat_grad[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True))
+  for h in handles:
+    h.wait()
+  if average:
+    flat_grad[:n].div_(ws)
+  return len(ranges)
+
+
+def sync_gradients(optimizer, params=None, bucket_mb=64.0):
+  """Average gradients across ranks before clipping (no-op in a single process).
+
+  Flat-backed parameters (the score network) go through ``allreduce_flat_``; any other
+  parameter list is flattened into one temporary bucket."""
+  if not is_distributed():
+    return
+  flat = getattr(optimizer, '_flat', None)
+  if flat is None and hasattr(optimizer, '_bind'):
+    try:
+      flat = optimizer._bind()
+    except RuntimeError:
+      flat = None
+  if flat is not None:
+    allreduce_flat_(flat.grad, flat.n_train, bucket_mb=bucket_mb)
+    return
+  if params is None:
+    params = [p for g in optimizer.param_groups for p in g['params']]
+  grads = [p.grad for p in params if p.grad is not None]
+  if not grads:
+    return
+  buf = torch.cat([g.reshape(-1) for g in grads])
+  allreduce_flat_(buf, buf.numel(), bucket_mb=bucket_mb)
+  off = 0
+  for g in grads:
+    g.copy_(buf[off:off + g.numel()].view_as(g))
+    off += g.numel()
+
+
+def shard_batch(batch):
+  """This rank's contiguous slice of a global batch (global batch must divide the world size)."""
+  ws, r = world_size(), rank()
+  if ws == 1:
+    return batch
+  assert batch.shape[0] % ws == 0, 'global batch must be divisible by the number of ranks'
+  per = batch.shape[0] // ws
+  return batch[r * per:(r + 1) * per]

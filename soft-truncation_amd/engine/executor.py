@@ -1,0 +1,179 @@
+"""Runs a planned score-network graph on the C-ABI kernels and bridges it into torch.autograd.
+
+One :class:`Executor` per model.  ``Executor.apply(x, emb_in, sigma)`` behaves like the
+reference's ``NCSNpp.forward`` body (models/ncsnpp.py:258-432) from autograd's point of view
+-- one differentiable node -- while inside it is a fixed launch sequence over pre-planned
+HBM buffers with hand-written backward kernels (engine/graph.py).
+
+Backend selection is explicit and never silent: the default backend is the HIP library
+(``engine.lib.load()``, raises if it is not built); a test may inject another implementation
+of include/stk.h (the oracle's CPU restatement) with ``set_backend``.
+"""
+import torch
+
+from . import lib as stk_lib
+from .flat import FlatParams
+from .graph import Graph, Runtime
+
+
+class Context:
+  """Buffers of one forward call, kept until its backward has run."""
+  __slots__ = ('prog', 'act', 'gact', 'rt', 'released', 'seed_dev')
+
+  def __init__(self, prog):
+    self.prog = prog
+    self.act = torch.empty(max(prog.graph.act_size, 1), dtype=torch.float32, device=prog.device)
+    self.gact = None
+    self.rt = None
+    self.released = False
+    self.seed_dev = None
+
+
+class Program:
+  """A finalized graph for one input signature plus its constant pool and context pool."""
+
+  def __init__(self, graph, device):
+    self.graph = graph
+    self.device = device
+    const = torch.zeros(max(graph.const_size, 1), dtype=torch.float32)
+    for off, arr in graph.const_chunks:
+      const[off:off + arr.size] = torch.from_numpy(arr)
+    self.const = const.to(device)
+    self.ws = torch.empty(graph.ws_bytes // 4, dtype=torch.float32, device=device)
+    self.free = []
+
+  def acquire(self):
+    c = self.free.pop() if self.free else Context(self)
+    c.released = False
+    return c
+
+  def release(self, c):
+    if not c.released:
+      c.released = True
+      c.rt = None
+      if len(self.free) < 4:
+        self.free.append(c)
+
+
+class _NetFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, ex, training, anchor, x, emb_in, sigma):
+    need_xgrad = bool(x.requires_grad)
+    out, c = ex.run_forward(x, emb_in, sigma, training, need_xgrad)
+    ctx.ex, ctx.c, ctx.need_xgrad = ex, c, need_xgrad
+    return out
+
+  @staticmethod
+  def backward(ctx, gout):
+    if ctx.c.released:
+      raise RuntimeError('score-network backward called twice on the same forward; the engine frees '
+                         'activations after the first backward')
+    gx = ctx.ex.run_backward(ctx.c, gout)
+    return None, None, None, (gx if ctx.need_xgrad else None), None, None
+
+
+class Executor:
+  def __init__(self, model, backend=None):
+    self.model = model
+    self.lib = backend if backend is not None else stk_lib.load()
+    self.flat = None
+    self.programs = {}
+    self._anchor = None
+
+  # -- parameters ---------------------------------------------------------------------------------
+  def set_backend(self, backend):
+    self.lib = backend
+    self.programs.clear()
+
+  def ensure_flat(self):
+    params = list(self.model.parameters())
+    device = params[0].device
+    if self.flat is None or self.flat.device != device or not self._layout_ok(params):
+      self.flat = FlatParams(params, device, groups=self.model._flat_groups())
+      self.programs.clear()
+      self._anchor = torch.zeros((), dtype=torch.float32, device=device, requires_grad=True)
+    else:
+      self.flat.rebind_grads()
+    if self.lib.is_device != (device.type == 'cuda'):
+      raise RuntimeError(f'backend {self.lib.backend} cannot run a model on {device}: the score network '
+                         f'runs on the HIP kernels only (no CPU / PyTorch fallback)')
+    return self.flat
+
+  def _layout_ok(self, params):
+    base = self.flat.data.data_ptr()
+    for p in params:
+      slot = self.flat._slot.get(id(p))
+      if slot is None or p.data.data_ptr() != base + 4 * slot[0]:
+        return False
+    return True
+
+  # -- programs -----------------------------------------------------------------------------------
+  def program(self, B, H, W, need_xgrad):
+    key = (B, H, W, need_xgrad)
+    prog = self.programs.get(key)
+    if prog is None:
+      g = Graph(self.flat)
+      out = self.model._emit(g, B, H, W, need_xgrad)
+      g.finalize(out, self.lib)
+      prog = self.programs[key] = Program(g, self.flat.device)
+    return prog
+
+  # -- execution ----------------------------------------------------------------------------------
+  def _copy_in(self, c, key, value):
+    t = c.prog.graph.inputs.get(key)
+    if t is None:
+      return
+    c.act[t.off:t.off + t.numel].view(t.shape).copy_(value.detach().reshape(t.shape))
+
+  def run_forward(self, x, emb_in, sigma, training, need_xgrad):
+    flat = self.ensure_flat()
+    B, _, H, W = x.shape
+    prog = self.program(B, H, W, need_xgrad)
+    c = prog.acquire()
+    g = prog.graph
+    self._copy_in(c, 'x', x)
+    self._copy_in(c, 'emb', emb_in)
+    if sigma is not None:
+      self._copy_in(c, 'sigma', sigma)
+    seed = 0
+    if training and self.model._uses_dropout():
+      seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    rt = Runtime(self.lib, stk_lib.stream_ptr(flat.device), c.act.data_ptr(), 0,
+                 flat.data.data_ptr(), flat.grad.data_ptr(), prog.const.data_ptr(),
+                 prog.ws.data_ptr(), g.ws_bytes, training, seed)
+    for op in g.ops:
+      op.forward(rt)
+    c.rt = rt
+    o = g.output
+    out = c.act[o.off:o.off + o.numel].view(o.shape).clone()
+    return out, c
+
+  def run_backward(self, c, gout):
+    prog, g, rt = c.prog, c.prog.graph, c.rt
+    flat = self.flat
+    if c.gact is None:
+      c.gact = torch.empty(max(g.gact_size, 1), dtype=torch.float32, device=prog.device)
+    rt.gbase['act'] = c.gact.data_ptr()
+    rt.gbase['param'] = flat.grad.data_ptr()
+    rt.stream = stk_lib.stream_ptr(flat.device)
+    o = g.output
+    c.gact[o.goff:o.goff + o.numel].view(o.shape).copy_(gout)
+    for op in reversed(g.ops):
+      op.backward(rt)
+    gx = None
+    xin = g.inputs['x']
+    if xin.needs_grad:
+      gx = c.gact[xin.goff:xin.goff + xin.numel].view(xin.shape).clone()
+    prog.release(c)
+    return gx
+
+  def apply(self, x, emb_in, sigma=None):
+    """Differentiable network evaluation (forward now, backward when autograd asks)."""
+    self.ensure_flat()
+    training = self.model.training
+    x = x.contiguous()
+    if torch.is_grad_enabled():
+      return _NetFn.apply(self, training, self._anchor, x, emb_in, sigma)
+    out, c = self.run_forward(x, emb_in, sigma, training, False)
+    c.prog.release(c)
+    return out

@@ -1,0 +1,566 @@
+"""Static op graph of one score-network evaluation and its hand-written backward.
+
+The reference runs the U-Net as ~37.7k eager ATen calls per training step with the autograd
+tape rebuilt every step.  Here the network is lowered ONCE per (batch, height,
+width) into a flat list of ops over pre-planned buffers:
+
+* every activation lives at a fixed offset of one HBM arena (288 GB per GPU makes "keep
+  everything resident" the cheap choice -- no allocator traffic, no recomputation);
+* every op launches C-ABI kernels (include/stk.h) on the current HIP stream, forward and
+  backward; the backward list is the forward list reversed, with gradient accumulation
+  (beta = 0 for the first writer of a gradient buffer, 1 afterwards) resolved at plan time;
+* parameter gradients are accumulated straight into the flat gradient buffer that the fused
+  optimizer and the RCCL all-reduce consume (engine/flat.py, engine/optim.py, engine/ddp.py).
+
+Because the plan is static, a whole forward/backward is a fixed launch sequence that can be
+captured into a hipGraph (engine/executor.py).
+"""
+import math
+
+import numpy as np
+
+SQRT2 = float(np.float32(np.sqrt(2.)))
+_ALIGN = 64  # floats (256 B) -- keeps every buffer float4-aligned
+
+
+def _round_up(n, a=_ALIGN):
+  return (n + a - 1) // a * a
+
+
+class Tensor:
+  """Symbolic fp32 tensor: a shape plus an offset into one of the runtime's address spaces."""
+  __slots__ = ('shape', 'numel', 'space', 'off', 'goff', 'needs_grad', 'name', 'seen', 'external_grad')
+
+  def __init__(self, shape, space, off, needs_grad, name):
+    self.shape = tuple(int(s) for s in shape)
+    self.numel = int(np.prod(self.shape)) if len(self.shape) else 1
+    self.space = space          # 'act' | 'param' | 'const'
+    self.off = off              # float offset in its space
+    self.goff = None            # float offset of the gradient (act: grad arena, param: flat grad)
+    self.needs_grad = needs_grad
+    self.name = name
+    self.seen = 0               # number of gradient writers already planned (backward order)
+    self.external_grad = False  # gradient is seeded from outside (network output)
+
+  def __repr__(self):
+    return f'T({self.name}{list(self.shape)}@{self.space}+{self.off})'
+
+
+class Runtime:
+  """Per-call view of the buffers: base addresses, stream, library, training flag."""
+
+  def __init__(self, lib, stream, act, gact, param, gparam, const, ws, ws_bytes, training, seed,
+               seed_dev=None):
+    self.lib = lib
+    self.stream = stream
+    self.base = {'act': act, 'param': param, 'const': const}
+    self.gbase = {'act': gact, 'param': gparam}
+    self.ws = ws
+    self.ws_bytes = ws_bytes
+    self.training = training
+    self.seed = seed
+    self.seed_dev = seed_dev
+
+  def v(self, t):
+    return None if t is None else self.base[t.space] + 4 * t.off
+
+  def g(self, t):
+    if t is None or not t.needs_grad or t.goff is None:
+      return None
+    return self.gbase[t.space] + 4 * t.goff
+
+
+class Op:
+  """Base class.  Subclasses list `inputs` (Tensors whose gradients they may write)."""
+  inputs = ()
+
+  def plan_backward(self):
+    """Called in backward order: fix beta (0 = overwrite, 1 = accumulate) per gradient target."""
+    self.beta = {}
+    for t in self.inputs:
+      if t is None or not t.needs_grad or t.space != 'act':
+        continue
+      if id(t) in self.beta:
+        continue
+      self.beta[id(t)] = 1.0 if (t.seen > 0 or t.external_grad) else 0.0
+      t.seen += 1
+
+  def b(self, t):
+    return self.beta.get(id(t), 1.0)
+
+  def forward(self, rt):
+    raise NotImplementedError
+
+  def backward(self, rt):
+    raise NotImplementedError
+
+  def ws_bytes(self, lib):
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# ops
+# ------------------------------------------------------------------------------------------------
+class GroupNormAct(Op):
+  """y = dropout(act(GroupNorm(cat(x1, x2))))  -- nn.GroupNorm + SiLU + Dropout call sites,
+  reference models/layerspp.py:256,277-278 (ResnetBlockBigGANpp), :90 (AttnBlockpp, act=False)."""
+
+  def __init__(self, g, x1, x2, gamma, beta_t, groups, eps, act, drop_p, name):
+    self.x1, self.x2, self.gamma, self.beta_t = x1, x2, gamma, beta_t
+    N, C1, H, W = x1.shape
+    C2 = x2.shape[1] if x2 is not None else 0
+    self.N, self.C1, self.C2, self.HW, self.G = N, C1, C2, H * W, groups
+    self.eps, self.act, self.drop_p = eps, int(act), float(drop_p)
+    self.y = g.new((N, C1 + C2, H, W), name=name)
+    self.mean = g.new((N * groups,), needs_grad=False, name=name + '.mean')
+    self.rstd = g.new((N * groups,), needs_grad=False, name=name + '.rstd')
+    self.inputs = (x1, x2)
+    self.op_id = g.next_id()
+
+  def _p(self, rt):
+    return self.drop_p if rt.training else 0.0
+
+  def forward(self, rt):
+    rt.lib.gn_fwd_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
+                      rt.v(self.y), rt.v(self.mean), rt.v(self.rstd), self.N, self.HW, self.G, self.eps,
+                      self.act, self._p(rt), (rt.seed + 0x9E3779B1 * self.op_id) & 0xFFFFFFFFFFFFFFFF,
+                      rt.seed_dev, rt.stream)
+
+  def backward(self, rt):
+    rt.lib.gn_bwd_f32(rt.g(self.y), rt.v(self.x1), self.C1, rt.v(self.x2), self.C2,
+                      rt.v(self.gamma), rt.v(self.beta_t), rt.v(self.mean), rt.v(self.rstd),
+                      rt.g(self.x1), self.b(self.x1), rt.g(self.x2), self.b(self.x2) if self.x2 is not None else 0.0,
+                      rt.g(self.gamma), rt.g(self.beta_t), rt.ws,
+                      self.N, self.HW, self.G, self.act, self._p(rt),
+                      (rt.seed + 0x9E3779B1 * self.op_id) & 0xFFFFFFFFFFFFFFFF, rt.seed_dev, rt.stream)
+
+  def ws_bytes(self, lib):
+    return 4 * 2 * self.N * (self.C1 + self.C2)
+
+
+class Conv(Op):
+  """y = (conv(cat(x1,x2), w) + bias + temb[:, col:col+Cout] + res) / out_div.
+
+  Covers nn.Conv2d 3x3/1x1 (models/layers.py:100-124), NIN (models/layers.py:546-555, w_layout 1),
+  the time-embedding add and the skip_rescale combine of ResnetBlockBigGANpp
+  (models/layerspp.py:273-287), Combine('sum') (:57-72) and the strided conv of
+  conv_downsample_2d (models/up_or_down_sampling.py:178)."""
+
+  def __init__(self, g, x1, x2, w, bias, w_layout, Cout, KH, KW, stride, pad, OH, OW,
+               temb=None, temb_col=0, res=None, out_div=1.0, name='conv'):
+    self.x1, self.x2, self.w, self.bias = x1, x2, w, bias
+    N, C1, H, W = x1.shape
+    C2 = x2.shape[1] if x2 is not None else 0
+    self.N, self.C1, self.C2, self.H, self.W = N, C1, C2, H, W
+    self.Cout, self.KH, self.KW, self.stride, self.pad, self.OH, self.OW = Cout, KH, KW, stride, pad, OH, OW
+    self.w_layout = w_layout
+    self.temb, self.temb_col = temb, temb_col
+    self.temb_stride = temb.shape[1] if temb is not None else 0
+    self.res, self.out_div = res, float(out_div)
+    self.y = g.new((N, Cout, OH, OW), name=name)
+    self.inputs = (x1, x2, res)
+
+  def _dims(self):
+    return (self.N, self.H, self.W, self.Cout, self.OH, self.OW, self.KH, self.KW, self.stride, self.pad)
+
+  def forward(self, rt):
+    temb = rt.v(self.temb) + 4 * self.temb_col if self.temb is not None else None
+    rt.lib.conv2d_fwd_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.w), self.w_layout,
+                          rt.v(self.bias), temb, self.temb_stride, rt.v(self.res), self.out_div,
+                          rt.v(self.y), *self._dims(), rt.stream)
+
+  def backward(self, rt):
+    gy = rt.g(self.y)
+    alpha = 1.0 / self.out_div
+    lib = rt.lib
+    if self.res is not None and self.res.needs_grad:
+      gr = rt.g(self.res)
+      lib.axpby_f32(gy, alpha, gr, self.b(self.res), gr, self.y.numel, rt.stream)
+    dtemb = None
+    if self.temb is not None and self.temb.needs_grad:
+      dtemb = rt.g(self.temb) + 4 * self.temb_col
+    gb = rt.g(self.bias)
+    if dtemb is not None or gb is not None:
+      lib.bias_grad_f32(gy, self.N, self.Cout, self.OH * self.OW, alpha, dtemb, self.temb_stride, gb,
+                        rt.ws, rt.stream)
+    gw = rt.g(self.w)
+    if gw is not None:
+      lib.conv2d_wgrad_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, gy, gw, self.w_layout, alpha,
+                           rt.ws, rt.ws_bytes, *self._dims(), rt.stream)
+    g1, g2 = rt.g(self.x1), rt.g(self.x2)
+    if g1 is not None or g2 is not None:
+      lib.conv2d_dgrad_f32(gy, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
+                           g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
+                           alpha, *self._dims(), rt.stream)
+
+  def ws_bytes(self, lib):
+    return max(int(lib.conv2d_wgrad_ws_bytes(self.C1, self.C2, self.N, self.Cout, self.OH, self.OW,
+                                             self.KH, self.KW)),
+               4 * self.N * self.Cout)
+
+
+class Linear(Op):
+  """y[B,out] = x[B,in] @ W[out,in]^T + b  -- nn.Linear (models/ncsnpp.py:97-102, layerspp.py:240)."""
+
+  def __init__(self, g, x, w, bias, name='linear'):
+    self.x, self.w, self.bias = x, w, bias
+    self.B, self.fin = x.shape
+    self.fout = w.shape[0]
+    self.y = g.new((self.B, self.fout), name=name)
+    self.inputs = (x,)
+
+  def forward(self, rt):
+    B, fin, fout = self.B, self.fin, self.fout
+    rt.lib.gemm_f32(rt.v(self.x), fin, 1, 0, rt.v(self.w), 1, fin, 0, rt.v(self.y), fout, 1, 0,
+                    rt.v(self.bias), 2 if self.bias is not None else 0, B, fout, fin, 1, 1.0, 0.0, rt.stream)
+
+  def backward(self, rt):
+    B, fin, fout = self.B, self.fin, self.fout
+    gy = rt.g(self.y)
+    lib = rt.lib
+    gx = rt.g(self.x)
+    if gx is not None:   # dX[b][k] = sum_n dY[b][n] W[n][k]
+      lib.gemm_f32(gy, fout, 1, 0, rt.v(self.w), fin, 1, 0, gx, fin, 1, 0, None, 0,
+                   B, fin, fout, 1, 1.0, self.b(self.x), rt.stream)
+    gw = rt.g(self.w)
+    if gw is not None:   # dW[n][k] += sum_b dY[b][n] X[b][k]
+      lib.gemm_f32(gy, 1, fout, 0, rt.v(self.x), fin, 1, 0, gw, fin, 1, 0, None, 0,
+                   fout, fin, B, 1, 1.0, 1.0, rt.stream)
+    gb = rt.g(self.bias)
+    if gb is not None:
+      lib.bias_grad_f32(gy, B, fout, 1, 1.0, None, 0, gb, rt.ws, rt.stream)
+
+  def ws_bytes(self, lib):
+    return 4 * self.B * self.fout
+
+
+class SiLU(Op):
+  def __init__(self, g, x, name='silu'):
+    self.x = x
+    self.y = g.new(x.shape, name=name)
+    self.inputs = (x,)
+
+  def forward(self, rt):
+    rt.lib.silu_fwd_f32(rt.v(self.x), rt.v(self.y), self.x.numel, rt.stream)
+
+  def backward(self, rt):
+    gx = rt.g(self.x)
+    if gx is not None:
+      rt.lib.silu_bwd_f32(rt.v(self.x), rt.g(self.y), gx, self.b(self.x), self.x.numel, rt.stream)
+
+
+class TimestepEmbedding(Op):
+  """layers.get_timestep_embedding (models/layers.py:515-529); no parameters, no gradient."""
+
+  def __init__(self, g, t, dim, name='temb.pos'):
+    self.t, self.dim = t, dim
+    self.y = g.new((t.shape[0], dim), needs_grad=False, name=name)
+
+  def forward(self, rt):
+    rt.lib.timestep_embedding_f32(rt.v(self.t), rt.v(self.y), self.t.shape[0], self.dim, 10000.0, rt.stream)
+
+  def backward(self, rt):
+    pass
+
+
+class FourierEmbedding(Op):
+  """GaussianFourierProjection (models/layerspp.py:45-54); W is frozen (requires_grad=False)."""
+
+  def __init__(self, g, x, W, name='temb.fourier'):
+    self.x, self.W = x, W
+    self.nf = W.shape[0]
+    self.y = g.new((x.shape[0], 2 * self.nf), needs_grad=False, name=name)
+
+  def forward(self, rt):
+    rt.lib.fourier_embedding_f32(rt.v(self.x), rt.v(self.W), rt.v(self.y), self.x.shape[0], self.nf, rt.stream)
+
+  def backward(self, rt):
+    pass
+
+
+class Affine(Op):
+  """y = a*x + b (the `2x - 1` recentring, models/ncsnpp.py:296-298)."""
+
+  def __init__(self, g, x, a, b, name='affine'):
+    self.x, self.a, self.bb = x, float(a), float(b)
+    self.y = g.new(x.shape, needs_grad=x.needs_grad, name=name)
+    self.inputs = (x,)
+
+  def forward(self, rt):
+    rt.lib.affine_f32(rt.v(self.x), self.a, self.bb, rt.v(self.y), self.x.numel, rt.stream)
+
+  def backward(self, rt):
+    gx = rt.g(self.x)
+    if gx is not None:
+      rt.lib.axpby_f32(rt.g(self.y), self.a, gx, self.b(self.x), gx, self.x.numel, rt.stream)
+
+
+class ResampleNaive(Op):
+  """naive_upsample_2d (2x2 repeat) / naive_downsample_2d (2x2 mean),
+  models/up_or_down_sampling.py:59-69."""
+
+  def __init__(self, g, x, up, name='resample'):
+    self.x, self.up = x, bool(up)
+    N, C, H, W = x.shape
+    self.planes, self.H, self.W = N * C, H, W
+    oshape = (N, C, H * 2, W * 2) if up else (N, C, H // 2, W // 2)
+    self.y = g.new(oshape, needs_grad=x.needs_grad, name=name)
+    self.inputs = (x,)
+
+  def forward(self, rt):
+    rt.lib.resample_naive_f32(rt.v(self.x), rt.v(self.y), self.planes, self.H, self.W,
+                              0 if self.up else 1, 1.0, 0.0, rt.stream)
+
+  def backward(self, rt):
+    gx = rt.g(self.x)
+    if gx is None:
+      return
+    if self.up:   # d/dx of repeat = 2x2 sum = 4 * mean
+      rt.lib.resample_naive_f32(rt.g(self.y), gx, self.planes, 2 * self.H, 2 * self.W, 1, 4.0,
+                                self.b(self.x), rt.stream)
+    else:         # d/dx of mean = 0.25 * repeat
+      rt.lib.resample_naive_f32(rt.g(self.y), gx, self.planes, self.H // 2, self.W // 2, 0, 0.25,
+                                self.b(self.x), rt.stream)
+
+
+class UpFirDn(Op):
+  """op.upfirdn2d on [N,C,H,W] (op/upfirdn2d.py:88-156).  Backward = the same operator with the
+  flipped taps, up<->down swapped and g_pad (op/upfirdn2d.py:111-114)."""
+
+  def __init__(self, g, x, taps, up, down, pad, name='upfirdn'):
+    self.x = x
+    taps = np.asarray(taps, dtype=np.float32)
+    self.kh, self.kw = taps.shape
+    self.k = g.const(taps)
+    self.kflip = g.const(taps[::-1, ::-1].copy())
+    self.up, self.down, self.pad0, self.pad1 = int(up), int(down), int(pad[0]), int(pad[1])
+    N, C, H, W = x.shape
+    self.major, self.H, self.W = N * C, H, W
+    self.OH = (H * up + pad[0] + pad[1] - self.kh) // down + 1
+    self.OW = (W * up + pad[0] + pad[1] - self.kw) // down + 1
+    self.gpad0_x = self.kw - self.pad0 - 1
+    self.gpad0_y = self.kh - self.pad0 - 1
+    self.gpad1_x = W * up - self.OW * down + self.pad0 - up + 1
+    self.gpad1_y = H * up - self.OH * down + self.pad0 - up + 1
+    self.y = g.new((N, C, self.OH, self.OW), needs_grad=x.needs_grad, name=name)
+    self.inputs = (x,)
+
+  def forward(self, rt):
+    rt.lib.upfirdn2d_f32(rt.v(self.x), rt.v(self.k), rt.v(self.y), self.major, self.H, self.W, 1,
+                         self.kh, self.kw, self.up, self.up, self.down, self.down,
+                         self.pad0, self.pad1, self.pad0, self.pad1, rt.stream)
+
+  def backward(self, rt):
+    gx = rt.g(self.x)
+    if gx is None:
+      return
+    rt.lib.upfirdn2d_acc_f32(rt.g(self.y), rt.v(self.kflip), gx, self.b(self.x), self.major, self.OH, self.OW, 1,
+                             self.kh, self.kw, self.down, self.down, self.up, self.up,
+                             self.gpad0_x, self.gpad1_x, self.gpad0_y, self.gpad1_y, rt.stream)
+
+
+class AddDiv(Op):
+  """out = (a + b) / div -- skip_rescale combines (models/ncsnpp.py:340-343,400-403) and the
+  plain pyramid sum (models/ncsnpp.py:396) with div = 1."""
+
+  def __init__(self, g, a, b, div, name='add'):
+    self.a, self.bt, self.div = a, b, float(div)
+    self.y = g.new(a.shape, name=name)
+    self.inputs = (a, b)
+
+  def forward(self, rt):
+    rt.lib.add_div_f32(rt.v(self.a), rt.v(self.bt), self.div, rt.v(self.y), self.a.numel, rt.stream)
+
+  def backward(self, rt):
+    gy = rt.g(self.y)
+    for t in (self.a, self.bt):
+      gt = rt.g(t)
+      if gt is not None:
+        rt.lib.axpby_f32(gy, 1.0 / self.div, gt, self.b(t), gt, t.numel, rt.stream)
+        # a tensor added to itself would need beta=1 on the second pass
+        if self.a is self.bt:
+          rt.lib.axpby_f32(gy, 1.0 / self.div, gt, 1.0, gt, t.numel, rt.stream)
+          break
+
+
+class AttentionCore(Op):
+  """o = softmax(q^T k / sqrt(C)) applied to v -- the two einsums and the softmax of AttnBlockpp
+  (models/layerspp.py:95-99), q/k/v/o all [B,C,H,W], single head of dimension C."""
+
+  def __init__(self, g, q, k, v, name='attn'):
+    self.q, self.k, self.vv = q, k, v
+    B, C, H, W = q.shape
+    self.B, self.C, self.T = B, C, H * W
+    self.scale = float(int(C) ** (-0.5))
+    self.s = g.new((B, self.T, self.T), needs_grad=False, name=name + '.s')
+    self.p = g.new((B, self.T, self.T), needs_grad=False, name=name + '.p')
+    self.o = g.new(q.shape, name=name + '.o')
+    self.y = self.o
+    self.inputs = (q, k, v)
+
+  def forward(self, rt):
+    B, C, T = self.B, self.C, self.T
+    lib = rt.lib
+    # S[b][t][t'] = sum_c Q[b][c][t] K[b][c][t']
+    lib.gemm_f32(rt.v(self.q), 1, T, C * T, rt.v(self.k), T, 1, C * T, rt.v(self.s), T, 1, T * T,
+                 None, 0, T, T, C, B, 1.0, 0.0, rt.stream)
+    lib.softmax_fwd_f32(rt.v(self.s), rt.v(self.p), B * T, T, self.scale, rt.stream)
+    # O[b][c][t] = sum_t' V[b][c][t'] P[b][t][t']
+    lib.gemm_f32(rt.v(self.vv), T, 1, C * T, rt.v(self.p), 1, T, T * T, rt.v(self.o), T, 1, C * T,
+                 None, 0, C, T, T, B, 1.0, 0.0, rt.stream)
+
+  def backward(self, rt):
+    B, C, T = self.B, self.C, self.T
+    lib = rt.lib
+    go = rt.g(self.o)
+    dp = rt.v(self.s)   # S is dead after the forward softmax: reuse it for dP, then dS
+    # dP[b][t][t'] = sum_c dO[b][c][t] V[b][c][t']
+    lib.gemm_f32(go, 1, T, C * T, rt.v(self.vv), T, 1, C * T, dp, T, 1, T * T,
+                 None, 0, T, T, C, B, 1.0, 0.0, rt.stream)
+    gv = rt.g(self.vv)
+    if gv is not None:  # dV[b][c][t'] = sum_t dO[b][c][t] P[b][t][t']
+      lib.gemm_f32(go, T, 1, C * T, rt.v(self.p), T, 1, T * T, gv, T, 1, C * T,
+                   None, 0, C, T, T, B, 1.0, self.b(self.vv), rt.stream)
+    lib.softmax_bwd_f32(rt.v(self.p), dp, dp, B * T, T, self.scale, rt.stream)   # dS in place
+    gq = rt.g(self.q)
+    if gq is not None:  # dQ[b][c][t] = sum_t' K[b][c][t'] dS[b][t][t']
+      lib.gemm_f32(rt.v(self.k), T, 1, C * T, dp, 1, T, T * T, gq, T, 1, C * T,
+                   None, 0, C, T, T, B, 1.0, self.b(self.q), rt.stream)
+    gk = rt.g(self.k)
+    if gk is not None:  # dK[b][c][t'] = sum_t Q[b][c][t] dS[b][t][t']
+      lib.gemm_f32(rt.v(self.q), T, 1, C * T, dp, T, 1, T * T, gk, T, 1, C * T,
+                   None, 0, C, T, T, B, 1.0, self.b(self.k), rt.stream)
+
+
+class RowScale(Op):
+  """out[n] = x[n] / s[n]  (scale_by_sigma, models/ncsnpp.py:428-430); s carries no gradient."""
+
+  def __init__(self, g, x, s, name='rowscale'):
+    self.x, self.s = x, s
+    self.N = x.shape[0]
+    self.inner = x.numel // self.N
+    self.y = g.new(x.shape, name=name)
+    self.inputs = (x,)
+
+  def forward(self, rt):
+    rt.lib.rowscale_f32(rt.v(self.x), rt.v(self.s), rt.v(self.y), self.N, self.inner, 1, rt.stream)
+
+  def backward(self, rt):
+    gx = rt.g(self.x)
+    if gx is None:
+      return
+    if self.b(self.x) == 0.0:
+      rt.lib.rowscale_f32(rt.g(self.y), rt.v(self.s), gx, self.N, self.inner, 1, rt.stream)
+    else:
+      # accumulate through a scratch row-scale in the workspace
+      rt.lib.rowscale_f32(rt.g(self.y), rt.v(self.s), rt.ws, self.N, self.inner, 1, rt.stream)
+      rt.lib.axpby_f32(rt.ws, 1.0, gx, 1.0, gx, self.x.numel, rt.stream)
+
+  def ws_bytes(self, lib):
+    return 4 * self.x.numel
+
+
+# ------------------------------------------------------------------------------------------------
+# graph
+# ------------------------------------------------------------------------------------------------
+class Graph:
+  """Builder: allocates symbolic tensors, records ops, then plans gradient buffers."""
+
+  def __init__(self, flat):
+    self.flat = flat                  # engine.flat.FlatParams (parameter -> flat offset)
+    self.ops = []
+    self.tensors = []
+    self.act_size = 0
+    self.gact_size = 0
+    self.const_chunks = []
+    self.const_size = 0
+    self.inputs = {}
+    self.output = None
+    self._id = 0
+    self._params = {}
+
+  def next_id(self):
+    self._id += 1
+    return self._id
+
+  def new(self, shape, needs_grad=True, name=''):
+    t = Tensor(shape, 'act', self.act_size, needs_grad, name)
+    self.act_size += _round_up(t.numel)
+    self.tensors.append(t)
+    return t
+
+  def input(self, key, shape, needs_grad=False):
+    t = self.new(shape, needs_grad=needs_grad, name='in.' + key)
+    self.inputs[key] = t
+    return t
+
+  def const(self, array):
+    array = np.ascontiguousarray(array, dtype=np.float32)
+    t = Tensor(array.shape, 'const', self.const_size, False, 'const')
+    self.const_chunks.append((self.const_size, array.reshape(-1)))
+    self.const_size += _round_up(array.size)
+    return t
+
+  def param(self, p):
+    """Tensor bound to an nn.Parameter's slot in the flat parameter / gradient buffers."""
+    if p is None:
+      return None
+    t = self._params.get(id(p))
+    if t is None:
+      off, trainable = self.flat.offset_of(p)
+      t = Tensor(tuple(p.shape), 'param', off, trainable, 'param')
+      t.goff = off if trainable else None
+      self._params[id(p)] = t
+    return t
+
+  def add(self, op):
+    self.ops.append(op)
+    return op.y
+
+  # -- convenience emitters -------------------------------------------------------------------
+  def gn_act(self, x1, x2, gn, act=True, drop_p=0.0, name='gn'):
+    op = GroupNormAct(self, x1, x2, self.param(gn.weight), self.param(gn.bias), gn.num_groups, gn.eps,
+                      act, drop_p, name)
+    return self.add(op)
+
+  def conv(self, x1, x2, weight, bias, w_layout=0, stride=1, pad=None, out_hw=None,
+           temb=None, temb_col=0, res=None, out_div=1.0, name='conv'):
+    if w_layout == 0:
+      Cout, _, KH, KW = weight.shape
+    else:
+      _, Cout = weight.shape
+      KH = KW = 1
+    if pad is None:
+      pad = KH // 2
+    H, W = x1.shape[2], x1.shape[3]
+    if out_hw is None:
+      OH = (H + 2 * pad - KH) // stride + 1
+      OW = (W + 2 * pad - KW) // stride + 1
+    else:
+      OH, OW = out_hw
+    op = Conv(self, x1, x2, self.param(weight), self.param(bias), w_layout, Cout, KH, KW, stride, pad, OH, OW,
+              temb=temb, temb_col=temb_col, res=res, out_div=out_div, name=name)
+    return self.add(op)
+
+  def linear(self, x, weight, bias, name='linear'):
+    return self.add(Linear(self, x, self.param(weight), self.param(bias), name))
+
+  def linear_t(self, x, w_tensor, b_tensor, name='linear'):
+    return self.add(Linear(self, x, w_tensor, b_tensor, name))
+
+  def silu(self, x, name='silu'):
+    return self.add(SiLU(self, x, name))
+
+  # -- planning -----------------------------------------------------------------------------------
+  def finalize(self, output, lib):
+    self.output = output
+    output.external_grad = True
+    for t in self.tensors:
+      if t.needs_grad:
+        t.goff = self.gact_size
+        self.gact_size += _round_up(t.numel)
+    for op in reversed(self.ops):
+      op.plan_backward()
+    self.ws_bytes = max([256] + [op.ws_bytes(lib) for op in self.ops])
+    self.ws_bytes = _round_up(self.ws_bytes, 256)
+    return self

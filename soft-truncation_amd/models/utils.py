@@ -1,0 +1,152 @@
+"""Model registry and the score-function wrappers (reference: models/utils.py).
+
+Kept verbatim at the interface level so a ``run_lib.py``-style driver works unchanged:
+``register_model`` / ``get_model`` (:25-48), ``get_sigmas`` (:51-62), ``get_ddpm_params`` (:65-86),
+``create_model`` (:89-95), ``get_model_fn`` (:97-126), ``get_score_fn`` (:128-190) and the
+flatten helpers (:193-200).
+
+MI355X-specific difference, by design: the reference wraps the model in
+``torch.nn.DataParallel`` (one process, threads, per-forward broadcast of all 247 MB of
+parameters).  Here every GPU runs its own process; :class:`DataParallel` below only keeps the
+``module.`` key prefix of the reference's checkpoints and, when ``torch.distributed`` is
+initialised, averages gradients with one bucketed RCCL all-reduce per step
+(see ``engine/ddp.py``).
+"""
+import numpy as np
+import torch
+
+from .. import sde_lib
+
+_MODELS = {}
+
+
+def register_model(cls=None, *, name=None):
+  """Decorator registering a model class under ``name`` (default: the class name)."""
+
+  def _register(cls):
+    local_name = cls.__name__ if name is None else name
+    if local_name in _MODELS:
+      raise ValueError(f'Already registered model with name: {local_name}')
+    _MODELS[local_name] = cls
+    return cls
+
+  return _register if cls is None else _register(cls)
+
+
+def get_model(name):
+  return _MODELS[name]
+
+
+def get_sigmas(config):
+  """Geometric ladder of SMLD noise levels, sigma_max -> sigma_min (models/utils.py:51-62)."""
+  return np.exp(np.linspace(np.log(config.model.sigma_max), np.log(config.model.sigma_min),
+                            config.model.num_scales))
+
+
+def get_ddpm_params(config):
+  """DDPM beta/alpha tables (models/utils.py:65-86)."""
+  num_diffusion_timesteps = 1000
+  beta_start = config.model.beta_min / config.model.num_scales
+  beta_end = config.model.beta_max / config.model.num_scales
+  betas = np.linspace(beta_start, beta_end, num_diffusion_timesteps, dtype=np.float64)
+  alphas = 1. - betas
+  alphas_cumprod = np.cumprod(alphas, axis=0)
+  return {
+    'betas': betas,
+    'alphas': alphas,
+    'alphas_cumprod': alphas_cumprod,
+    'sqrt_alphas_cumprod': np.sqrt(alphas_cumprod),
+    'sqrt_1m_alphas_cumprod': np.sqrt(1. - alphas_cumprod),
+    'beta_min': beta_start * (num_diffusion_timesteps - 1),
+    'beta_max': beta_end * (num_diffusion_timesteps - 1),
+    'num_diffusion_timesteps': num_diffusion_timesteps,
+  }
+
+
+class DataParallel(torch.nn.Module):
+  """Single-device stand-in for ``torch.nn.DataParallel`` (models/utils.py:94).
+
+  state_dict keys keep the ``module.`` prefix of the reference's checkpoints.  Data
+  parallelism is one process per GPU: gradient exchange happens in ``losses.optimize_fn`` via
+  ``engine.ddp`` when a process group exists, never by replicating the module across threads.
+  """
+
+  def __init__(self, module):
+    super().__init__()
+    self.module = module
+
+  def forward(self, *args, **kwargs):
+    return self.module(*args, **kwargs)
+
+
+def create_model(config, sde):
+  """Instantiate ``config.model.name`` on ``config.device`` (models/utils.py:89-95)."""
+  score_model = get_model(config.model.name)(config, sde)
+  score_model = score_model.to(config.device)
+  return DataParallel(score_model)
+
+
+def get_model_fn(model, train=False):
+  """Callable running the model in train or eval mode (models/utils.py:97-126)."""
+
+  def model_fn(x, labels):
+    if not train:
+      model.eval()
+    else:
+      model.train()
+    return model(x, labels)
+
+  return model_fn
+
+
+def get_score_fn(config, sde, model, train=False, continuous=False):
+  """Turn the raw network into a score function s(x, t) (models/utils.py:128-190).
+
+  VP / subVP: labels = 999 t (continuous), score = -net/std when ``training.ddpm_score``;
+  VE / RVE:   labels = sigma(t) (continuous), the network output is already the score.
+  """
+  model_fn = get_model_fn(model, train=train)
+
+  if isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE)):
+    def score_fn(x, t, logsnr_model=None, logsnr=None):
+      if continuous or isinstance(sde, sde_lib.subVPSDE):
+        if config.training.unbounded_parametrization:
+          sc = config.training.stabilizing_constant
+          a0 = sde.antiderivative(1e-5, stabilizing_constant=sc)
+          labels = (sde.antiderivative(t, stabilizing_constant=sc) - a0) / \
+                   (sde.antiderivative(sde.T, stabilizing_constant=sc) - a0) * 999.
+        else:
+          labels = t * 999
+        std = sde.marginal_prob(torch.zeros_like(x), t)[1]
+        score = model_fn(x, labels)
+      else:
+        labels = t * (sde.N - 1)
+        score = model_fn(x, labels)
+        std = sde.sqrt_1m_alphas_cumprod.to(labels.device)[labels.long()]
+
+      if config.training.ddpm_score:
+        score = - score / std[:, None, None, None]
+      return score
+
+  elif isinstance(sde, (sde_lib.VESDE, sde_lib.reciprocal_VESDE)):
+    def score_fn(x, t):
+      if continuous:
+        labels = sde.marginal_prob(torch.zeros_like(x), t)[1]
+      else:
+        labels = sde.T - t
+        labels *= sde.N - 1
+        labels = torch.round(labels).long()
+      return model_fn(x, labels)
+
+  else:
+    raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+
+  return score_fn
+
+
+def to_flattened_numpy(x):
+  return x.detach().cpu().numpy().reshape((-1,))
+
+
+def from_flattened_numpy(x, shape):
+  return torch.from_numpy(x.reshape(shape))

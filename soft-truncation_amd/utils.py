@@ -1,0 +1,73 @@
+"""Driver glue on the boundary of the hot path (reference: utils.py:13-82).
+
+``restore_checkpoint`` / ``save_checkpoint`` keep the reference's on-disk layout -- a
+``torch.save`` of ``{'optimizer', 'model', 'ema', 'step'}`` with ``module.``-prefixed model keys and
+``ema.shadow_params`` as a list of tensors -- so checkpoints are interchangeable.
+``load_model`` and ``get_loss_fns`` reproduce what ``run_lib.train`` calls before its loop
+(run_lib.py:51-66).  The TensorFlow file API of the reference (``tf.io.gfile``) is replaced by
+``os``; likelihood evaluators are outside the hot path and are not provided.
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import losses, sampling
+from .models import utils as mutils
+from .models.ema import ExponentialMovingAverage
+
+
+def restore_checkpoint(config, ckpt_dir, state, device):
+  if not os.path.exists(ckpt_dir):
+    os.makedirs(os.path.dirname(ckpt_dir), exist_ok=True)
+    logging.warning(f"No checkpoint found at {ckpt_dir}. Returned the same state as input")
+    return state
+  logging.info(ckpt_dir + ' loaded ...')
+  loaded_state = torch.load(ckpt_dir, map_location=device, weights_only=False)
+  state['optimizer'].load_state_dict(loaded_state['optimizer'])
+  state['model'].load_state_dict(loaded_state['model'], strict=False)
+  state['ema'].load_state_dict(loaded_state['ema'])
+  state['step'] = loaded_state['step']
+  return state
+
+
+def save_checkpoint(config, ckpt_dir, state):
+  saved_state = {
+    'optimizer': state['optimizer'].state_dict(),
+    'model': state['model'].state_dict(),
+    'ema': state['ema'].state_dict(),
+    'step': state['step'],
+  }
+  torch.save(saved_state, ckpt_dir)
+
+
+def load_model(config, workdir, print_=True, sde=None):
+  """Model + optimizer + EMA + (resumed) step (utils.py:49-73)."""
+  score_model = mutils.create_model(config, sde)
+  optimizer = losses.get_optimizer(config, score_model.parameters())
+  ema = ExponentialMovingAverage(score_model.parameters(), decay=config.model.ema_rate)
+  state = dict(optimizer=optimizer, model=score_model, ema=ema, step=0)
+  if print_:
+    model_params = sum(np.prod(p.size()) for p in score_model.parameters() if p.requires_grad)
+    total_num_params = sum(np.prod(p.size()) for p in score_model.parameters())
+    logging.info(f"model parameters: {model_params}")
+    logging.info(f"total number of parameters: {total_num_params}")
+  checkpoint_dir = os.path.join(workdir, "checkpoints")
+  checkpoint_meta_dir = os.path.join(workdir, "checkpoints-meta", "checkpoint.pth")
+  os.makedirs(checkpoint_dir, exist_ok=True)
+  os.makedirs(os.path.dirname(checkpoint_meta_dir), exist_ok=True)
+  state = restore_checkpoint(config, checkpoint_meta_dir, state, config.device)
+  return state, score_model, ema, checkpoint_dir, checkpoint_meta_dir
+
+
+def get_loss_fns(config, sde, inverse_scaler, train=True):
+  """(train_step_fn, nll_fn, nelbo_fn, sampling_fn) as in utils.py:75-82; the two likelihood
+  evaluators belong to likelihood.py (outside this path) and are returned as None."""
+  optimize_fn = losses.optimization_manager(config)
+  train_step_fn = losses.get_step_fn(config, sde, train=train, optimize_fn=optimize_fn)
+  sampling_shape = (config.sampling.batch_size, config.data.num_channels,
+                    config.data.image_size, config.data.image_size)
+  sampling_fn = sampling.get_sampling_fn(config, sde, sampling_shape, inverse_scaler,
+                                         config.sampling.truncation_time)
+  return train_step_fn, None, None, sampling_fn
