@@ -153,9 +153,11 @@ int stk_resample_naive_f32(const float* in, float* out, long planes, int H, int 
                            float alpha, float beta, void* stream);
 /* out[n, :] = mode==0 ? x[n,:]*s[n] : x[n,:]/s[n]   (scale_by_sigma, models/ncsnpp.py:428-430) */
 int stk_rowscale_f32(const float* x, const float* s, float* out, int N, long inner, int mode, void* stream);
-/* positional embedding: out[b, j] = sin(t_b f_j), out[b, half + j] = cos(t_b f_j),
- * f_j = exp(-j ln(max_positions)/(half-1)); dim odd -> last column 0 (models/layers.py:515-529) */
-int stk_timestep_embedding_f32(const float* t, float* out, int B, int dim, float max_positions, void* stream);
+/* positional embedding: out[b, j] = sin(t_b f_j), out[b, half + j] = cos(t_b f_j), half = dim/2;
+ * dim odd -> last column 0 (models/layers.py:515-529).  The frequency table
+ * f_j = exp(-j ln(10000)/(half-1)) is supplied by the host (freqs[half]): t_b reaches 999, so a 1-ulp
+ * difference between two exp implementations would be amplified ~1000x in the sin/cos argument. */
+int stk_timestep_embedding_f32(const float* t, const float* freqs, float* out, int B, int dim, void* stream);
 /* Gaussian Fourier features: p = x_b * W_j * 2 * pi; out[b,j] = sin p, out[b,nf+j] = cos p */
 int stk_fourier_embedding_f32(const float* x, const float* W, float* out, int B, int nf, void* stream);
 /* out[n,:] = a[n]*x[n,:] + s[n]*z[n,:]   (perturbation kernel x_t = mean + std*z, losses.py:118-119) */

@@ -1,0 +1,284 @@
+// groupnorm.hip -- GroupNorm (+SiLU) (+dropout), forward and backward, for gfx950.
+//
+// Replaces the nn.GroupNorm -> nn.SiLU -> nn.Dropout chains of the reference
+// (models/layerspp.py:232,244-245,256,277-278; AttnBlockpp :80,90; models/ncsnpp.py:378-422) with one
+// kernel per direction.  The op is HBM-bound: in NCHW one (sample, group) is a contiguous run of
+// (C/G)*H*W floats, so a workgroup owns one (sample, group) and streams it with float4 lanes.
+//
+//  * The input may be the channel-concat of two tensors (the skip connections of the up path,
+//    models/ncsnpp.py:368); the concat is never materialised: a group is at most two contiguous
+//    segments, one in each source.
+//  * Statistics use shifted sums (shift = first element of the group) so that a single pass gives
+//    mean and variance without the cancellation of E[x^2]-E[x]^2; wave64 shuffles reduce inside a
+//    wave, LDS across the 4 waves.
+//  * The normalisation pass re-reads the group right after the statistics pass; a group is
+//    16 KB - 1 MB, so the second read is served by the XCD's 4 MB L2 / the 256 MB Infinity Cache
+//    rather than HBM (algorithmic traffic: one read + one write of the tensor).
+//  * Dropout is a counter-based mask, a pure function of (seed, flat element index) (stk_rng.h), so the
+//    backward pass regenerates it instead of storing it.
+//  * backward: per (sample, group) workgroup computes the per-channel partial sums of d(gamma),
+//    d(beta) into a [N,C,2] scratch and dx; a second tiny kernel folds the scratch over N.
+#include "common.h"
+
+namespace {
+
+struct GnArgs {
+  const float* x1; const float* x2;
+  int C1, C2;
+  const float* gamma; const float* beta;
+  int N, HW, G, cpg;
+  int act; float drop_p; float keep_scale;
+  unsigned long long seed; const unsigned long long* seed_dev;
+};
+
+// Segment decomposition of group (n, g): channels [c0, c1) -> part in x1, part in x2.
+struct Seg {
+  const float* p; int len; int c_first;   // len in floats, first channel index (global)
+};
+__device__ __forceinline__ void group_segments(const GnArgs& a, int n, int g, Seg (&s)[2]) {
+  const int c0 = g * a.cpg, c1 = c0 + a.cpg;
+  const int e1 = min(c1, a.C1);
+  if (c0 < a.C1) {
+    s[0].p = a.x1 + ((long)n * a.C1 + c0) * a.HW;
+    s[0].len = (e1 - c0) * a.HW;
+    s[0].c_first = c0;
+  } else {
+    s[0].p = nullptr; s[0].len = 0; s[0].c_first = c0;
+  }
+  const int b2 = max(c0, a.C1);
+  if (c1 > a.C1) {
+    s[1].p = a.x2 + ((long)n * a.C2 + (b2 - a.C1)) * a.HW;
+    s[1].len = (c1 - b2) * a.HW;
+    s[1].c_first = b2;
+  } else {
+    s[1].p = nullptr; s[1].len = 0; s[1].c_first = c1;
+  }
+}
+
+__device__ __forceinline__ float silu_f(float u) { return u / (1.f + expf(-u)); }
+
+// ---- forward ------------------------------------------------------------------------------------
+// VEC: 4 when HW % 4 == 0 and all pointers are 16-B aligned, else 1.
+template <int VEC>
+__global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs a, float* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, float eps) {
+  __shared__ float red[16];
+  const int ng = blockIdx.x;
+  const int n = ng / a.G, g = ng - n * a.G;
+  Seg seg[2];
+  group_segments(a, n, g, seg);
+  const int L = a.cpg * a.HW;
+  const float shift = seg[0].len ? seg[0].p[0] : seg[1].p[0];
+
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float* p = seg[q].p;
+    const int len = seg[q].len;
+    if (VEC == 4) {
+      const float4* p4 = reinterpret_cast<const float4*>(p);
+      for (int i = threadIdx.x; i < (len >> 2); i += 256) {
+        const float4 v = p4[i];
+        const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+        s[0] += (d0 + d1) + (d2 + d3);
+        s[1] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    } else {
+      for (int i = threadIdx.x; i < len; i += 256) {
+        const float d = p[i] - shift;
+        s[0] += d;
+        s[1] += d * d;
+      }
+    }
+  }
+  block_sum<2>(s, red);
+  const float inv_l = 1.f / (float)L;
+  const float md = s[0] * inv_l;                       // mean - shift
+  const float var = fmaxf(s[1] * inv_l - md * md, 0.f);
+  const float mean = shift + md;
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_out[ng] = mean;
+    rstd_out[ng] = rstd;
+  }
+
+  unsigned long long seed = a.seed;
+  if (a.drop_p > 0.f && a.seed_dev) seed += *a.seed_dev;
+  const int C = a.C1 + a.C2;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float* p = seg[q].p;
+    const int len = seg[q].len;
+    if (!len) continue;
+    float* o = y + ((long)n * C + seg[q].c_first) * a.HW;
+    const unsigned long long flat0 = ((unsigned long long)n * C + seg[q].c_first) * a.HW;
+    if (VEC == 4) {
+      const float4* p4 = reinterpret_cast<const float4*>(p);
+      float4* o4 = reinterpret_cast<float4*>(o);
+      for (int i = threadIdx.x; i < (len >> 2); i += 256) {
+        const int c = seg[q].c_first + (i * 4) / a.HW;
+        const float ga = a.gamma[c], be = a.beta[c];
+        const float4 v = p4[i];
+        float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float u = ga * ((r[j] - mean) * rstd) + be;
+          float t = a.act ? silu_f(u) : u;
+          if (a.drop_p > 0.f) t = (stk_uniform(seed, flat0 + (unsigned long long)(i * 4 + j)) >= a.drop_p) ? t * a.keep_scale : 0.f;
+          r[j] = t;
+        }
+        o4[i] = make_float4(r[0], r[1], r[2], r[3]);
+      }
+    } else {
+      for (int i = threadIdx.x; i < len; i += 256) {
+        const int c = seg[q].c_first + i / a.HW;
+        float u = a.gamma[c] * ((p[i] - mean) * rstd) + a.beta[c];
+        float t = a.act ? silu_f(u) : u;
+        if (a.drop_p > 0.f) t = (stk_uniform(seed, flat0 + (unsigned long long)i) >= a.drop_p) ? t * a.keep_scale : 0.f;
+        o[i] = t;
+      }
+    }
+  }
+}
+
+// ---- backward -------------------------------------------------------------------------------------
+// du = dy * mask * act'(u);  dgamma_c = sum du*xhat;  dbeta_c = sum du;
+// dx = rstd * (du*gamma - mean_g(du*gamma) - xhat * mean_g(du*gamma*xhat))
+__device__ __forceinline__ float gn_du(const GnArgs& a, float xv, float dyv, float mean, float rstd, float ga, float be,
+                                       unsigned long long seed, unsigned long long flat, float& xhat) {
+  xhat = (xv - mean) * rstd;
+  float go = dyv;
+  if (a.drop_p > 0.f) go = (stk_uniform(seed, flat) >= a.drop_p) ? go * a.keep_scale : 0.f;
+  if (a.act) {
+    const float u = ga * xhat + be;
+    const float sg = 1.f / (1.f + expf(-u));
+    go = go * (sg * (1.f + u * (1.f - sg)));
+  }
+  return go;
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_kernel(GnArgs a, const float* __restrict__ dy,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     float* __restrict__ dx1, float beta1, float* __restrict__ dx2,
+                                                     float beta2, float* __restrict__ ws) {
+  __shared__ float red[16];
+  const int ng = blockIdx.x;
+  const int n = ng / a.G, g = ng - n * a.G;
+  const int C = a.C1 + a.C2;
+  const float mean = mean_in[ng], rstd = rstd_in[ng];
+  unsigned long long seed = a.seed;
+  if (a.drop_p > 0.f && a.seed_dev) seed += *a.seed_dev;
+
+  // pass A: per-channel sums (channel loop; each channel is one contiguous HW run)
+  float gs[2] = {0.f, 0.f};   // group sums of du*gamma and du*gamma*xhat (thread-partial)
+  for (int c = g * a.cpg; c < (g + 1) * a.cpg; ++c) {
+    const float* xp = c < a.C1 ? a.x1 + ((long)n * a.C1 + c) * a.HW : a.x2 + ((long)n * a.C2 + (c - a.C1)) * a.HW;
+    const float* dp = dy + ((long)n * C + c) * a.HW;
+    const unsigned long long flat0 = ((unsigned long long)n * C + c) * a.HW;
+    const float ga = a.gamma[c], be = a.beta[c];
+    float cs[2] = {0.f, 0.f};
+    for (int i = threadIdx.x; i < a.HW; i += 256) {
+      float xhat;
+      const float du = gn_du(a, xp[i], dp[i], mean, rstd, ga, be, seed, flat0 + i, xhat);
+      cs[0] += du;
+      cs[1] += du * xhat;
+    }
+    gs[0] += cs[0] * ga;
+    gs[1] += cs[1] * ga;
+    block_sum<2>(cs, red);
+    if (threadIdx.x == 0) {
+      ws[((long)n * C + c) * 2 + 0] = cs[0];
+      ws[((long)n * C + c) * 2 + 1] = cs[1];
+    }
+  }
+  block_sum<2>(gs, red);
+  const float inv_l = 1.f / ((float)a.cpg * (float)a.HW);
+  const float m1 = gs[0] * inv_l, m2 = gs[1] * inv_l;
+
+  // pass B: dx
+  for (int c = g * a.cpg; c < (g + 1) * a.cpg; ++c) {
+    const float* xp; float* op; float ob;
+    if (c < a.C1) {
+      xp = a.x1 + ((long)n * a.C1 + c) * a.HW;
+      op = dx1 ? dx1 + ((long)n * a.C1 + c) * a.HW : nullptr;
+      ob = beta1;
+    } else {
+      xp = a.x2 + ((long)n * a.C2 + (c - a.C1)) * a.HW;
+      op = dx2 ? dx2 + ((long)n * a.C2 + (c - a.C1)) * a.HW : nullptr;
+      ob = beta2;
+    }
+    if (!op) continue;
+    const float* dp = dy + ((long)n * C + c) * a.HW;
+    const unsigned long long flat0 = ((unsigned long long)n * C + c) * a.HW;
+    const float ga = a.gamma[c], be = a.beta[c];
+    for (int i = threadIdx.x; i < a.HW; i += 256) {
+      float xhat;
+      const float du = gn_du(a, xp[i], dp[i], mean, rstd, ga, be, seed, flat0 + i, xhat);
+      const float r = rstd * (du * ga - m1 - xhat * m2);
+      op[i] = (ob != 0.f ? ob * op[i] : 0.f) + r;
+    }
+  }
+}
+
+// dgamma[c] += sum_n ws[n,c,1];  dbeta[c] += sum_n ws[n,c,0]
+__global__ void gn_param_grad_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int N, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float sb = 0.f, sg = 0.f;
+  for (int n = 0; n < N; ++n) {
+    sb += ws[((long)n * C + c) * 2 + 0];
+    sg += ws[((long)n * C + c) * 2 + 1];
+  }
+  if (dgamma) dgamma[c] += sg;
+  if (dbeta) dbeta[c] += sb;
+}
+
+}  // namespace
+
+extern "C" {
+
+int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
+                   float* mean, float* rstd, int N, int HW, int G, float eps, int act, float drop_p,
+                   unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
+  const int C = C1 + C2;
+  if (!x1 || !gamma || !beta || !y || !mean || !rstd || N <= 0 || HW <= 0 || G <= 0 || C1 <= 0 || C2 < 0 || C % G ||
+      (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f)
+    return STK_EINVAL;
+  GnArgs a;
+  a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
+  a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p);
+  a.seed = seed; a.seed_dev = seed_dev;
+  const bool vec = (HW & 3) == 0 && stk_aligned16(x1) && stk_aligned16(y) && (!x2 || stk_aligned16(x2));
+  if (vec)
+    hipLaunchKernelGGL((gn_fwd_kernel<4>), dim3(N * G), dim3(256), 0, (hipStream_t)stream, a, y, mean, rstd, eps);
+  else
+    hipLaunchKernelGGL((gn_fwd_kernel<1>), dim3(N * G), dim3(256), 0, (hipStream_t)stream, a, y, mean, rstd, eps);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+
+int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, int C2, const float* gamma,
+                   const float* beta, const float* mean, const float* rstd, float* dx1, float dx1_beta, float* dx2,
+                   float dx2_beta, float* dgamma, float* dbeta, float* ws, int N, int HW, int G, int act, float drop_p,
+                   unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
+  const int C = C1 + C2;
+  if (!dy || !x1 || !gamma || !beta || !mean || !rstd || !ws || N <= 0 || HW <= 0 || G <= 0 || C1 <= 0 || C2 < 0 ||
+      C % G || (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f)
+    return STK_EINVAL;
+  GnArgs a;
+  a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
+  a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p);
+  a.seed = seed; a.seed_dev = seed_dev;
+  hipLaunchKernelGGL(gn_bwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, dx1_beta,
+                     dx2, dx2_beta, ws);
+  STK_CHECK_LAUNCH();
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(stk_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, ws, dgamma,
+                       dbeta, N, C);
+    STK_CHECK_LAUNCH();
+  }
+  return STK_OK;
+}
+
+}  // extern "C"

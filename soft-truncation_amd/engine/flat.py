@@ -26,6 +26,8 @@ class FlatParams:
     """params: ordered list of nn.Parameter.  groups: lists of parameters that must be laid out
     contiguously and unpadded, in order (e.g. all Dense_0 weights)."""
     self.device = torch.device(device)
+    params = list(params)
+    self.module_order = params      # the order of model.parameters(): what state_dicts / EMA lists use
     seen = set()
     order = []
     self.group_ranges = []
@@ -103,16 +105,17 @@ class FlatParams:
           p.grad.zero_()
 
   def trainable_views(self, flat):
-    """Per-parameter views of another flat buffer with the same layout (Adam moments, EMA)."""
+    """Per-parameter views of another flat buffer with the same layout (Adam moments, EMA), in
+    ``model.parameters()`` order (the order of the reference's ``shadow_params`` list)."""
     out = []
-    for p in self.params:
+    for p in self.module_order:
       o, n, tr = self._slot[id(p)]
       if tr:
         out.append(flat[o:o + n].view(p.shape))
     return out
 
   def trainable_params(self):
-    return [p for p in self.params if self._slot[id(p)][2]]
+    return [p for p in self.module_order if self._slot[id(p)][2]]
 
 
 def flat_of(params):

@@ -252,12 +252,17 @@ class SiLU(Op):
 class TimestepEmbedding(Op):
   """layers.get_timestep_embedding (models/layers.py:515-529); no parameters, no gradient."""
 
-  def __init__(self, g, t, dim, name='temb.pos'):
+  def __init__(self, g, t, dim, max_positions=10000, name='temb.pos'):
+    import torch
     self.t, self.dim = t, dim
+    half = dim // 2
+    # frequency table evaluated exactly as the reference does on the host (torch.exp of an f32 ramp)
+    e = math.log(max_positions) / (half - 1)
+    self.freqs = g.const(torch.exp(torch.arange(half, dtype=torch.float32) * -e).numpy())
     self.y = g.new((t.shape[0], dim), needs_grad=False, name=name)
 
   def forward(self, rt):
-    rt.lib.timestep_embedding_f32(rt.v(self.t), rt.v(self.y), self.t.shape[0], self.dim, 10000.0, rt.stream)
+    rt.lib.timestep_embedding_f32(rt.v(self.t), rt.v(self.freqs), rt.v(self.y), self.t.shape[0], self.dim, rt.stream)
 
   def backward(self, rt):
     pass

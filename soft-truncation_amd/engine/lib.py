@@ -46,7 +46,7 @@ SIGNATURES = {
   'stk_affine_f32': [P, F, F, P, L, S],
   'stk_resample_naive_f32': [P, P, L, I, I, I, F, F, S],
   'stk_rowscale_f32': [P, P, P, I, L, I, S],
-  'stk_timestep_embedding_f32': [P, P, I, I, F, S],
+  'stk_timestep_embedding_f32': [P, P, P, I, I, S],
   'stk_fourier_embedding_f32': [P, P, P, I, I, S],
   'stk_perturb_f32': [P, P, P, P, P, I, L, S],
   'stk_sm_loss_fwd_f32': [P, P, P, P, P, I, L, I, I, I, S],

@@ -51,10 +51,11 @@ def optimization_manager(config):
 
   def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup,
                   grad_clip=config.optim.grad_clip):
+    params = list(params)
     if warmup > 0:
       for g in optimizer.param_groups:
         g['lr'] = lr * np.minimum(step / warmup, 1.0)
-    ddp.sync_gradients(optimizer, None if hasattr(optimizer, 'clip_grad_norm') else list(params))
+    ddp.sync_gradients(optimizer, None if hasattr(optimizer, 'clip_grad_norm') else params)
     if grad_clip >= 0:
       if hasattr(optimizer, 'clip_grad_norm'):
         optimizer.clip_grad_norm(grad_clip)

@@ -1,0 +1,188 @@
+"""Model-level parity cases, shared by the CPU host-logic tests (checker backend) and the GPU parity
+tests (HIP backend).  Every case compares the product path -- NCSNpp.forward on the planned-graph
+engine, FusedAdam, the fused EMA, the samplers -- with the oracle RefNet driven by the same host code
+and torch's own Adam, on identical inputs and explicitly injected noise.
+
+Tolerance: the north star asks for loss/score tensors within 1e-3 relative (fp32) of the reference's
+CPU path; the kernels are exact-fp32 MFMA, so the tests hold a tighter 2e-4.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from _model_util import build_pair, grads_close, make_state, patched_rng, rel_err, tiny_config
+
+TOL = 2e-4
+
+
+def _inputs(cfg, sde, B, seed=1):
+  g = torch.Generator().manual_seed(seed)
+  H = cfg.data.image_size
+  x = torch.randn(B, cfg.data.num_channels, H, H, generator=g)
+  t = torch.rand(B, generator=g) * 0.9 + 0.05
+  if cfg.model.embedding_type == 'positional':
+    cond = t * 999
+  else:
+    cond = sde.marginal_prob(x, t)[1]
+  return x, t, cond
+
+
+def forward_backward(st, lib, family):
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, family), lib)
+  dev = cfg.device
+  x, t, cond = _inputs(cfg, sde, 3)
+  model.eval(); ref.eval()
+  xg = x.clone().to(dev).requires_grad_(True)
+  y = model(xg, cond.to(dev))
+  xr = x.clone().requires_grad_(True)
+  yr = ref(xr, cond)
+  assert rel_err(y, yr) <= TOL, f'forward mismatch {rel_err(y, yr):.3e}'
+  go = torch.randn(yr.shape, generator=torch.Generator().manual_seed(5))
+  (y * go.to(dev)).sum().backward()
+  (yr * go).sum().backward()
+  assert rel_err(xg.grad, xr.grad) <= TOL, f'input-gradient mismatch {rel_err(xg.grad, xr.grad):.3e}'
+  grads_close(model, ref, TOL)
+  # a second forward under no_grad (sampling path) gives the same values
+  with torch.no_grad():
+    y2 = model(x.to(dev), cond.to(dev))
+  assert torch.equal(y2, y.detach())
+
+
+def score_fn_parity(st, lib, family):
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, family), lib)
+  dev = cfg.device
+  x, t, _ = _inputs(cfg, sde, 2)
+  s = st.models.utils.get_score_fn(cfg, sde, model, train=False, continuous=True)(x.to(dev), t.to(dev))
+  sr = st.models.utils.get_score_fn(cfg_cpu, sde, ref, train=False, continuous=True)(x, t)
+  assert rel_err(s, sr) <= TOL
+
+
+def train_steps(st, lib, family, steps=3, num_micro_batch=1, mixed=False):
+  base = tiny_config(st, family)
+  base.optim.num_micro_batch = num_micro_batch
+  base.optim.warmup = 2
+  base.training.mixed = mixed
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, base, lib)
+  dev = cfg.device
+  state = make_state(st, cfg, model)
+  assert type(state['optimizer']).__name__ == 'FusedAdam'
+  state['optimizer']._backend = lib
+  state['ema'].set_backend(lib)
+  rstate = make_state(st, cfg_cpu, ref)
+  assert type(rstate['optimizer']).__name__ == 'Adam'
+  step_fn = st.losses.get_step_fn(cfg, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg))
+  rstep_fn = st.losses.get_step_fn(cfg_cpu, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg_cpu))
+  B = 4
+  for i in range(steps):
+    batch = st.datasets.synthetic_batch(cfg_cpu, B, generator=torch.Generator().manual_seed(100 + i))
+    np.random.seed(7 + i)
+    with patched_rng(50 + i):
+      loss = step_fn(state, batch.to(dev))
+    np.random.seed(7 + i)
+    with patched_rng(50 + i):
+      rloss = rstep_fn(rstate, batch)
+    assert loss.device.type == 'cpu' and loss.shape == rloss.shape
+    assert rel_err(loss, rloss) <= TOL, f'step {i}: loss mismatch {rel_err(loss, rloss):.3e}'
+  assert state['step'] == rstate['step'] == steps
+  # parameters after `steps` Adam updates.  Adam normalises the gradient (m/sqrt(v)), which amplifies
+  # round-off in entries whose gradient is ~0, so parameters are compared in units of the total update.
+  lr = cfg.optim.lr
+  for (k, p), (rk, rp) in zip(model.named_parameters(), ref.named_parameters()):
+    if not p.requires_grad:
+      continue
+    d = (p.detach().cpu() - rp.detach()).abs().max().item()
+    assert d <= 0.05 * lr * steps + 1e-7, f'{k}: parameter drift {d:.3e} after {steps} steps'
+  for s, rs in zip(state['ema'].shadow_params, rstate['ema'].shadow_params):
+    assert (s.detach().cpu() - rs).abs().max().item() <= 0.05 * lr * steps + 1e-7
+  return state, rstate
+
+
+def dropout_consistency(st, lib):
+  """With dropout on, forward and backward must use the SAME mask: check the gradient of a training
+  forward by finite differences through the frozen mask (same seed via the same torch CPU draw)."""
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, 'vp', dropout=0.3), lib)
+  dev = cfg.device
+  x, t, cond = _inputs(cfg, sde, 2)
+  model.train()
+  go = torch.randn(x.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+
+  def f(xin):
+    torch.manual_seed(123)            # the engine draws its per-call dropout seed from torch's CPU generator
+    return (model(xin, cond.to(dev)) * go).sum()
+
+  xg = x.clone().to(dev).requires_grad_(True)
+  f(xg).backward()
+  v = torch.randn(x.shape, generator=torch.Generator().manual_seed(6)).to(dev)
+  eps = 1e-2
+  with torch.no_grad():
+    fd = (f(xg.detach() + eps * v) - f(xg.detach() - eps * v)).item() / (2 * eps)
+  an = (xg.grad * v).sum().item()
+  assert abs(fd - an) <= 2e-2 * max(abs(an), abs(fd), 1e-3), (fd, an)
+  # and eval mode ignores dropout entirely
+  model.eval(); ref.eval()
+  with torch.no_grad():
+    assert rel_err(model(x.to(dev), cond.to(dev)), ref(x, cond)) <= TOL
+
+
+def pc_sampler_steps(st, lib, family, n=3):
+  """A few iterations of the PC loop + the denoising step, product vs oracle, same noise."""
+  base = tiny_config(st, family)
+  if family == 'vp':
+    base.sampling.method, base.sampling.predictor, base.sampling.corrector = 'pc', 'euler_maruyama', 'none'
+  elif family == 've':
+    base.sampling.method, base.sampling.predictor, base.sampling.corrector = 'pc', 'reverse_diffusion', 'langevin'
+  else:
+    raise ValueError('RVE PC sampling raises in the reference (SURVEY.md a6)')
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, base, lib)
+  sde.N = n      # shorten the loop (the sigma / beta ladders keep their configured length)
+  shape = (2, cfg.data.num_channels, cfg.data.image_size, cfg.data.image_size)
+  inv = st.datasets.get_data_inverse_scaler(cfg)
+  fn = st.sampling.get_sampling_fn(cfg, sde, shape, inv, 1e-3)
+  rfn = st.sampling.get_sampling_fn(cfg_cpu, sde, shape, inv, 1e-3)
+  with patched_rng(11):
+    xs, nfe = fn(model)
+  with patched_rng(11):
+    xr, rnfe = rfn(ref)
+  assert nfe == rnfe
+  assert rel_err(xs, xr) <= 5 * TOL, f'sampler mismatch {rel_err(xs, xr):.3e}'
+
+
+def ode_sampler(st, lib):
+  base = tiny_config(st, 'vp')
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, base, lib)
+  shape = (2, 3, cfg.data.image_size, cfg.data.image_size)
+  inv = st.datasets.get_data_inverse_scaler(cfg)
+  fn = st.sampling.get_ode_sampler(cfg, sde, shape, inv, denoise=True, rtol=1e-3, atol=1e-3, eps=1e-3, device=cfg.device)
+  rfn = st.sampling.get_ode_sampler(cfg_cpu, sde, shape, inv, denoise=True, rtol=1e-3, atol=1e-3, eps=1e-3, device='cpu')
+  with patched_rng(3):
+    xs, nfe = fn(model)
+  with patched_rng(3):
+    xr, rnfe = rfn(ref)
+  assert abs(nfe - rnfe) <= 12      # adaptive controller: the step count may differ by a step or two
+  assert rel_err(xs, xr) <= 2e-2    # ... so agreement is to the solver tolerance, not to round-off
+
+
+def checkpoint_roundtrip(st, lib, tmp_path):
+  state, rstate = train_steps(st, lib, 'vp', steps=2)
+  cfg = state['model'].module.config
+  path = str(tmp_path / 'checkpoint.pth')
+  st.utils.save_checkpoint(cfg, path, state)
+  saved = torch.load(path, weights_only=False)
+  assert set(saved) == {'optimizer', 'model', 'ema', 'step'}
+  assert all(k.startswith('module.') for k in saved['model'])
+  assert set(saved['ema']) == {'decay', 'num_updates', 'shadow_params'}
+  # the optimizer state has torch.optim.Adam's structure, so it loads into torch's Adam ...
+  rstate['optimizer'].load_state_dict(saved['optimizer'])
+  # ... and a fresh product state restores everything
+  cfg2, _, sde, model2, _ = build_pair(st, tiny_config(st, 'vp'), lib, seed=9)
+  state2 = make_state(st, cfg2, model2)
+  state2['optimizer']._backend = lib
+  state2['ema'].set_backend(lib)
+  st.utils.restore_checkpoint(cfg2, path, state2, cfg2.device)
+  assert state2['step'] == 2 and state2['optimizer']._step == 2
+  for p, q in zip(state['model'].parameters(), state2['model'].parameters()):
+    assert torch.equal(p.detach().cpu(), q.detach().cpu())
+  assert torch.equal(state['optimizer']._m.cpu(), state2['optimizer']._m.cpu())
+  for a, b in zip(state['ema'].shadow_params, state2['ema'].shadow_params):
+    assert torch.equal(a.cpu(), b.cpu())

@@ -1,0 +1,430 @@
+"""GPU parity tests proper: every C-ABI entry of libstk.so (HIP, gfx950) against the oracle's plain-C
+restatement (oracle/libstk_ref.so) on identical seeded inputs, called through the C ABI.
+
+Tolerances: these are fp32 kernels checked against a double-accumulating restatement, so the bar is
+"within fp32 round-off of the exact result": 1e-5 relative to the tensor's scale for streaming
+kernels, 1e-4 for contractions with up to ~4.6k-term fp32 accumulation chains (the north-star
+tolerance for end-to-end loss/score tensors is 1e-3; see test_gpu_model.py).
+"""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from _util import call, close, dev_of, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def both(ref_lib, hip_lib, fn):
+  """Run `fn(lib, to)` on the checker and on the GPU; `to` moves a CPU tensor to the backend."""
+  outs = []
+  for lib in (ref_lib, hip_lib):
+    d = dev_of(lib)
+    outs.append(fn(lib, lambda t: None if t is None else t.to(d).contiguous()))
+  if hip_lib.is_device:
+    torch.cuda.synchronize()
+  return outs
+
+
+def compare(outs, rtol, what):
+  ref, got = outs
+  for k in ref:
+    close(got[k], ref[k], rtol=rtol, what=f'{what}:{k}')
+
+
+# ---------------------------------------------------------------------------------------------------
+# upfirdn2d
+# ---------------------------------------------------------------------------------------------------
+FIR = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32) / 64.
+UFD_CASES = [
+  # (major, H, W, up, down, pad0, pad1, taps, beta)
+  (6, 32, 32, 1, 2, 1, 1, FIR, 0.0),          # downsample_2d
+  (6, 16, 16, 2, 1, 2, 1, FIR * 4, 0.0),      # upsample_2d
+  (6, 32, 32, 1, 1, 2, 2, FIR, 0.0),          # conv_downsample_2d prefilter
+  (6, 33, 33, 1, 1, 1, 1, FIR[::-1, ::-1].copy(), 0.5),   # its backward (flipped taps, pad 1,1), accumulate
+  (5, 64, 64, 1, 2, 1, 1, FIR, 0.0),
+  (3, 128, 128, 2, 1, 2, 1, FIR * 4, 0.0),
+  (3, 256, 256, 1, 2, 1, 1, FIR, 0.0),
+  (7, 8, 8, 1, 2, 1, 1, FIR, 0.0),            # tiny plane -> direct kernel
+  (7, 4, 4, 2, 1, 2, 1, FIR * 4, 1.0),
+  (4, 20, 24, 1, 2, 1, 1, FIR, 0.0),          # ragged sizes
+  (4, 17, 19, 2, 1, 2, 1, FIR * 4, 0.0),
+  (2, 40, 40, 3, 2, 2, 3, np.arange(25, dtype=np.float32).reshape(5, 5) / 25., 0.0),   # generic factors
+  (2, 24, 24, 1, 1, -1, -1, FIR, 0.0),        # negative padding (crop)
+]
+
+
+@pytest.mark.parametrize('case', UFD_CASES, ids=lambda c: f'{c[0]}x{c[1]}x{c[2]}_u{c[3]}d{c[4]}p{c[5]}{c[6]}')
+def test_upfirdn2d(ref_lib, hip_lib, case):
+  major, H, W, up, down, p0, p1, taps, beta = case
+  kh, kw = taps.shape
+  oh = (H * up + p0 + p1 - kh) // down + 1
+  ow = (W * up + p0 + p1 - kw) // down + 1
+  x = rnd(major, H, W, 1, seed=1)
+  k = torch.from_numpy(taps)
+  o0 = rnd(major, oh, ow, 1, seed=2)
+
+  def fn(lib, to):
+    out = to(o0.clone())
+    call(lib, 'upfirdn2d_acc_f32', to(x), to(k), out, float(beta), major, H, W, 1, kh, kw, up, up, down, down,
+         p0, p1, p0, p1)
+    out2 = to(torch.zeros_like(o0))
+    call(lib, 'upfirdn2d_f32', to(x), to(k), out2, major, H, W, 1, kh, kw, up, up, down, down, p0, p1, p0, p1)
+    return {'acc': out, 'plain': out2}
+
+  compare(both(ref_lib, hip_lib, fn), 1e-5, 'upfirdn2d')
+
+
+def test_upfirdn2d_minor_dim(ref_lib, hip_lib):
+  x = rnd(3, 12, 12, 5, seed=3)
+  k = torch.from_numpy(FIR)
+
+  def fn(lib, to):
+    out = to(torch.zeros(3, 6, 6, 5))
+    call(lib, 'upfirdn2d_f32', to(x), to(k), out, 3, 12, 12, 5, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1)
+    return {'out': out}
+
+  compare(both(ref_lib, hip_lib, fn), 1e-5, 'upfirdn2d.minor')
+
+
+def test_upfirdn2d_adjoint_full_size(hip_lib):
+  """Size-independent property at CelebA-64 size: <up(x), y> == <x, down_adjoint(y)> where the
+  adjoint is the same operator with flipped taps, up<->down swapped and g_pad (op/upfirdn2d.py:111-114)."""
+  d = dev_of(hip_lib)
+  major, H = 128 * 16, 64
+  x = rnd(major, H, H, 1, seed=4).to(d)
+  k = torch.from_numpy(FIR).to(d)
+  kf = torch.flip(k, [0, 1]).contiguous()
+  y = torch.empty(major, H // 2, H // 2, 1, device=d)
+  call(hip_lib, 'upfirdn2d_f32', x, k, y, major, H, H, 1, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1)
+  g = rnd(major, H // 2, H // 2, 1, seed=5).to(d)
+  gx = torch.empty_like(x)
+  # backward of (up1, down2, pad(1,1)): up2, down1, g_pad = (k-p0-1, in*up - out*down + p0 - up + 1) = (2, 1)
+  call(hip_lib, 'upfirdn2d_f32', g, kf, gx, major, H // 2, H // 2, 1, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1)
+  lhs = (y.double() * g.double()).sum().item()
+  rhs = (x.double() * gx.double()).sum().item()
+  assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+
+
+# ---------------------------------------------------------------------------------------------------
+# element-wise family
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n', [1, 7, 1024, 4099, 1 << 20])
+def test_elementwise(ref_lib, hip_lib, n):
+  a, b, g = rnd(n, seed=1), rnd(n, seed=2), rnd(n, seed=3)
+
+  def fn(lib, to):
+    o = {}
+    y = to(torch.zeros(n)); call(lib, 'silu_fwd_f32', to(a), y, n); o['silu'] = y
+    dx = to(b.clone()); call(lib, 'silu_bwd_f32', to(a), to(g), dx, 0.5, n); o['silu_bwd'] = dx
+    dx0 = to(torch.full((n,), float('nan'))); call(lib, 'silu_bwd_f32', to(a), to(g), dx0, 0.0, n); o['silu_bwd0'] = dx0
+    z = to(torch.zeros(n)); call(lib, 'axpby_f32', to(a), 1.5, to(b), -0.25, z, n); o['axpby'] = z
+    z2 = to(torch.zeros(n)); call(lib, 'axpby_f32', to(a), 0.7, None, 0.0, z2, n); o['ax'] = z2
+    z3 = to(b.clone()); call(lib, 'axpby_f32', to(a), 0.7, z3, 1.0, z3, n); o['axpby_alias'] = z3
+    w = to(torch.zeros(n)); call(lib, 'add_div_f32', to(a), to(b), float(np.float32(np.sqrt(2.))), w, n); o['add_div'] = w
+    w1 = to(torch.zeros(n)); call(lib, 'add_div_f32', to(a), to(b), 1.0, w1, n); o['add'] = w1
+    v = to(torch.zeros(n)); call(lib, 'affine_f32', to(a), 2.0, -1.0, v, n); o['affine'] = v
+    m = to(torch.zeros(n)); call(lib, 'dropout_mask_f32', m, n, 0.1, 12345); o['mask'] = m
+    return o
+
+  outs = both(ref_lib, hip_lib, fn)
+  compare(outs, 2e-6, 'elementwise')
+  assert torch.equal(outs[0]['mask'], outs[1]['mask'].cpu()), 'dropout mask must be bit-identical across backends'
+
+
+@pytest.mark.parametrize('shape,act,grad', [((4, 6, 8, 8), 3, 0), ((4, 6, 8, 8), 3, 1), ((5, 7), 3, 0),
+                                            ((3, 5, 9), 1, 0), ((2, 4, 4, 4), 3, 2)])
+def test_fused_bias_act(ref_lib, hip_lib, shape, act, grad):
+  x, ref = rnd(*shape, seed=1), rnd(*shape, seed=2)
+  bias = rnd(shape[1], seed=3)
+  n = x.numel()
+  step_b = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+
+  def fn(lib, to):
+    o = to(torch.zeros(shape))
+    call(lib, 'fused_bias_act_f32', to(x), to(bias), to(ref) if grad == 1 else None, o, n, step_b, shape[1], act, grad,
+         0.2, float(2 ** 0.5))
+    o2 = to(torch.zeros(shape))
+    call(lib, 'fused_bias_act_f32', to(x), None, to(ref), o2, n, 1, 1, act, grad, 0.1, 1.0)
+    return {'bias': o, 'nobias': o2}
+
+  compare(both(ref_lib, hip_lib, fn), 1e-6, 'fused_bias_act')
+
+
+@pytest.mark.parametrize('planes,H,W', [(6, 16, 16), (3, 32, 32), (5, 4, 4), (2, 6, 10)])
+def test_resample_naive(ref_lib, hip_lib, planes, H, W):
+  x = rnd(planes, H, W, seed=1)
+  up0, dn0 = rnd(planes, 2 * H, 2 * W, seed=2), rnd(planes, H // 2, W // 2, seed=3)
+
+  def fn(lib, to):
+    u = to(up0.clone()); call(lib, 'resample_naive_f32', to(x), u, planes, H, W, 0, 1.0, 0.0)
+    ub = to(up0.clone()); call(lib, 'resample_naive_f32', to(x), ub, planes, H, W, 0, 0.25, 1.0)
+    d = to(dn0.clone()); call(lib, 'resample_naive_f32', to(x), d, planes, H, W, 1, 1.0, 0.0)
+    db = to(dn0.clone()); call(lib, 'resample_naive_f32', to(x), db, planes, H, W, 1, 4.0, 1.0)
+    return {'up': u, 'up_acc': ub, 'down': d, 'down_acc': db}
+
+  compare(both(ref_lib, hip_lib, fn), 1e-6, 'resample')
+
+
+def test_small_helpers(ref_lib, hip_lib):
+  B, inner = 6, 3 * 16 * 16
+  x, z = rnd(B, inner, seed=1), rnd(B, inner, seed=2)
+  s = torch.rand(B, generator=torch.Generator().manual_seed(3)) + 0.5
+  a = torch.rand(B, generator=torch.Generator().manual_seed(4))
+  t = torch.rand(B, generator=torch.Generator().manual_seed(5)) * 999
+  freqs = torch.exp(torch.arange(64, dtype=torch.float32) * -(np.log(10000) / 63))
+  W = rnd(32, seed=6, scale=16.)
+  ls = torch.log(s)
+  wgt = torch.rand(B, generator=torch.Generator().manual_seed(7)) * 10
+  dl = rnd(B, seed=8)
+
+  def fn(lib, to):
+    o = {}
+    r = to(torch.zeros(B, inner)); call(lib, 'rowscale_f32', to(x), to(s), r, B, inner, 1); o['rowdiv'] = r
+    r2 = to(torch.zeros(B, inner)); call(lib, 'rowscale_f32', to(x), to(s), r2, B, inner, 0); o['rowmul'] = r2
+    p = to(torch.zeros(B, inner)); call(lib, 'perturb_f32', to(x), to(z), to(a), to(s), p, B, inner); o['perturb'] = p
+    p2 = to(torch.zeros(B, inner)); call(lib, 'perturb_f32', to(x), to(z), None, to(s), p2, B, inner); o['perturb_ve'] = p2
+    e = to(torch.zeros(B, 128)); call(lib, 'timestep_embedding_f32', to(t), to(freqs), e, B, 128); o['temb'] = e
+    f = to(torch.zeros(B, 64)); call(lib, 'fourier_embedding_f32', to(ls), to(W), f, B, 32); o['fourier'] = f
+    for vp, mode, rm in itertools.product((0, 1), (0, 1), (0, 1)):
+      l = to(torch.zeros(B)); call(lib, 'sm_loss_fwd_f32', to(x), to(z), to(s), to(wgt), l, B, inner, vp, mode, rm)
+      o[f'loss{vp}{mode}{rm}'] = l
+      g = to(torch.zeros(B, inner))
+      call(lib, 'sm_loss_bwd_f32', to(x), to(z), to(s), to(wgt), to(dl), g, B, inner, vp, mode, rm)
+      o[f'dloss{vp}{mode}{rm}'] = g
+    return o
+
+  outs = both(ref_lib, hip_lib, fn)
+  ref, got = outs
+  for k in ref:
+    # sin/cos of arguments up to ~1e3 (temb) / ~1e2 (fourier): device and host libm agree to ~1 ulp of the result
+    close(got[k], ref[k], rtol=2e-5 if k in ('temb', 'fourier') else 2e-6, what=k)
+
+
+# ---------------------------------------------------------------------------------------------------
+# GroupNorm (+SiLU) (+dropout)
+# ---------------------------------------------------------------------------------------------------
+GN_CASES = [
+  # N, C1, C2, H, G, act, p
+  (3, 128, 0, 8, 32, 1, 0.0),
+  (2, 256, 128, 8, 32, 1, 0.0),      # concat, groups of 12 straddle the two sources
+  (2, 128, 256, 4, 32, 1, 0.1),
+  (3, 16, 0, 16, 4, 0, 0.0),         # attention's GroupNorm (no activation)
+  (2, 32, 16, 16, 12, 1, 0.2),
+  (2, 128, 0, 32, 32, 1, 0.1),
+  (1, 256, 256, 16, 32, 1, 0.0),
+  (2, 12, 0, 5, 3, 1, 0.0),          # HW = 25: scalar path
+  (1, 128, 0, 64, 32, 1, 0.0),
+]
+
+
+@pytest.mark.parametrize('case', GN_CASES, ids=str)
+def test_groupnorm(ref_lib, hip_lib, case):
+  N, C1, C2, H, G, act, p = case
+  C, HW = C1 + C2, H * H
+  x1 = rnd(N, C1, H, H, seed=1) * 2 + 0.5
+  x2 = rnd(N, C2, H, H, seed=2) - 0.3 if C2 else None
+  gamma, beta = rnd(C, seed=3) + 1, rnd(C, seed=4)
+  dy = rnd(N, C, H, H, seed=5)
+  d1, d2 = rnd(N, C1, H, H, seed=6), (rnd(N, C2, H, H, seed=7) if C2 else None)
+  seed = 0xABCDEF12345
+
+  def fn(lib, to):
+    dev = dev_of(lib)
+    y, mean, rstd = to(torch.zeros(N, C, H, H)), to(torch.zeros(N * G)), to(torch.zeros(N * G))
+    sdev = torch.tensor([17], dtype=torch.int64, device=dev)
+    a1, a2, ga, be = to(x1), to(x2), to(gamma), to(beta)
+    call(lib, 'gn_fwd_f32', a1, C1, a2, C2, ga, be, y, mean, rstd, N, HW, G, 1e-6, act, p, seed, sdev)
+    dx1, dx2 = to(d1.clone()), to(d2.clone()) if C2 else None
+    dg, db = to(torch.ones(C)), to(torch.ones(C))
+    ws = to(torch.zeros(2 * N * C))
+    call(lib, 'gn_bwd_f32', to(dy), a1, C1, a2, C2, ga, be, mean, rstd, dx1, 0.0, dx2, 1.0, dg, db, ws, N, HW, G, act,
+         p, seed, sdev)
+    o = {'y': y, 'mean': mean, 'rstd': rstd, 'dx1': dx1, 'dgamma': dg, 'dbeta': db}
+    if C2:
+      o['dx2'] = dx2
+    return o
+
+  compare(both(ref_lib, hip_lib, fn), 2e-5, 'groupnorm')
+
+
+# ---------------------------------------------------------------------------------------------------
+# convolution: forward / dgrad / wgrad / bias-grad
+# ---------------------------------------------------------------------------------------------------
+CONV_CASES = [
+  # N, C1, C2, H, W, Cout, K, stride, pad, OH, OW, layout, temb, res, div
+  (2, 16, 0, 16, 16, 32, 3, 1, 1, 16, 16, 0, True, True, True),
+  (4, 128, 0, 32, 32, 128, 3, 1, 1, 32, 32, 0, True, False, False),     # 128x128 tiles
+  (3, 96, 64, 16, 16, 128, 3, 1, 1, 16, 16, 0, False, True, True),      # concat input
+  (2, 3, 0, 32, 32, 128, 3, 1, 1, 32, 32, 0, False, False, False),      # stem
+  (2, 128, 0, 32, 32, 3, 3, 1, 1, 32, 32, 0, False, False, False),      # head
+  (3, 64, 0, 17, 17, 48, 3, 2, 0, 8, 8, 0, False, True, True),          # conv_downsample_2d's strided conv
+  (2, 32, 0, 16, 16, 32, 3, 2, 0, 8, 8, 0, False, False, False),        # F.pad(0,1,0,1) + stride 2 (asymmetric)
+  (3, 64, 32, 8, 8, 64, 1, 1, 0, 8, 8, 0, False, False, False),         # 1x1 shortcut on a concat
+  (3, 256, 0, 16, 16, 256, 1, 1, 0, 16, 16, 1, False, True, True),      # NIN_3 + residual
+  (5, 40, 0, 4, 4, 56, 1, 1, 0, 4, 4, 1, False, False, False),          # NIN, ragged channels
+  (2, 20, 12, 12, 10, 24, 3, 1, 1, 12, 10, 0, True, True, False),       # ragged everything
+  (130, 128, 0, 4, 4, 128, 3, 1, 1, 4, 4, 0, True, False, True),        # many tiny images per tile
+]
+
+
+def _conv_id(c):
+  return f'N{c[0]}_C{c[1]}+{c[2]}_{c[3]}x{c[4]}_o{c[5]}_k{c[6]}s{c[7]}p{c[8]}_l{c[11]}'
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=_conv_id)
+def test_conv(ref_lib, hip_lib, case):
+  N, C1, C2, H, W, Cout, K, stride, pad, OH, OW, layout, use_temb, use_res, use_div = case
+  Cin = C1 + C2
+  x1 = rnd(N, C1, H, W, seed=1)
+  x2 = rnd(N, C2, H, W, seed=2) if C2 else None
+  w = (rnd(Cout, Cin, K, K, seed=3) if layout == 0 else rnd(Cin, Cout, seed=3)) * (1.0 / np.sqrt(Cin * K * K))
+  bias = rnd(Cout, seed=4)
+  TS = Cout + 24
+  temb = rnd(N, TS, seed=5) if use_temb else None
+  res = rnd(N, Cout, OH, OW, seed=6) if use_res else None
+  div = float(np.float32(np.sqrt(2.))) if use_div else 1.0
+  dy = rnd(N, Cout, OH, OW, seed=7)
+  g1, g2 = rnd(N, C1, H, W, seed=8), (rnd(N, C2, H, W, seed=9) if C2 else None)
+  dw0, db0 = rnd(*w.shape, seed=10), rnd(Cout, seed=11)
+  dims = (N, H, W, Cout, OH, OW, K, K, stride, pad)
+
+  def fn(lib, to):
+    o = {}
+    a1, a2, ww = to(x1), to(x2), to(w)
+    tp = None
+    if use_temb:
+      tt = to(temb)
+      tp = tt.data_ptr() + 4 * 8            # a column slice of a wider [N, TS] tensor
+    y = to(torch.zeros(N, Cout, OH, OW))
+    call(lib, 'conv2d_fwd_f32', a1, C1, a2, C2, ww, layout, to(bias), tp, TS if use_temb else 0, to(res), div, y, *dims)
+    o['y'] = y
+    y2 = to(torch.zeros(N, Cout, OH, OW))
+    call(lib, 'conv2d_fwd_f32', a1, C1, a2, C2, ww, layout, None, None, 0, None, 1.0, y2, *dims)
+    o['y_plain'] = y2
+    d = to(dy)
+    dx1, dx2 = to(g1.clone()), (to(g2.clone()) if C2 else None)
+    call(lib, 'conv2d_dgrad_f32', d, ww, layout, dx1, C1, 0.0, dx2, C2, 1.0, 0.5, *dims)
+    o['dx1'] = dx1
+    if C2:
+      o['dx2'] = dx2
+    nbytes = int(lib.conv2d_wgrad_ws_bytes(C1, C2, N, Cout, OH, OW, K, K))
+    ws = to(torch.zeros(max(nbytes // 4, N * Cout, 64)))
+    dw = to(dw0.clone())
+    call(lib, 'conv2d_wgrad_f32', a1, C1, a2, C2, d, dw, layout, 0.5, ws, ws.numel() * 4, *dims)
+    o['dw'] = dw
+    db = to(db0.clone())
+    dt = to(torch.zeros(N, TS))
+    call(lib, 'bias_grad_f32', d, N, Cout, OH * OW, 0.5, dt.data_ptr() + 4 * 8, TS, db, ws)
+    o['dbias'], o['dtemb'] = db, dt
+    db2 = to(db0.clone())
+    call(lib, 'bias_grad_f32', d, N, Cout, OH * OW, 1.0, None, 0, db2, ws)
+    o['dbias_only'] = db2
+    return o
+
+  compare(both(ref_lib, hip_lib, fn), 1e-4, 'conv')
+
+
+def test_conv_adjoint_full_size(hip_lib):
+  """Size-independent properties at the BASELINE size (DDPM++ 32x32, batch 128, 128->128 3x3):
+  <conv(x), g> == <x, dgrad(g)> == <w, wgrad(x, g)>."""
+  d = dev_of(hip_lib)
+  N, C, H = 128, 128, 32
+  x = rnd(N, C, H, H, seed=1).to(d)
+  w = (rnd(C, C, 3, 3, seed=2) / 34.).to(d)
+  g = rnd(N, C, H, H, seed=3).to(d)
+  dims = (N, H, H, C, H, H, 3, 3, 1, 1)
+  y = torch.empty_like(x)
+  call(hip_lib, 'conv2d_fwd_f32', x, C, None, 0, w, 0, None, None, 0, None, 1.0, y, *dims)
+  dx = torch.empty_like(x)
+  call(hip_lib, 'conv2d_dgrad_f32', g, w, 0, dx, C, 0.0, None, 0, 0.0, 1.0, *dims)
+  ws = torch.zeros(int(hip_lib.conv2d_wgrad_ws_bytes(C, 0, N, C, H, H, 3, 3)) // 4 + 64, device=d)
+  dw = torch.zeros_like(w)
+  call(hip_lib, 'conv2d_wgrad_f32', x, C, None, 0, g, dw, 0, 1.0, ws, ws.numel() * 4, *dims)
+  a = (y.double() * g.double()).sum().item()
+  b = (x.double() * dx.double()).sum().item()
+  c = (w.double() * dw.double()).sum().item()
+  tol = 2e-5 * max(abs(a), 1.0)
+  assert abs(a - b) <= tol and abs(a - c) <= tol, (a, b, c)
+
+
+# ---------------------------------------------------------------------------------------------------
+# batched strided GEMM, softmax
+# ---------------------------------------------------------------------------------------------------
+GEMM_CASES = [
+  # M, N, K, batch, a_kcontig, b_kcontig, bias_mode, beta
+  (256, 256, 256, 6, False, False, 0, 0.0),     # S = Q^T K
+  (256, 256, 256, 6, True, True, 0, 0.5),       # O = V P^T
+  (64, 64, 256, 3, True, False, 0, 0.0),
+  (512, 7, 128, 1, True, True, 2, 0.0),         # Linear: [B=7] outputs, bias along n... (here along n)
+  (8, 512, 512, 1, True, True, 2, 0.0),         # temb MLP shape (batch 8)
+  (130, 70, 33, 2, False, True, 1, 1.0),        # ragged
+  (16, 16, 16, 5, False, False, 0, 0.0),        # mid-block attention at 4x4
+]
+
+
+@pytest.mark.parametrize('case', GEMM_CASES, ids=str)
+def test_gemm(ref_lib, hip_lib, case):
+  M, N, K, batch, akc, bkc, bias_mode, beta = case
+  A = rnd(batch, M, K, seed=1) if akc else rnd(batch, K, M, seed=1)
+  B = rnd(batch, N, K, seed=2) if bkc else rnd(batch, K, N, seed=2)
+  C0 = rnd(batch, M, N, seed=3)
+  bias = rnd(M if bias_mode == 1 else N, seed=4) if bias_mode else None
+  sam, sak = (K, 1) if akc else (1, M)
+  sbk, sbn = (1, K) if bkc else (N, 1)
+
+  def fn(lib, to):
+    c = to(C0.clone())
+    call(lib, 'gemm_f32', to(A), sam, sak, M * K, to(B), sbk, sbn, N * K, c, N, 1, M * N, to(bias), bias_mode,
+         M, N, K, batch, 0.75, beta)
+    ct = to(C0.transpose(1, 2).contiguous().clone())     # transposed output (scm = 1)
+    call(lib, 'gemm_f32', to(A), sam, sak, M * K, to(B), sbk, sbn, N * K, ct, 1, M, M * N, to(bias), bias_mode,
+         M, N, K, batch, 0.75, beta)
+    return {'c': c, 'ct': ct}
+
+  compare(both(ref_lib, hip_lib, fn), 1e-4, 'gemm')
+
+
+@pytest.mark.parametrize('rows,cols', [(64, 256), (37, 16), (10, 64), (5, 300), (1000, 1)])
+def test_softmax(ref_lib, hip_lib, rows, cols):
+  x, dy = rnd(rows, cols, seed=1) * 3, rnd(rows, cols, seed=2)
+
+  def fn(lib, to):
+    y = to(torch.zeros(rows, cols))
+    call(lib, 'softmax_fwd_f32', to(x), y, rows, cols, 0.0625)
+    dx = to(dy.clone())
+    call(lib, 'softmax_bwd_f32', y, dx, dx, rows, cols, 0.0625)      # in place, as the attention op uses it
+    return {'y': y, 'dx': dx}
+
+  compare(both(ref_lib, hip_lib, fn), 1e-5, 'softmax')
+
+
+# ---------------------------------------------------------------------------------------------------
+# optimizer side
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n', [1, 1000, 1 << 20, (1 << 22) + 3])
+def test_optimizer_kernels(ref_lib, hip_lib, n):
+  p, g, m = rnd(n, seed=1), rnd(n, seed=2) * 0.01, rnd(n, seed=3) * 0.01
+  v = (rnd(n, seed=4) * 0.01) ** 2
+  sh = rnd(n, seed=5)
+
+  def fn(lib, to):
+    o = {}
+    ws, ss = to(torch.zeros(2048)), to(torch.zeros(1))
+    gg = to(g.clone())
+    call(lib, 'sumsq_f32', gg, n, ss, ws)
+    o['sumsq'] = ss
+    pp, mm, vv = to(p.clone()), to(m.clone()), to(v.clone())
+    call(lib, 'adam_f32', pp, gg, mm, vv, n, 2e-4, 0.9, 0.999, 1e-8, 0.0, 0, 1 - 0.9 ** 3, 1 - 0.999 ** 3, ss, 1.0)
+    o.update(p=pp, g=gg, m=mm, v=vv)
+    p2, g2, m2, v2 = to(p.clone()), to(g.clone()), to(m.clone()), to(v.clone())
+    call(lib, 'adam_f32', p2, g2, m2, v2, n, 1e-3, 0.9, 0.99, 1e-8, 0.01, 1, 0.1, 0.01, None, -1.0)
+    o.update(p_w=p2, m_w=m2, v_w=v2)
+    s = to(sh.clone())
+    call(lib, 'ema_f32', s, pp, n, 1 - 0.9999)
+    o['ema'] = s
+    return o
+
+  compare(both(ref_lib, hip_lib, fn), 2e-5, 'optimizer')
