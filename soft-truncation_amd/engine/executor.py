@@ -58,7 +58,7 @@ class Program:
 class _NetFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, ex, training, anchor, x, emb_in, sigma):
-    need_xgrad = bool(x.requires_grad)
+    need_xgrad = bool(ctx.needs_input_grad[3])
     out, c = ex.run_forward(x, emb_in, sigma, training, need_xgrad)
     ctx.ex, ctx.c, ctx.need_xgrad = ex, c, need_xgrad
     return out
@@ -79,6 +79,7 @@ class Executor:
     self.flat = None
     self.programs = {}
     self._anchor = None
+    self.profiler = None     # engine.profile.KernelTimer or None
 
   # -- parameters ---------------------------------------------------------------------------------
   def set_backend(self, backend):
@@ -141,6 +142,7 @@ class Executor:
     rt = Runtime(self.lib, stk_lib.stream_ptr(flat.device), c.act.data_ptr(), 0,
                  flat.data.data_ptr(), flat.grad.data_ptr(), prog.const.data_ptr(),
                  prog.ws.data_ptr(), g.ws_bytes, training, seed)
+    rt.prof = self.profiler
     for op in g.ops:
       op.forward(rt)
     c.rt = rt
@@ -156,6 +158,7 @@ class Executor:
     rt.gbase['act'] = c.gact.data_ptr()
     rt.gbase['param'] = flat.grad.data_ptr()
     rt.stream = stk_lib.stream_ptr(flat.device)
+    rt.prof = self.profiler
     o = g.output
     c.gact[o.goff:o.goff + o.numel].view(o.shape).copy_(gout)
     for op in reversed(g.ops):

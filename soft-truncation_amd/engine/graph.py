@@ -60,6 +60,14 @@ class Runtime:
     self.training = training
     self.seed = seed
     self.seed_dev = seed_dev
+    self.prof = None      # optional engine.profile.KernelTimer: HIP events around the contraction launches
+
+  def timed(self, kind, flops, fn, *args):
+    """Launch `fn(*args)`; with a profiler attached, bracket it with HIP events on the launch stream."""
+    if self.prof is None:
+      fn(*args)
+    else:
+      self.prof.launch(kind, flops, fn, args)
 
   def v(self, t):
     return None if t is None else self.base[t.space] + 4 * t.off
@@ -159,15 +167,27 @@ class Conv(Op):
     self.res, self.out_div = res, float(out_div)
     self.y = g.new((N, Cout, OH, OW), name=name)
     self.inputs = (x1, x2, res)
+    # algorithmic FLOPs of one launch (1 MAC = 2 FLOP); identical for fwd, dgrad and wgrad
+    self.flops = 2.0 * N * OH * OW * Cout * (C1 + C2) * KH * KW
+
+  def _kind(self, direction, M, Ncols, wgrad=False):
+    """Kernel-symbol label: direction, taps and the tile variant csrc/conv.hip picks for this shape."""
+    if wgrad:
+      big = M >= 96 and Ncols >= 96
+    else:
+      t = -(-M // 128) * -(-Ncols // 128)
+      big = M >= 96 and Ncols >= 96 and t >= 192
+    return f'conv{self.KH}x{self.KW}.{direction}.{"t128" if big else "t64"}'
 
   def _dims(self):
     return (self.N, self.H, self.W, self.Cout, self.OH, self.OW, self.KH, self.KW, self.stride, self.pad)
 
   def forward(self, rt):
     temb = rt.v(self.temb) + 4 * self.temb_col if self.temb is not None else None
-    rt.lib.conv2d_fwd_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.w), self.w_layout,
-                          rt.v(self.bias), temb, self.temb_stride, rt.v(self.res), self.out_div,
-                          rt.v(self.y), *self._dims(), rt.stream)
+    rt.timed(self._kind('fwd', self.Cout, self.N * self.OH * self.OW), self.flops, rt.lib.conv2d_fwd_f32,
+             rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.w), self.w_layout,
+             rt.v(self.bias), temb, self.temb_stride, rt.v(self.res), self.out_div,
+             rt.v(self.y), *self._dims(), rt.stream)
 
   def backward(self, rt):
     gy = rt.g(self.y)
@@ -185,13 +205,15 @@ class Conv(Op):
                         rt.ws, rt.stream)
     gw = rt.g(self.w)
     if gw is not None:
-      lib.conv2d_wgrad_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, gy, gw, self.w_layout, alpha,
-                           rt.ws, rt.ws_bytes, *self._dims(), rt.stream)
+      rt.timed(self._kind('wgrad', self.Cout, self.C1 + self.C2, wgrad=True), self.flops, lib.conv2d_wgrad_f32,
+               rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, gy, gw, self.w_layout, alpha,
+               rt.ws, rt.ws_bytes, *self._dims(), rt.stream)
     g1, g2 = rt.g(self.x1), rt.g(self.x2)
     if g1 is not None or g2 is not None:
-      lib.conv2d_dgrad_f32(gy, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
-                           g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
-                           alpha, *self._dims(), rt.stream)
+      rt.timed(self._kind('dgrad', self.C1 + self.C2, self.N * self.H * self.W), self.flops, lib.conv2d_dgrad_f32,
+               gy, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
+               g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
+               alpha, *self._dims(), rt.stream)
 
   def ws_bytes(self, lib):
     return max(int(lib.conv2d_wgrad_ws_bytes(self.C1, self.C2, self.N, self.Cout, self.OH, self.OW,
