@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: Soft-Truncation training step of the NCSN++/DDPM++ score network.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one call of ``losses.get_step_fn(...)(state, batch)`` -- time sampling, perturbation,
+score-network forward and backward on the HIP engine, gradient all-reduce (N > 1), clip + Adam, EMA --
+on one synthetic batch already resident in HBM.  Workload at N = 1 (BASELINE.json configs[1]):
+DDPM++ (VP) CIFAR-10 32x32, per-GPU batch 128, fp32.  Scaling is weak: the per-GPU batch is fixed and
+the global batch is 128 N.  Rank 0 prints ONE JSON line.
+
+Extra objects in that line:
+  roofline      the dominant kernel (by total time inside the timed region), timed with HIP events on the
+                launch stream: achieved = algorithmic FLOPs per launch / average launch duration, against
+                the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).  `kernels` lists the other
+                contraction kernels the same way.
+  cpu_baseline  the oracle's PyTorch-CPU restatement of the same training step (RefNet + torch Adam) timed
+                on this box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+  if _p not in sys.path:
+    sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+TRAIN_FLOPS_PER_IMG = {'cifar10_ddpmpp_nll_st': 65.072e9, 'imagenet32_ddpmpp_st': 65.072e9,
+                       'celeba_uncsnpp_st': 252.128e9, 'celebahq_uncsnpp_st': 1598.169e9}
+
+WORKLOADS = {
+  # name -> (config factory name, per-GPU batch, description)
+  'cifar10': ('cifar10_ddpmpp_nll_st', 128, 'DDPM++ (VP) CIFAR-10 32x32, configs/vp/CIFAR10/ddpmpp_nll_st.py (BASELINE configs[1])'),
+  'imagenet32': ('imagenet32_ddpmpp_st', 128, 'DDPM++ (VP) ImageNet32, configs/vp/IMAGENET32/ddpmpp_st.py (BASELINE configs[3])'),
+  'celeba64': ('celeba_uncsnpp_st', 128, 'UNCSN++ (RVE) CelebA 64x64, configs/ve/CELEBA/uncsnpp_st.py (BASELINE configs[2])'),
+  'celebahq256': ('celebahq_uncsnpp_st', 4, 'NCSN++ (VE) CelebA-HQ 256x256, configs/ve/celebahq/uncsnpp_st.py (BASELINE configs[4])'),
+}
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--workload', default='cifar10', choices=sorted(WORKLOADS))
+  ap.add_argument('--batch', type=int, default=0, help='per-GPU batch override')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-kernel-timer', action='store_true')
+  ap.add_argument('--cpu-batch', type=int, default=8)
+  ap.add_argument('--cpu-steps', type=int, default=5)
+  return ap.parse_args()
+
+
+def cpu_baseline(st, cfg_name, batch, steps):
+  """The oracle restatement (PyTorch CPU, oneDNN) of the same training step on the host cores."""
+  import ref_torch
+  cfg = st.configs.get_config(cfg_name)
+  cfg.device = torch.device('cpu')
+  sde = st.sde_lib.get_sde(cfg, None)
+  # the product model only serves as the parameter initialiser here (same shapes / state_dict keys)
+  torch.manual_seed(0)
+  proto = st.models.ncsnpp.NCSNpp(cfg, sde)
+  sd = {'module.' + k: v for k, v in proto.state_dict().items()}
+  del proto
+  ref = st.models.utils.DataParallel(ref_torch.RefNet(cfg, sd))
+  opt = st.losses.get_optimizer(cfg, ref.parameters())
+  ema = st.models.ema.ExponentialMovingAverage(ref.parameters(), decay=cfg.model.ema_rate)
+  state = dict(optimizer=opt, model=ref, ema=ema, step=0)
+  step_fn = st.losses.get_step_fn(cfg, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg))
+  x = st.datasets.synthetic_batch(cfg, batch, generator=torch.Generator().manual_seed(0))
+  times = []
+  for i in range(steps + 1):
+    t0 = time.perf_counter()
+    step_fn(state, x)
+    times.append(time.perf_counter() - t0)
+  med = float(np.median(times[1:]))
+  return {'value': batch / med, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+          'sample': f'{cfg_name} full-size model, batch {batch}, median of {steps} training steps after 1 warm-up '
+                    f'(oracle/ref_torch.RefNet + torch.optim.Adam + EMA, PyTorch CPU fp32)',
+          'sec_per_step': med}
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+  if world > 1:
+    dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
+
+  import soft_truncation_amd as st
+  cfg_name, per_gpu_batch, desc = WORKLOADS[args.workload]
+  if args.batch:
+    per_gpu_batch = args.batch
+  cfg = st.configs.get_config(cfg_name)
+  cfg.device = device
+  st.engine.ddp.seed_everything(cfg.seed)                  # numpy shared (t_min), torch per rank
+
+  sde = st.sde_lib.get_sde(cfg, None)
+  score_model = st.models.utils.create_model(cfg, sde)     # random-init weights of the named architecture
+  score_model.module.engine().ensure_flat()
+  optimizer = st.losses.get_optimizer(cfg, score_model.parameters())
+  ema = st.models.ema.ExponentialMovingAverage(score_model.parameters(), decay=cfg.model.ema_rate)
+  state = dict(optimizer=optimizer, model=score_model, ema=ema, step=0)
+  step_fn = st.losses.get_step_fn(cfg, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg))
+  batch = st.datasets.synthetic_batch(cfg, per_gpu_batch, device=device,
+                                      generator=torch.Generator().manual_seed(1234 + rank))
+
+  def sync():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+      torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    step_fn(state, batch)
+  timer = None
+  if not args.no_kernel_timer:
+    from importlib import import_module
+    timer = import_module('soft-truncation_amd.engine.profile').KernelTimer()
+    score_model.module.engine().profiler = timer
+  sync()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    losses_ = step_fn(state, batch)
+  sync()
+  elapsed = time.perf_counter() - t0
+  score_model.module.engine().profiler = None
+  if world > 1:
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  if rank == 0:
+    global_batch = per_gpu_batch * world
+    ips = global_batch * args.steps / elapsed
+    out = {
+      'metric': 'training images/sec (DDPM++ CIFAR-10 32x32)' if args.workload == 'cifar10'
+                else f'training images/sec ({args.workload})',
+      'value': ips, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+      'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': desc, 'per_gpu_batch': per_gpu_batch, 'global_batch': global_batch,
+                 'parallelism': f'dp{world}', 'loss_mean': float(losses_.mean())},
+    }
+    step_tflops = TRAIN_FLOPS_PER_IMG[cfg_name] * ips / world / 1e12
+    out['step_roofline'] = {'bound': 'mfma', 'achieved': step_tflops, 'peak': PEAK_F32_MFMA_TFLOPS,
+                            'unit': 'TFLOP/s', 'frac': step_tflops / PEAK_F32_MFMA_TFLOPS,
+                            'note': 'whole training step per GPU: BASELINE.md train FLOPs/img x images/s'}
+    if timer is not None:
+      summ = timer.summary()
+      if summ:
+        dom = max(summ, key=lambda k: summ[k]['total_ms'])
+        a = summ[dom]
+        out['roofline'] = {'bound': 'mfma', 'achieved': a['tflops'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': a['tflops'] / PEAK_F32_MFMA_TFLOPS, 'traffic': None, 'kernel': dom,
+                           'avg_us': a['avg_us'], 'launches': a['count'], 'flops_per_launch': a['flops_per_launch'],
+                           'share_of_step': a['total_ms'] / (1e3 * elapsed)}
+        out['kernels'] = {k: {'tflops': round(v['tflops'], 2), 'avg_us': round(v['avg_us'], 1), 'launches': v['count'],
+                              'total_ms_per_step': round(v['total_ms'] / args.steps, 3)} for k, v in summ.items()}
+    if world == 1 and not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline(st, cfg_name, args.cpu_batch, args.cpu_steps)
+    print(json.dumps(out), flush=True)
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

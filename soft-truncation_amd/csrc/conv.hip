@@ -10,8 +10,8 @@
 //
 // In all three the pixel index is the fastest-varying index of the activation operand in HBM (NCHW),
 // so the activation loaders put lanes along pixels: a wave reads 64 consecutive floats (256 B) per
-// instruction, shifted by the tap offset; halo / padding / stride-2 holes are predicated zeros.
-// The channel-concat of the up path (two sources) is just a pointer select on the channel index.
+// instruction, shifted by the tap offset; halo / padding / stride-2 holes are zeros.
+// The channel-concat of the up path (two sources) is just a source select on the channel index.
 // Weights are read in their native layouts ([Cout,Cin,KH,KW] or NIN's [Cin,Cout]) by whichever lane
 // mapping makes those reads contiguous; they are L2-resident (<= 4.7 MB per layer).
 //
@@ -23,8 +23,13 @@
 namespace {
 
 using igemm::Cfg;
-using igemm::KMajor;
 using igemm::MnMajor;
+using igemm::keep_if;
+using igemm::strip_row;
+
+// Global-address-space float: pointers rebuilt from integers must say so, or hipcc emits FLAT loads,
+// which also count on lgkmcnt and would make the LDS waits of the MFMA loop wait for HBM.
+typedef __attribute__((address_space(1))) float gfloat;
 
 struct ConvP {
   const float* x1; const float* x2; int C1, C2;
@@ -35,88 +40,188 @@ struct ConvP {
   float* part; long part_stride;
   int N, H, W, Cin, Cout, OH, OW, KH, KW, stride, pad, sshift;
   int HW, OHW, taps;
-  // generic strided A operand (weights viewed as a matrix): element (m,k) at wA[m*sam + k*sak]
-  long sam, sak;
 };
 
-// ---- A loaders ------------------------------------------------------------------------------------------
-// Strided matrix A(m,k) = w[m*sam + k*sak], M rows, Ktot columns.
-template <class C, bool K_CONTIG>
-struct AStrided {
-  int m0, tid, M, Ktot;
-  __device__ void init(const ConvP& p, int m0_, int tid_, int) {
-    m0 = m0_; tid = tid_;
-    M = 0; Ktot = 0;
+// ---- loaders ---------------------------------------------------------------------------------------------
+// Rules that shape them (measured: the first version, with one predicated load per element, compiled to an
+// exec-mask branch plus an s_waitcnt per load and ran the fp32 MFMA pipe at ~50%):
+//   * every load is UNCONDITIONAL from an always-valid address; validity goes into a per-thread bitmask and
+//     the zeroing happens when the registers are written to LDS (after the MFMAs of the previous chunk), so
+//     the 18 + 18 loads of a chunk issue back to back and stay in flight under the matrix work;
+//   * activation bases are wave-uniform (SGPR) and per-lane offsets are 32-bit element offsets
+//     (the host side rejects tensors of >= 2^31 elements): a load is `global_load_dword v, voff, s[base]`;
+//   * K-contiguous operands (weights, GEMM rows) use a row-chunk mapping: 4 threads per row, each loading
+//     KC/4 consecutive k at immediate offsets from one per-chunk address (merged into dwordx4 by hipcc).
+
+// K-contiguous rows:  X(row, k) = base[row * ld + k],  row < R, k < Ktot.   Thread (r = tid/4, q = tid%4)
+// loads k in [q*PERQ, (q+1)*PERQ) of rows r and (B == 128) r + 64.
+template <int B, int KC, int LD>
+struct RowChunk {
+  static constexpr int PERQ = KC / 4, PASSES = B / 64, PER = PASSES * PERQ;
+  static_assert(KC % 4 == 0 && B % 64 == 0 && PER <= 32, "bad RowChunk tile");
+  const float* rowp[PASSES];     // start of this thread's row (row 0 of the operand when the row is out of range)
+  unsigned rowbits;              // bit ps: row of pass ps is in range
+  unsigned okm;                  // validity of the PER staged elements
+  int q, tid, Ktot;
+  __device__ __forceinline__ void init(const float* base, long ld, int row0, int R, int Ktot_, int tid_) {
+    tid = tid_; q = tid & 3; Ktot = Ktot_; rowbits = 0; okm = 0;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int row = row0 + (tid >> 2) + 64 * ps;
+      const bool ok = row < R;
+      rowbits |= (ok ? 1u : 0u) << ps;
+      rowp[ps] = base + (ok ? (long)row * ld : 0);
+    }
   }
-  __device__ __forceinline__ void set_dims(int M_, int K_) { M = M_; Ktot = K_; }
-  __device__ void load(const ConvP& p, int k0, float (&r)[C::NA]) {
-    if (K_CONTIG) {
-      using Mp = KMajor<C::BM, C::KC>;
+  // Ktot % PERQ == 0 is a precondition (the host dispatches ragged K to MnStrided), so a thread's PERQ
+  // elements are valid or invalid together: no branch, PERQ loads at immediate offsets (-> dwordx4).
+  __device__ __forceinline__ void load(int k0, float (&r)[PER]) {
+    const int kb = k0 + q * PERQ;
+    const bool kin = kb + PERQ <= Ktot;
+    const int ko = kin ? kb : 0;
+    okm = 0;
 #pragma unroll
-      for (int i = 0; i < C::NA; ++i) {
-        const int m = m0 + Mp::mn(tid, i), k = k0 + Mp::kk(tid, i);
-        r[i] = (m < M && k < Ktot) ? p.w[(long)m * p.sam + (long)k * p.sak] : 0.f;
-      }
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const float* s = rowp[ps] + ko;
+#pragma unroll
+      for (int j = 0; j < PERQ; ++j) r[ps * PERQ + j] = s[j];
+      okm |= ((kin && ((rowbits >> ps) & 1u)) ? ((1u << PERQ) - 1u) : 0u) << (ps * PERQ);
+    }
+  }
+  __device__ __forceinline__ void store(const float (&r)[PER], float* t) {
+    if (okm == (PER == 32 ? 0xffffffffu : (1u << PER) - 1u)) {       // interior tile: nothing to zero
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+        for (int j = 0; j < PERQ; ++j) t[(q * PERQ + j) * LD + (tid >> 2) + 64 * ps] = r[ps * PERQ + j];
     } else {
-      using Mp = MnMajor<C::BM, C::KC>;
-      const int m = m0 + Mp::mn(tid);
 #pragma unroll
-      for (int i = 0; i < C::NA; ++i) {
-        const int k = k0 + Mp::kk(tid, i);
-        r[i] = (m < M && k < Ktot) ? p.w[(long)m * p.sam + (long)k * p.sak] : 0.f;
-      }
+      for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+        for (int j = 0; j < PERQ; ++j)
+          t[(q * PERQ + j) * LD + (tid >> 2) + 64 * ps] = keep_if(r[ps * PERQ + j], okm, ps * PERQ + j);
+    }
+  }
+};
+
+// MN-contiguous operand with a k stride:  X(mn, k) = base[mn * smn + k * sk]  (lanes along mn).
+template <int B, int KC, int LD>
+struct MnStrided {
+  using Mp = MnMajor<B, KC>;
+  static constexpr int PER = Mp::PER;
+  const float* pm; long sk; int kg, tid, Ktot; bool ok;
+  unsigned okm;
+  __device__ __forceinline__ void init(const float* base, long smn, long sk_, int o0, int lim, int Ktot_, int tid_) {
+    tid = tid_; sk = sk_; Ktot = Ktot_; okm = 0;
+    const int mn = o0 + Mp::mn(tid);
+    ok = mn < lim;
+    pm = base + (ok ? (long)mn * smn : 0);
+    kg = Mp::kgroup(tid) * PER;
+  }
+  __device__ __forceinline__ void load(int k0, float (&r)[PER]) {
+    okm = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int k = k0 + kg + i;
+      const bool v = ok && k < Ktot;
+      r[i] = pm[v ? (long)k * sk : 0];
+      okm |= (v ? 1u : 0u) << i;
+    }
+  }
+  __device__ __forceinline__ void store(const float (&r)[PER], float* t) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) t[(kg + i) * LD + Mp::mn(tid)] = keep_if(r[i], okm, i);
+  }
+};
+
+// ---- A loaders ----------------------------------------------------------------------------------------------
+template <class C>
+struct AFwdK {       // [Cout][Cin*taps] row-major weights: A(m=co, k) = w[co*K + k]
+  RowChunk<C::BM, C::KC, C::LDA> rc;
+  __device__ void init(const ConvP& p, int m0, int tid, int) { rc.init(p.w, (long)p.Cin * p.taps, m0, p.Cout, p.Cin * p.taps, tid); }
+  __device__ void load(const ConvP&, int k0, float (&r)[C::NA]) { rc.load(k0, r); }
+  __device__ void store(const float (&r)[C::NA], float* t) { rc.store(r, t); }
+};
+template <class C>
+struct AFwdGen {     // same matrix, any K (e.g. Cin = 3): lanes along m, k strided by 1 -- uncoalesced but tiny
+  MnStrided<C::BM, C::KC, C::LDA> ms;
+  __device__ void init(const ConvP& p, int m0, int tid, int) { ms.init(p.w, (long)p.Cin * p.taps, 1, m0, p.Cout, p.Cin * p.taps, tid); }
+  __device__ void load(const ConvP&, int k0, float (&r)[C::NA]) { ms.load(k0, r); }
+  __device__ void store(const float (&r)[C::NA], float* t) { ms.store(r, t); }
+};
+template <class C>
+struct AFwdNin {     // NIN w[Cin][Cout]: A(m=co, k=ci) = w[ci*Cout + co]  (m contiguous)
+  MnStrided<C::BM, C::KC, C::LDA> ms;
+  __device__ void init(const ConvP& p, int m0, int tid, int) { ms.init(p.w, 1, p.Cout, m0, p.Cout, p.Cin, tid); }
+  __device__ void load(const ConvP&, int k0, float (&r)[C::NA]) { ms.load(k0, r); }
+  __device__ void store(const float (&r)[C::NA], float* t) { ms.store(r, t); }
+};
+template <class C>
+struct ADgradNin {   // NIN dgrad: A(m=ci, k=co) = w[ci*Cout + co]  (k contiguous)
+  RowChunk<C::BM, C::KC, C::LDA> rc;
+  __device__ void init(const ConvP& p, int m0, int tid, int) { rc.init(p.w, p.Cout, m0, p.Cin, p.Cout, tid); }
+  __device__ void load(const ConvP&, int k0, float (&r)[C::NA]) { rc.load(k0, r); }
+  __device__ void store(const float (&r)[C::NA], float* t) { rc.store(r, t); }
+};
+template <class C>
+struct ADgradNinGen {   // NIN dgrad with Cout % 8 != 0
+  MnStrided<C::BM, C::KC, C::LDA> ms;
+  __device__ void init(const ConvP& p, int m0, int tid, int) { ms.init(p.w, p.Cout, 1, m0, p.Cin, p.Cout, tid); }
+  __device__ void load(const ConvP&, int k0, float (&r)[C::NA]) { ms.load(k0, r); }
+  __device__ void store(const float (&r)[C::NA], float* t) { ms.store(r, t); }
+};
+template <class C>
+struct ADgrad1 {     // 1x1 Conv2d dgrad: A(m=ci, k=co) = w[co*Cin + ci]  (m contiguous)
+  MnStrided<C::BM, C::KC, C::LDA> ms;
+  __device__ void init(const ConvP& p, int m0, int tid, int) { ms.init(p.w, 1, p.Cin, m0, p.Cin, p.Cout, tid); }
+  __device__ void load(const ConvP&, int k0, float (&r)[C::NA]) { ms.load(k0, r); }
+  __device__ void store(const float (&r)[C::NA], float* t) { ms.store(r, t); }
+};
+// 3x3 dgrad on [Cout,Cin,3,3]:  A(m=ci, k=(co,tap)) = w[(co*Cin + ci)*9 + tap]: for a fixed (ci, co) the 9 taps
+// are contiguous -> the row-chunk geometry with q = co within the chunk.
+template <class C>
+struct ADgrad9 {
+  static_assert(C::KC == 36, "3x3 chunks are 4 channels x 9 taps");
+  static constexpr int PASSES = C::BM / 64;
+  int m0, tid; unsigned okp;
+  __device__ void init(const ConvP&, int m0_, int tid_, int) { m0 = m0_; tid = tid_; okp = 0; }
+  __device__ void load(const ConvP& p, int k0, float (&r)[C::NA]) {
+    const int co = k0 / 9 + (tid & 3);
+    okp = 0;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int m = m0 + (tid >> 2) + 64 * ps;
+      const bool ok = m < p.Cin && co < p.Cout;
+      const float* s = p.w + (ok ? ((long)co * p.Cin + m) * 9 : 0);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) r[ps * 9 + j] = s[j];
+      okp |= (ok ? 1u : 0u) << ps;
     }
   }
   __device__ void store(const float (&r)[C::NA], float* t) {
-    if (K_CONTIG) igemm::store_k_major<C::BM, C::KC, C::LDA>(r, t, tid);
-    else igemm::store_mn_major<C::BM, C::KC, C::LDA>(r, t, tid);
-  }
-};
-template <class C, bool K_CONTIG>
-struct AFwd : AStrided<C, K_CONTIG> {      // M = Cout, K = Cin*taps
-  __device__ void init(const ConvP& p, int m0_, int tid_, int zb) {
-    AStrided<C, K_CONTIG>::init(p, m0_, tid_, zb);
-    this->set_dims(p.Cout, p.Cin * p.taps);
-  }
-};
-template <class C, bool K_CONTIG>
-struct ADgrad1 : AStrided<C, K_CONTIG> {   // 1x1 dgrad: M = Cin, K = Cout
-  __device__ void init(const ConvP& p, int m0_, int tid_, int zb) {
-    AStrided<C, K_CONTIG>::init(p, m0_, tid_, zb);
-    this->set_dims(p.Cin, p.Cout);
-  }
-};
-// 3x3 dgrad on [Cout,Cin,3,3]:  A(m=ci, k=(co,tap)) = w[(co*Cin + ci)*9 + tap]
-template <class C>
-struct ADgrad9 {
-  int m0, tid;
-  __device__ void init(const ConvP&, int m0_, int tid_, int) { m0 = m0_; tid = tid_; }
-  __device__ void load(const ConvP& p, int k0, float (&r)[C::NA]) {
-    using Mp = KMajor<C::BM, C::KC>;
-    const int co0 = k0 / 9;
 #pragma unroll
-    for (int i = 0; i < C::NA; ++i) {
-      const int m = m0 + Mp::mn(tid, i), kk = Mp::kk(tid, i);
-      const int co = co0 + kk / 9, tap = kk % 9;
-      r[i] = (m < p.Cin && co < p.Cout) ? p.w[((long)co * p.Cin + m) * 9 + tap] : 0.f;
-    }
+    for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+        t[((tid & 3) * 9 + j) * C::LDA + (tid >> 2) + 64 * ps] = keep_if(r[ps * 9 + j], okp, ps);
   }
-  __device__ void store(const float (&r)[C::NA], float* t) { igemm::store_k_major<C::BM, C::KC, C::LDA>(r, t, tid); }
 };
 
 // ---- B loaders: activations, lanes along pixels -----------------------------------------------------------
 // forward im2col:  B(k=(ci,tap), n=(b,oy,ox)) = x[b, ci, oy*s + kh - pad, ox*s + kw - pad]
-template <class C, int TAPS>
+template <class C, int TAPS, bool DUAL>
 struct BFwd {
   using Mp = MnMajor<C::BN, C::KC>;
-  static_assert(Mp::PER % TAPS == 0, "k rows per thread must cover whole channels");
-  const float* p1; const float* p2;
-  int cig, tid; unsigned mask;
+  static constexpr int NCH = C::NB / TAPS;     // channels per thread per chunk
+  static_assert(Mp::PER % TAPS == 0 && C::NB <= 32, "k rows per thread must cover whole channels");
+  int tb1, tb2;          // per-lane element offset of (image b, channel 0, pixel (iy0, ix0)) in x1 / x2
+  int cig, tid; unsigned mask, okm;
   __device__ void init(const ConvP& p, int n0, int tid_, int) {
     tid = tid_;
     const int n = n0 + Mp::mn(tid);
-    cig = Mp::kgroup(tid) * (Mp::PER / TAPS);
-    mask = 0; p1 = p.x1; p2 = p.x2;
+    // channel offset of this thread's k rows inside a chunk; wave-uniform -> keep it in an SGPR
+    cig = __builtin_amdgcn_readfirstlane(Mp::kgroup(tid) * (Mp::PER / TAPS));
+    mask = 0; okm = 0; tb1 = 0; tb2 = 0;
     if (n < p.N * p.OHW) {
       const int b = n / p.OHW, ohw = n - b * p.OHW;
       const int oy = ohw / p.OW, ox = ohw - oy * p.OW;
@@ -127,39 +232,51 @@ struct BFwd {
         const int iy = iy0 + t / KW, ix = ix0 + t % KW;
         if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
       }
-      const long pix = (long)iy0 * p.W + ix0;
-      p1 = p.x1 + (long)b * p.C1 * p.HW + pix;
-      p2 = p.x2 ? p.x2 + (long)b * p.C2 * p.HW + pix : nullptr;
+      const int pix = iy0 * p.W + ix0;
+      tb1 = b * p.C1 * p.HW + pix;
+      tb2 = b * p.C2 * p.HW + pix;
     }
   }
   __device__ void load(const ConvP& p, int k0, float (&r)[C::NB]) {
-    const int ci0 = k0 / TAPS + cig;
+    const int ci0 = k0 / TAPS + cig;          // scalar
     const int KW = TAPS == 9 ? 3 : 1;
+    okm = 0;
 #pragma unroll
-    for (int i = 0; i < C::NB; ++i) {
-      const int ci = ci0 + i / TAPS, t = i % TAPS;
-      const int off = (t / KW) * p.W + (t % KW);
-      float v = 0.f;
-      if (((mask >> t) & 1u) && ci < p.Cin)
-        v = ci < p.C1 ? p1[(long)ci * p.HW + off] : p2[(long)(ci - p.C1) * p.HW + off];
-      r[i] = v;
+    for (int c = 0; c < NCH; ++c) {
+      const int ci = ci0 + c;                 // scalar (k0 and cig are wave-uniform)
+      const unsigned cm = ci < p.Cin ? mask : 0u;
+      okm |= cm << (c * TAPS);
+      const int cs = min(ci, p.Cin - 1);      // clamp so that the channel base below is always inside a tensor
+      // Channel-plane base as a scalar address.  The source select is done on integers: a select between the
+      // two tensor POINTERS made hipcc issue the load from both sources and select the value afterwards.
+      const bool first = !DUAL || cs < p.C1;
+      const uintptr_t tensor = first ? (uintptr_t)p.x1 : (uintptr_t)p.x2;
+      const gfloat* plane = (const gfloat*)(tensor + (uintptr_t)(first ? cs : cs - p.C1) * (uintptr_t)p.HW * 4u);
+      const int tb = first ? tb1 : tb2;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+        r[c * TAPS + t] = plane[((cm >> t) & 1u) ? tb + (t / KW) * p.W + (t % KW) : 0];
     }
   }
-  __device__ void store(const float (&r)[C::NB], float* t) { igemm::store_mn_major<C::BN, C::KC, C::LDB>(r, t, tid); }
+  __device__ void store(const float (&r)[C::NB], float* t) {
+    const int kg = Mp::kgroup(tid) * Mp::PER, mn = Mp::mn(tid);
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) t[(kg + i) * C::LDB + mn] = keep_if(r[i], okm, i);
+  }
 };
 
 // dgrad gather:  B(k=(co,tap), n=(b,y,x)) = dy[b, co, (y+pad-kh)/s, (x+pad-kw)/s]  where divisible & in range
 template <class C, int TAPS>
 struct BDgrad {
   using Mp = MnMajor<C::BN, C::KC>;
-  static_assert(Mp::PER % TAPS == 0, "k rows per thread must cover whole channels");
-  const float* pd;
-  int cig, tid, yp, xp; unsigned mask;
+  static constexpr int NCH = C::NB / TAPS;
+  static_assert(Mp::PER % TAPS == 0 && C::NB <= 32, "k rows per thread must cover whole channels");
+  int tb, cig, tid, yp, xp; unsigned mask, okm;
   __device__ void init(const ConvP& p, int n0, int tid_, int) {
     tid = tid_;
     const int n = n0 + Mp::mn(tid);
-    cig = Mp::kgroup(tid) * (Mp::PER / TAPS);
-    mask = 0; pd = p.dy; yp = 0; xp = 0;
+    cig = __builtin_amdgcn_readfirstlane(Mp::kgroup(tid) * (Mp::PER / TAPS));
+    mask = 0; okm = 0; tb = 0; yp = 0; xp = 0;
     if (n < p.N * p.HW) {
       const int b = n / p.HW, hw = n - b * p.HW;
       const int y = hw / p.W, x = hw - y * p.W;
@@ -172,119 +289,181 @@ struct BDgrad {
         if (ty >= 0 && tx >= 0 && !(ty & sm) && !(tx & sm) && (ty >> p.sshift) < p.OH && (tx >> p.sshift) < p.OW)
           mask |= 1u << t;
       }
-      pd = p.dy + (long)b * p.Cout * p.OHW;
+      tb = b * p.Cout * p.OHW;
     }
   }
   __device__ void load(const ConvP& p, int k0, float (&r)[C::NB]) {
-    const int co0 = k0 / TAPS + cig;
+    const int co0 = k0 / TAPS + cig;          // scalar
     const int KW = TAPS == 9 ? 3 : 1;
+    okm = 0;
 #pragma unroll
-    for (int i = 0; i < C::NB; ++i) {
-      const int co = co0 + i / TAPS, t = i % TAPS;
-      float v = 0.f;
-      if (((mask >> t) & 1u) && co < p.Cout) {
-        const int off = ((yp - t / KW) >> p.sshift) * p.OW + ((xp - t % KW) >> p.sshift);
-        v = pd[(long)co * p.OHW + off];
+    for (int c = 0; c < NCH; ++c) {
+      const int co = co0 + c;
+      const unsigned cm = co < p.Cout ? mask : 0u;
+      const int cb = tb + co * p.OHW;
+      okm |= cm << (c * TAPS);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int off = cb + ((yp - t / KW) >> p.sshift) * p.OW + ((xp - t % KW) >> p.sshift);
+        r[c * TAPS + t] = p.dy[((cm >> t) & 1u) ? off : 0];
       }
-      r[i] = v;
     }
   }
-  __device__ void store(const float (&r)[C::NB], float* t) { igemm::store_mn_major<C::BN, C::KC, C::LDB>(r, t, tid); }
+  __device__ void store(const float (&r)[C::NB], float* t) {
+    const int kg = Mp::kgroup(tid) * Mp::PER, mn = Mp::mn(tid);
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) t[(kg + i) * C::LDB + mn] = keep_if(r[i], okm, i);
+  }
 };
 
 // ---- wgrad loaders (K = pixels, lanes along pixels; tap = blockIdx.z) ------------------------------------
-// KMajor with KC = 32: kk = tid & 31 is fixed per thread, mn = tid/32 + 8 r.
+// KC = 32: kk = tid & 31 is this thread's pixel inside the chunk for every element, mn = tid/32 + 8 i.
 template <class C>
 struct AWgrad {       // A(m=co, k=pixel) = dy[b, co, ohw]
-  static_assert(C::KC == 32, "wgrad uses 32-pixel chunks");
-  int m0, tid;
-  __device__ void init(const ConvP&, int m0_, int tid_, int) { m0 = m0_; tid = tid_; }
+  static_assert(C::KC == 32 && C::NA <= 32, "wgrad uses 32-pixel chunks");
+  int m0, tid; unsigned okm;
+  __device__ void init(const ConvP&, int m0_, int tid_, int) { m0 = m0_; tid = tid_; okm = 0; }
   __device__ void load(const ConvP& p, int k0, float (&r)[C::NA]) {
     const int k = k0 + (tid & 31);
     const bool kv = k < p.N * p.OHW;
     const int b = kv ? k / p.OHW : 0;
-    const int ohw = k - b * p.OHW;
-    const float* base = p.dy + (long)b * p.Cout * p.OHW + ohw;
+    const int base = b * p.Cout * p.OHW + (kv ? k - b * p.OHW : 0);
+    const int mrow = m0 + (tid >> 5);
+    okm = 0;
 #pragma unroll
     for (int i = 0; i < C::NA; ++i) {
-      const int m = m0 + (tid >> 5) + 8 * i;
-      r[i] = (kv && m < p.Cout) ? base[(long)m * p.OHW] : 0.f;
+      const int m = mrow + 8 * i;
+      const bool ok = kv && m < p.Cout;
+      r[i] = p.dy[ok ? base + m * p.OHW : 0];
+      okm |= (ok ? 1u : 0u) << i;
     }
   }
   __device__ void store(const float (&r)[C::NA], float* t) {
 #pragma unroll
-    for (int i = 0; i < C::NA; ++i) t[(tid & 31) * C::LDA + (tid >> 5) + 8 * i] = r[i];
+    for (int i = 0; i < C::NA; ++i) t[(tid & 31) * C::LDA + (tid >> 5) + 8 * i] = keep_if(r[i], okm, i);
   }
 };
-template <class C>
+template <class C, bool DUAL>
 struct BWgrad {       // B(k=pixel, n=ci) = x[b, ci, oy*s + kh - pad, ox*s + kw - pad]
-  static_assert(C::KC == 32, "wgrad uses 32-pixel chunks");
-  int n0, tid, kh, kw;
+  static_assert(C::KC == 32 && C::NB <= 32, "wgrad uses 32-pixel chunks");
+  int n0, tid, kh, kw; unsigned okm;
   __device__ void init(const ConvP& p, int n0_, int tid_, int zb) {
-    n0 = n0_; tid = tid_;
+    n0 = n0_; tid = tid_; okm = 0;
     kh = zb / p.KW; kw = zb - kh * p.KW;
   }
   __device__ void load(const ConvP& p, int k0, float (&r)[C::NB]) {
     const int k = k0 + (tid & 31);
     bool kv = k < p.N * p.OHW;
     const int b = kv ? k / p.OHW : 0;
-    const int ohw = k - b * p.OHW;
+    const int ohw = kv ? k - b * p.OHW : 0;
     const int oy = ohw / p.OW, ox = ohw - oy * p.OW;
     const int iy = oy * p.stride + kh - p.pad, ix = ox * p.stride + kw - p.pad;
     kv = kv && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    const long pix = (long)iy * p.W + ix;
-    const float* b1 = p.x1 + (long)b * p.C1 * p.HW + pix;
-    const float* b2 = p.x2 ? p.x2 + (long)b * p.C2 * p.HW + pix : nullptr;
+    const int pix = iy * p.W + ix;
+    const int b1 = b * p.C1 * p.HW + pix, b2 = b * p.C2 * p.HW + pix;
+    const int crow = n0 + (tid >> 5);
+    okm = 0;
 #pragma unroll
     for (int i = 0; i < C::NB; ++i) {
-      const int ci = n0 + (tid >> 5) + 8 * i;
-      float v = 0.f;
-      if (kv && ci < p.Cin) v = ci < p.C1 ? b1[(long)ci * p.HW] : b2[(long)(ci - p.C1) * p.HW];
-      r[i] = v;
+      const int ci = crow + 8 * i;
+      const bool ok = kv && ci < p.Cin;
+      if (DUAL) {
+        const bool first = ci < p.C1;
+        const uintptr_t tensor = first ? (uintptr_t)p.x1 : (uintptr_t)p.x2;
+        const int off = first ? b1 + ci * p.HW : b2 + (ci - p.C1) * p.HW;
+        r[i] = ((const gfloat*)tensor)[ok ? off : 0];
+      } else {
+        r[i] = p.x1[ok ? b1 + ci * p.HW : 0];
+      }
+      okm |= (ok ? 1u : 0u) << i;
     }
   }
   __device__ void store(const float (&r)[C::NB], float* t) {
 #pragma unroll
-    for (int i = 0; i < C::NB; ++i) t[(tid & 31) * C::LDB + (tid >> 5) + 8 * i] = r[i];
+    for (int i = 0; i < C::NB; ++i) t[(tid & 31) * C::LDB + (tid >> 5) + 8 * i] = keep_if(r[i], okm, i);
   }
 };
 
-// ---- epilogues ----------------------------------------------------------------------------------------------
+// ---- epilogues: one 16-row strip of one output column per call, loads batched ------------------------------
 struct EpFwd {        // y = (acc + bias + temb + res) * inv_div
-  int b; long col_off;
+  int b; int col_off;
   __device__ void init(const ConvP&, int, int) {}
   __device__ void col(const ConvP& p, int n) {
     b = n / p.OHW;
-    col_off = (long)b * p.Cout * p.OHW + (n - b * p.OHW);
+    col_off = b * p.Cout * p.OHW + (n - b * p.OHW);
   }
-  __device__ void put(const ConvP& p, int m, int, float acc) {
-    const long idx = col_off + (long)m * p.OHW;
-    float v = acc;
-    if (p.bias) v += p.bias[m];
-    if (p.temb) v += p.temb[(long)b * p.temb_stride + m];
-    if (p.res) v += p.res[idx];
-    if (p.use_div) v *= p.inv_div;
-    p.y[idx] = v;
+  __device__ void strip(const ConvP& p, int mbase, int M, bool nok, int, const floatx16& acc) {
+    // 4 rows at a time: up to 12 independent loads in flight, and only a dozen live registers on top of
+    // the accumulators (a 16-row batch pushed the whole kernel to 249 VGPRs = 2 waves/SIMD).
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float bv[4], tv[4], rv[4];
+      int idx[4]; bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int m = mbase + strip_row(4 * g + u);
+        ok[u] = nok && m < M;
+        idx[u] = ok[u] ? col_off + m * p.OHW : 0;
+        const int ms = ok[u] ? m : 0;
+        bv[u] = p.bias ? p.bias[ms] : 0.f;
+        tv[u] = p.temb ? p.temb[ok[u] ? (long)b * p.temb_stride + m : 0] : 0.f;
+        rv[u] = p.res ? p.res[idx[u]] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v = acc[4 * g + u];
+        if (p.bias) v += bv[u];
+        if (p.temb) v += tv[u];
+        if (p.res) v += rv[u];
+        if (p.use_div) v *= p.inv_div;
+        if (ok[u]) p.y[idx[u]] = v;
+      }
+    }
   }
 };
 struct EpDgrad {      // dx{1,2} = beta*dx + alpha*acc, rows routed to the two sources of the concat
   int b, hw;
   __device__ void init(const ConvP&, int, int) {}
   __device__ void col(const ConvP& p, int n) { b = n / p.HW; hw = n - b * p.HW; }
-  __device__ void put(const ConvP& p, int m, int, float acc) {
-    float* d; float beta;
-    if (m < p.C1) { d = p.dx1 ? p.dx1 + ((long)b * p.C1 + m) * p.HW + hw : nullptr; beta = p.beta1; }
-    else { d = p.dx2 ? p.dx2 + ((long)b * p.C2 + (m - p.C1)) * p.HW + hw : nullptr; beta = p.beta2; }
-    if (d) *d = (beta != 0.f ? beta * *d : 0.f) + p.alpha * acc;
+  __device__ void strip(const ConvP& p, int mbase, int M, bool nok, int, const floatx16& acc) {
+    float* d[16]; float old[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = mbase + strip_row(e);
+      float* q = nullptr;
+      if (nok && m < M) {
+        if (m < p.C1) { if (p.dx1) q = p.dx1 + ((long)b * p.C1 + m) * p.HW + hw; }
+        else if (p.dx2) q = p.dx2 + ((long)b * p.C2 + (m - p.C1)) * p.HW + hw;
+      }
+      d[e] = q;
+    }
+    const bool acc1 = p.beta1 != 0.f, acc2 = p.beta2 != 0.f;
+    if (acc1 || acc2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = mbase + strip_row(e);
+        const float beta = m < p.C1 ? p.beta1 : p.beta2;
+        old[e] = (d[e] && beta != 0.f) ? beta * *d[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (d[e]) *d[e] = ((acc1 || acc2) ? old[e] : 0.f) + p.alpha * acc[e];
   }
 };
 struct EpWgrad {      // partial slab of split zs, tap zb, in the weight's own layout
   float* slab; int tap;
   __device__ void init(const ConvP& p, int zb, int zs) { slab = p.part + (long)zs * p.part_stride; tap = zb; }
   __device__ void col(const ConvP&, int) {}
-  __device__ void put(const ConvP& p, int m, int n, float acc) {
-    if (p.w_layout == 0) slab[((long)m * p.Cin + n) * p.taps + tap] = acc;
-    else slab[(long)n * p.Cout + m] = acc;
+  __device__ void strip(const ConvP& p, int mbase, int M, bool nok, int n, const floatx16& acc) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = mbase + strip_row(e);
+      if (nok && m < M) {
+        if (p.w_layout == 0) slab[((long)m * p.Cin + n) * p.taps + tap] = acc[e];
+        else slab[(long)n * p.Cout + m] = acc[e];
+      }
+    }
   }
 };
 
@@ -308,69 +487,61 @@ struct GemmP {
   float alpha, beta;
 };
 template <class C, bool K_CONTIG>
-struct GA {
-  const float* base; int m0, tid;
-  __device__ void init(const GemmP& p, int m0_, int tid_, int zb) { m0 = m0_; tid = tid_; base = p.A + (long)zb * p.sab; }
-  __device__ void load(const GemmP& p, int k0, float (&r)[C::NA]) {
-    if (K_CONTIG) {
-      using Mp = KMajor<C::BM, C::KC>;
-#pragma unroll
-      for (int i = 0; i < C::NA; ++i) {
-        const int m = m0 + Mp::mn(tid, i), k = k0 + Mp::kk(tid, i);
-        r[i] = (m < p.M && k < p.K) ? base[(long)m * p.sam + (long)k * p.sak] : 0.f;
-      }
-    } else {
-      using Mp = MnMajor<C::BM, C::KC>;
-      const int m = m0 + Mp::mn(tid);
-#pragma unroll
-      for (int i = 0; i < C::NA; ++i) {
-        const int k = k0 + Mp::kk(tid, i);
-        r[i] = (m < p.M && k < p.K) ? base[(long)m * p.sam + (long)k * p.sak] : 0.f;
-      }
-    }
+struct GA {           // A(m,k): K_CONTIG -> rows of contiguous k (sak == 1); else lanes along m with a k stride
+  RowChunk<C::BM, C::KC, C::LDA> rc;
+  MnStrided<C::BM, C::KC, C::LDA> ms;
+  __device__ void init(const GemmP& p, int m0, int tid, int zb) {
+    const float* base = p.A + (long)zb * p.sab;
+    if (K_CONTIG) rc.init(base, p.sam, m0, p.M, p.K, tid);
+    else ms.init(base, p.sam, p.sak, m0, p.M, p.K, tid);
+  }
+  __device__ void load(const GemmP&, int k0, float (&r)[C::NA]) {
+    if (K_CONTIG) rc.load(k0, r); else ms.load(k0, r);
   }
   __device__ void store(const float (&r)[C::NA], float* t) {
-    if (K_CONTIG) igemm::store_k_major<C::BM, C::KC, C::LDA>(r, t, tid);
-    else igemm::store_mn_major<C::BM, C::KC, C::LDA>(r, t, tid);
+    if (K_CONTIG) rc.store(r, t); else ms.store(r, t);
   }
 };
 template <class C, bool K_CONTIG>
-struct GB {
-  const float* base; int n0, tid;
-  __device__ void init(const GemmP& p, int n0_, int tid_, int zb) { n0 = n0_; tid = tid_; base = p.B + (long)zb * p.sbb; }
-  __device__ void load(const GemmP& p, int k0, float (&r)[C::NB]) {
-    if (K_CONTIG) {
-      using Mp = KMajor<C::BN, C::KC>;
-#pragma unroll
-      for (int i = 0; i < C::NB; ++i) {
-        const int n = n0 + Mp::mn(tid, i), k = k0 + Mp::kk(tid, i);
-        r[i] = (n < p.N && k < p.K) ? base[(long)k * p.sbk + (long)n * p.sbn] : 0.f;
-      }
-    } else {
-      using Mp = MnMajor<C::BN, C::KC>;
-      const int n = n0 + Mp::mn(tid);
-#pragma unroll
-      for (int i = 0; i < C::NB; ++i) {
-        const int k = k0 + Mp::kk(tid, i);
-        r[i] = (n < p.N && k < p.K) ? base[(long)k * p.sbk + (long)n * p.sbn] : 0.f;
-      }
-    }
+struct GB {           // B(k,n): K_CONTIG -> columns stored as rows of contiguous k (sbk == 1); else lanes along n
+  RowChunk<C::BN, C::KC, C::LDB> rc;
+  MnStrided<C::BN, C::KC, C::LDB> ms;
+  __device__ void init(const GemmP& p, int n0, int tid, int zb) {
+    const float* base = p.B + (long)zb * p.sbb;
+    if (K_CONTIG) rc.init(base, p.sbn, n0, p.N, p.K, tid);
+    else ms.init(base, p.sbn, p.sbk, n0, p.N, p.K, tid);
+  }
+  __device__ void load(const GemmP&, int k0, float (&r)[C::NB]) {
+    if (K_CONTIG) rc.load(k0, r); else ms.load(k0, r);
   }
   __device__ void store(const float (&r)[C::NB], float* t) {
-    if (K_CONTIG) igemm::store_k_major<C::BN, C::KC, C::LDB>(r, t, tid);
-    else igemm::store_mn_major<C::BN, C::KC, C::LDB>(r, t, tid);
+    if (K_CONTIG) rc.store(r, t); else ms.store(r, t);
   }
 };
 struct EpGemm {
   float* base;
   __device__ void init(const GemmP& p, int zb, int) { base = p.C + (long)zb * p.scb; }
   __device__ void col(const GemmP&, int) {}
-  __device__ void put(const GemmP& p, int m, int n, float acc) {
-    float v = p.alpha * acc;
-    if (p.bias_mode == 1) v += p.bias[m];
-    else if (p.bias_mode == 2) v += p.bias[n];
-    float* c = base + (long)m * p.scm + (long)n * p.scn;
-    *c = (p.beta != 0.f ? p.beta * *c : 0.f) + v;
+  __device__ void strip(const GemmP& p, int mbase, int M, bool nok, int n, const floatx16& acc) {
+    float old[16];
+    if (p.beta != 0.f) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = mbase + strip_row(e);
+        const bool ok = nok && m < M;
+        old[e] = base[ok ? (long)m * p.scm + (long)n * p.scn : 0];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = mbase + strip_row(e);
+      if (nok && m < M) {
+        float v = p.alpha * acc[e];
+        if (p.bias_mode == 1) v += p.bias[m];
+        else if (p.bias_mode == 2) v += p.bias[n];
+        base[(long)m * p.scm + (long)n * p.scn] = (p.beta != 0.f ? p.beta * old[e] : 0.f) + v;
+      }
+    }
   }
 };
 
@@ -397,6 +568,9 @@ inline int fill_common(ConvP& p, int N, int H, int W, int C1, int C2, int Cout, 
   if (N <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0 || OH <= 0 || OW <= 0) return STK_EINVAL;
   if (!((KH == 3 && KW == 3) || (KH == 1 && KW == 1))) return STK_EUNSUPPORTED;
   if (stride != 1 && stride != 2) return STK_EUNSUPPORTED;
+  // 32-bit element offsets inside the kernels
+  const long lim = 0x7fffffffL;
+  if ((long)N * (C1 > C2 ? C1 : C2) * H * W >= lim || (long)N * Cout * OH * OW >= lim) return STK_EUNSUPPORTED;
   p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.Cin = C1 + C2; p.Cout = Cout; p.OH = OH; p.OW = OW;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.sshift = stride == 2 ? 1 : 0;
   p.HW = H * W; p.OHW = OH * OW; p.taps = KH * KW;
@@ -436,27 +610,32 @@ int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const f
   ConvP p = {};
   int rc = fill_common(p, N, H, W, C1, C2, Cout, OH, OW, KH, KW, stride, pad);
   if (rc) return rc;
-  p.x1 = x1; p.x2 = C2 > 0 ? x2 : nullptr; p.w = w; p.w_layout = w_layout; p.bias = bias; p.temb = temb;
+  p.x1 = x1; p.x2 = C2 > 0 ? x2 : x1; p.w = w; p.w_layout = w_layout; p.bias = bias; p.temb = temb;
   p.temb_stride = temb_stride; p.res = res; p.inv_div = 1.f / out_div; p.use_div = out_div != 1.f; p.y = y;
   const int K = p.Cin * p.taps;
   const long Ng = (long)N * p.OHW;
   const bool big = use_big_tile(Cout, Ng, 1);
   hipStream_t s = (hipStream_t)stream;
   if (p.taps == 9) {
-    p.sam = K; p.sak = 1;
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;
-    if (big) return launch<CB, ConvP, AFwd<CB, true>, BFwd<CB, 9>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
-    return launch<CS, ConvP, AFwd<CS, true>, BFwd<CS, 9>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
+    if (C2 > 0) {
+      if (big) return launch<CB, ConvP, AFwdK<CB>, BFwd<CB, 9, true>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
+      return launch<CS, ConvP, AFwdK<CS>, BFwd<CS, 9, true>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
+    }
+    if (big) return launch<CB, ConvP, AFwdK<CB>, BFwd<CB, 9, false>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
+    return launch<CS, ConvP, AFwdK<CS>, BFwd<CS, 9, false>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
   }
   using CB = Cfg<128, 128, 32>; using CS = Cfg<64, 64, 32>;
+  // 1x1: B loader always with the dual-source form (the shortcut convs of the up path read a concat)
   if (w_layout == 0) {
-    p.sam = K; p.sak = 1;
-    if (big) return launch<CB, ConvP, AFwd<CB, true>, BFwd<CB, 1>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
-    return launch<CS, ConvP, AFwd<CS, true>, BFwd<CS, 1>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
+    if (K % 8 == 0) {      // row-chunk weight loader needs whole 8-float chunks
+      if (big) return launch<CB, ConvP, AFwdK<CB>, BFwd<CB, 1, true>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
+      return launch<CS, ConvP, AFwdK<CS>, BFwd<CS, 1, true>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
+    }
+    return launch<CS, ConvP, AFwdGen<CS>, BFwd<CS, 1, true>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
   }
-  p.sam = 1; p.sak = Cout;   // NIN: w[ci][co]
-  if (big) return launch<CB, ConvP, AFwd<CB, false>, BFwd<CB, 1>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
-  return launch<CS, ConvP, AFwd<CS, false>, BFwd<CS, 1>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
+  if (big) return launch<CB, ConvP, AFwdNin<CB>, BFwd<CB, 1, true>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
+  return launch<CS, ConvP, AFwdNin<CS>, BFwd<CS, 1, true>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
 }
 
 int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* dx1, int C1, float beta1, float* dx2,
@@ -481,13 +660,13 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
   }
   using CB = Cfg<128, 128, 32>; using CS = Cfg<64, 64, 32>;
   if (w_layout == 0) {       // A(m=ci,k=co) = w[co*Cin + ci]
-    p.sam = 1; p.sak = Cin;
-    if (big) return launch<CB, ConvP, ADgrad1<CB, false>, BDgrad<CB, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
-    return launch<CS, ConvP, ADgrad1<CS, false>, BDgrad<CS, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
+    if (big) return launch<CB, ConvP, ADgrad1<CB>, BDgrad<CB, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
+    return launch<CS, ConvP, ADgrad1<CS>, BDgrad<CS, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
   }
-  p.sam = Cout; p.sak = 1;   // NIN: A(m=ci,k=co) = w[ci*Cout + co]
-  if (big) return launch<CB, ConvP, ADgrad1<CB, true>, BDgrad<CB, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
-  return launch<CS, ConvP, ADgrad1<CS, true>, BDgrad<CS, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
+  // NIN: A(m=ci,k=co) = w[ci*Cout + co]
+  if (K % 8 != 0) return launch<CS, ConvP, ADgradNinGen<CS>, BDgrad<CS, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
+  if (big) return launch<CB, ConvP, ADgradNin<CB>, BDgrad<CB, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
+  return launch<CS, ConvP, ADgradNin<CS>, BDgrad<CS, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
 }
 
 long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW) {
@@ -506,14 +685,19 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
   if (rc) return rc;
   const WgradPlan q = wgrad_plan(p.Cin, N, Cout, OH, OW, KH, KW);
   if (ws_bytes < (long)q.splits * q.slab * 4) return STK_EINVAL;
-  p.x1 = x1; p.x2 = C2 > 0 ? x2 : nullptr; p.dy = dy; p.w_layout = w_layout; p.part = ws; p.part_stride = q.slab;
+  p.x1 = x1; p.x2 = C2 > 0 ? x2 : x1; p.dy = dy; p.w_layout = w_layout; p.part = ws; p.part_stride = q.slab;
   const long Kl = (long)N * p.OHW;
   if (Kl > 0x7fffffffL) return STK_EUNSUPPORTED;
   const int K = (int)Kl;
   hipStream_t s = (hipStream_t)stream;
   using CB = Cfg<128, 128, 32>; using CS = Cfg<64, 64, 32>;
-  if (q.big) rc = launch<CB, ConvP, AWgrad<CB>, BWgrad<CB>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s);
-  else rc = launch<CS, ConvP, AWgrad<CS>, BWgrad<CS>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s);
+  if (C2 > 0) {
+    if (q.big) rc = launch<CB, ConvP, AWgrad<CB>, BWgrad<CB, true>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s);
+    else rc = launch<CS, ConvP, AWgrad<CS>, BWgrad<CS, true>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s);
+  } else {
+    if (q.big) rc = launch<CB, ConvP, AWgrad<CB>, BWgrad<CB, false>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s);
+    else rc = launch<CS, ConvP, AWgrad<CS>, BWgrad<CS, false>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s);
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid(q.slab)), dim3(256), 0, s, ws, dw, q.slab, q.splits,
                      q.slab, alpha);
@@ -531,8 +715,9 @@ int stk_gemm_f32(const float* A, long sam, long sak, long sab, const float* B, l
   p.A = A; p.sam = sam; p.sak = sak; p.sab = sab; p.B = B; p.sbk = sbk; p.sbn = sbn; p.sbb = sbb;
   p.C = C; p.scm = scm; p.scn = scn; p.scb = scb; p.bias = bias; p.bias_mode = bias_mode;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.beta = beta;
-  const bool ak = sak == 1 || sam != 1;   // lanes along k unless m is the contiguous index
-  const bool bk = sbk == 1 && sbn != 1;   // lanes along n unless only k is contiguous
+  // row-chunk loaders need unit k stride and whole 8-float chunks; anything else goes lanes-along-m/n
+  const bool ak = sak == 1 && (K % 8) == 0;
+  const bool bk = sbk == 1 && sbn != 1 && (K % 8) == 0;
   const bool big = use_big_tile(M, N, batch);
   hipStream_t s = (hipStream_t)stream;
   using CB = Cfg<128, 128, 32>; using CS = Cfg<64, 64, 32>;

@@ -69,12 +69,16 @@ struct KMajor {
 // ------------------------------------------------------------------------------------------------
 // The kernel.  AL / BL: loaders with
 //     __device__ void init(const P&, int tile_origin, int tid, int zb);
-//     __device__ void load(const P&, int k0, float (&r)[N]);   // global -> registers, zero-filled
-//     __device__ void store(const float (&r)[N], float* lds);  // registers -> LDS tile [KC][LD]
+//     __device__ void load(const P&, int k0, float (&r)[N]);   // global -> registers: UNCONDITIONAL loads from
+//                                                              //   safe addresses + a validity bitmask kept aside
+//     __device__ void store(const float (&r)[N], float* lds);  // registers -> LDS tile [KC][LD], invalid -> 0
+//   (the zeroing happens at store time, i.e. after the MFMAs of the previous chunk, so the loads of a chunk
+//    are never waited for before the matrix work that hides them)
 // EP: epilogue with
 //     __device__ void init(const P&, int zb, int zs);
 //     __device__ void col(const P&, int n);                     // per output column setup
-//     __device__ void put(const P&, int m, int n, float acc);   // one output element
+//     __device__ void strip(const P&, int mbase, int M, bool nok, int n, const floatx16& acc);
+//                                                               // 16 rows mbase + strip_row(e) of column n
 // Grid: x = tiles (XCD-remapped, m fastest), y = split-K slice, z = batch.
 // ------------------------------------------------------------------------------------------------
 template <class C, class P, class AL, class BL, class EP>
@@ -140,22 +144,27 @@ __global__ __launch_bounds__(256) void kernel(P p, int M, int N, int K, int tile
   }
 
   // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  // The epilogue handles one 16-register strip (one column, 16 rows) at a time so that it can batch its
+  // own loads (bias / residual / old values) instead of waiting on them one by one.
   EP ep;
   ep.init(p, zb, zs);
 #pragma unroll
   for (int j = 0; j < C::TN; ++j) {
     const int n = n0 + wn0 + j * 32 + fc;
-    if (n >= N) continue;
-    ep.col(p, n);
+    const bool nok = n < N;
+    ep.col(p, nok ? n : 0);
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fk;
-        if (m < M) ep.put(p, m, n, acc[i][j][e]);
-      }
-    }
+    for (int i = 0; i < C::TM; ++i) ep.strip(p, m0 + wm0 + i * 32 + 4 * fk, M, nok, nok ? n : 0, acc[i][j]);
   }
+}
+
+// row of strip element e (relative to the strip base)
+__device__ __forceinline__ constexpr int strip_row(int e) { return (e & 3) + 8 * (e >> 2); }
+
+// Zero a value unless bit `idx` of `okm` is set -- two VALU ops (bfe + and), no VCC, no branch.
+__device__ __forceinline__ float keep_if(float v, unsigned okm, int idx) {
+  const int m = -(int)((okm >> idx) & 1u);
+  return __int_as_float(__float_as_int(v) & m);
 }
 
 // Generic LDS store helpers -----------------------------------------------------------------------------

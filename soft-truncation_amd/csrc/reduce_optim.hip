@@ -67,13 +67,24 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ d
     out[(long)n * out_stride + c] = alpha * s;
   }
 }
-// dbias[c] += sum_n src[n*stride + c]
-__global__ void colsum_acc_kernel(const float* __restrict__ src, float* __restrict__ dbias, int N, int C, int stride) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// dbias[c] += sum_n src[n*stride + c].  32 channels per 256-thread block: thread (c = t%32, part = t/32)
+// sums every 8th row (32 consecutive floats per row segment -> coalesced), LDS folds the 8 parts.
+__global__ __launch_bounds__(256) void colsum_acc_kernel(const float* __restrict__ src, float* __restrict__ dbias, int N,
+                                                         int C, int stride) {
+  __shared__ float red[256];
+  const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int n = 0; n < N; ++n) s += src[(long)n * stride + c];
-  dbias[c] += s;
+  if (c < C)
+    for (int n = part; n < N; n += 8) s += src[(long)n * stride + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q * 32 + cl];
+    dbias[c] += t;
+  }
 }
 
 // ---- sum of squares (deterministic two-stage) -------------------------------------------------------
@@ -216,7 +227,7 @@ int stk_bias_grad_f32(const float* dy, int N, int C, int HW, float alpha, float*
                      alpha);
   STK_CHECK_LAUNCH();
   if (dbias) {
-    hipLaunchKernelGGL(colsum_acc_kernel, dim3(stk_cdiv(C, 128)), dim3(128), 0, S(stream), rows, dbias, N, C, stride);
+    hipLaunchKernelGGL(colsum_acc_kernel, dim3(stk_cdiv(C, 32)), dim3(256), 0, S(stream), rows, dbias, N, C, stride);
     STK_CHECK_LAUNCH();
   }
   return STK_OK;

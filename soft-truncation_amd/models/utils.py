@@ -83,6 +83,10 @@ def create_model(config, sde):
   """Instantiate ``config.model.name`` on ``config.device`` (models/utils.py:89-95)."""
   score_model = get_model(config.model.name)(config, sde)
   score_model = score_model.to(config.device)
+  if hasattr(score_model, 'engine'):
+    # bind the parameters to the flat HBM buffers now, so the optimizer and the EMA created right after
+    # (utils.load_model) see the final storage.  Loads libstk.so: raises if the HIP library is missing.
+    score_model.engine().ensure_flat()
   return DataParallel(score_model)
 
 
