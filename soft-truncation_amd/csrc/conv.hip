@@ -40,6 +40,7 @@ struct ConvP {
   float* part; long part_stride;
   int N, H, W, Cin, Cout, OH, OW, KH, KW, stride, pad, sshift;
   int HW, OHW, taps;
+  int ohw_shift, ow_shift;    // log2 when OHW / OW are powers of two, else -1
 };
 
 // ---- loaders ---------------------------------------------------------------------------------------------
@@ -318,25 +319,39 @@ struct BDgrad {
 
 // ---- wgrad loaders (K = pixels, lanes along pixels; tap = blockIdx.z) ------------------------------------
 // KC = 32: kk = tid & 31 is this thread's pixel inside the chunk for every element, mn = tid/32 + 8 i.
+// Pixel index -> (image, pixel in image) and (row, column); shifts when the sizes are powers of two.
+__device__ __forceinline__ void split_pixel(const ConvP& p, int k, int& b, int& ohw) {
+  if (p.ohw_shift >= 0) { b = k >> p.ohw_shift; ohw = k & (p.OHW - 1); }
+  else { b = k / p.OHW; ohw = k - b * p.OHW; }
+}
+__device__ __forceinline__ void split_row(const ConvP& p, int ohw, int& oy, int& ox) {
+  if (p.ow_shift >= 0) { oy = ohw >> p.ow_shift; ox = ohw & (p.OW - 1); }
+  else { oy = ohw / p.OW; ox = ohw - oy * p.OW; }
+}
+
 template <class C>
 struct AWgrad {       // A(m=co, k=pixel) = dy[b, co, ohw]
   static_assert(C::KC == 32 && C::NA <= 32, "wgrad uses 32-pixel chunks");
-  int m0, tid; unsigned okm;
-  __device__ void init(const ConvP&, int m0_, int tid_, int) { m0 = m0_; tid = tid_; okm = 0; }
+  int roff[C::NA];     // (clamped) row offsets m*OHW: chunk-invariant, so they are computed once
+  int tid; unsigned okrows, okm;
+  __device__ void init(const ConvP& p, int m0, int tid_, int) {
+    tid = tid_; okm = 0; okrows = 0;
+#pragma unroll
+    for (int i = 0; i < C::NA; ++i) {
+      const int m = m0 + (tid >> 5) + 8 * i;
+      okrows |= (m < p.Cout ? 1u : 0u) << i;
+      roff[i] = min(m, p.Cout - 1) * p.OHW;
+    }
+  }
   __device__ void load(const ConvP& p, int k0, float (&r)[C::NA]) {
     const int k = k0 + (tid & 31);
     const bool kv = k < p.N * p.OHW;
-    const int b = kv ? k / p.OHW : 0;
-    const int base = b * p.Cout * p.OHW + (kv ? k - b * p.OHW : 0);
-    const int mrow = m0 + (tid >> 5);
-    okm = 0;
+    int b, ohw;
+    split_pixel(p, kv ? k : 0, b, ohw);
+    const int base = b * p.Cout * p.OHW + ohw;     // pixel 0 of image 0 when the pixel is out of range
+    okm = kv ? okrows : 0u;
 #pragma unroll
-    for (int i = 0; i < C::NA; ++i) {
-      const int m = mrow + 8 * i;
-      const bool ok = kv && m < p.Cout;
-      r[i] = p.dy[ok ? base + m * p.OHW : 0];
-      okm |= (ok ? 1u : 0u) << i;
-    }
+    for (int i = 0; i < C::NA; ++i) r[i] = p.dy[base + roff[i]];
   }
   __device__ void store(const float (&r)[C::NA], float* t) {
 #pragma unroll
@@ -346,36 +361,40 @@ struct AWgrad {       // A(m=co, k=pixel) = dy[b, co, ohw]
 template <class C, bool DUAL>
 struct BWgrad {       // B(k=pixel, n=ci) = x[b, ci, oy*s + kh - pad, ox*s + kw - pad]
   static_assert(C::KC == 32 && C::NB <= 32, "wgrad uses 32-pixel chunks");
-  int n0, tid, kh, kw; unsigned okm;
-  __device__ void init(const ConvP& p, int n0_, int tid_, int zb) {
-    n0 = n0_; tid = tid_; okm = 0;
+  int roff[C::NB];     // (clamped) channel offsets ci*HW inside its source tensor
+  int tid, kh, kw; unsigned okrows, okm, first;
+  __device__ void init(const ConvP& p, int n0, int tid_, int zb) {
+    tid = tid_; okm = 0; okrows = 0; first = 0;
     kh = zb / p.KW; kw = zb - kh * p.KW;
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) {
+      const int ci = min(n0 + (tid >> 5) + 8 * i, p.Cin - 1);
+      okrows |= (n0 + (tid >> 5) + 8 * i < p.Cin ? 1u : 0u) << i;
+      const bool f = !DUAL || ci < p.C1;
+      first |= (f ? 1u : 0u) << i;
+      roff[i] = (f ? ci : ci - p.C1) * p.HW;
+    }
   }
   __device__ void load(const ConvP& p, int k0, float (&r)[C::NB]) {
     const int k = k0 + (tid & 31);
     bool kv = k < p.N * p.OHW;
-    const int b = kv ? k / p.OHW : 0;
-    const int ohw = kv ? k - b * p.OHW : 0;
-    const int oy = ohw / p.OW, ox = ohw - oy * p.OW;
+    int b, ohw, oy, ox;
+    split_pixel(p, kv ? k : 0, b, ohw);
+    split_row(p, ohw, oy, ox);
     const int iy = oy * p.stride + kh - p.pad, ix = ox * p.stride + kw - p.pad;
     kv = kv && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    const int pix = iy * p.W + ix;
+    const int pix = kv ? iy * p.W + ix : 0;
     const int b1 = b * p.C1 * p.HW + pix, b2 = b * p.C2 * p.HW + pix;
-    const int crow = n0 + (tid >> 5);
-    okm = 0;
+    okm = kv ? okrows : 0u;
 #pragma unroll
     for (int i = 0; i < C::NB; ++i) {
-      const int ci = crow + 8 * i;
-      const bool ok = kv && ci < p.Cin;
       if (DUAL) {
-        const bool first = ci < p.C1;
-        const uintptr_t tensor = first ? (uintptr_t)p.x1 : (uintptr_t)p.x2;
-        const int off = first ? b1 + ci * p.HW : b2 + (ci - p.C1) * p.HW;
-        r[i] = ((const gfloat*)tensor)[ok ? off : 0];
+        const bool f = (first >> i) & 1u;
+        const uintptr_t tensor = f ? (uintptr_t)p.x1 : (uintptr_t)p.x2;
+        r[i] = ((const gfloat*)tensor)[(f ? b1 : b2) + roff[i]];
       } else {
-        r[i] = p.x1[ok ? b1 + ci * p.HW : 0];
+        r[i] = p.x1[b1 + roff[i]];
       }
-      okm |= (ok ? 1u : 0u) << i;
     }
   }
   __device__ void store(const float (&r)[C::NB], float* t) {
@@ -451,7 +470,7 @@ struct EpDgrad {      // dx{1,2} = beta*dx + alpha*acc, rows routed to the two s
       if (d[e]) *d[e] = ((acc1 || acc2) ? old[e] : 0.f) + p.alpha * acc[e];
   }
 };
-struct EpWgrad {      // partial slab of split zs, tap zb, in the weight's own layout
+struct EpWgrad {      // partial slab of split zs as [tap][Cout][Cin] (coalesced); the reduce kernel re-lays it out
   float* slab; int tap;
   __device__ void init(const ConvP& p, int zb, int zs) { slab = p.part + (long)zs * p.part_stride; tap = zb; }
   __device__ void col(const ConvP&, int) {}
@@ -460,19 +479,29 @@ struct EpWgrad {      // partial slab of split zs, tap zb, in the weight's own l
     for (int e = 0; e < 16; ++e) {
       const int m = mbase + strip_row(e);
       if (nok && m < M) {
-        if (p.w_layout == 0) slab[((long)m * p.Cin + n) * p.taps + tap] = acc[e];
-        else slab[(long)n * p.Cout + m] = acc[e];
+        slab[((long)tap * p.Cout + m) * p.Cin + n] = acc[e];     // [tap][co][ci]: lanes (= ci) contiguous
       }
     }
   }
 };
 
+// dw (in the weight's own layout) += alpha * sum over splits of slab[tap][co][ci]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                            long n, int splits, long stride, float alpha) {
+                                                            long n, int splits, long stride, float alpha, int layout,
+                                                            int Cout, int Cin, int taps) {
   const long gstride = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += gstride) {
+    long src;
+    if (layout == 0) {           // i = (co*Cin + ci)*taps + tap
+      const int tap = (int)(i % taps);
+      const long mc = i / taps;  // co*Cin + ci
+      src = (long)tap * Cout * Cin + mc;
+    } else {                     // NIN: i = ci*Cout + co
+      const int co = (int)(i % Cout), ci = (int)(i / Cout);
+      src = (long)co * Cin + ci;
+    }
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += part[(long)z * stride + i];
+    for (int z = 0; z < splits; ++z) s += part[(long)z * stride + src];
     dw[i] += alpha * s;
   }
 }
@@ -553,12 +582,20 @@ inline bool use_big_tile(int M, long N, int z) {
 }
 
 template <class C, class P, class AL, class BL, class EP>
-int launch(const P& p, int M, long Nl, int K, int k_per_split, int splits, int batch, hipStream_t s) {
+int launch(const P& p, int M, long Nl, int K, int k_per_split, int splits, int batch, hipStream_t s,
+           bool flat = false) {
   if (Nl > 0x7fffffffL) return STK_EUNSUPPORTED;
   const int N = (int)Nl;
   const int tm = stk_cdiv(M, C::BM), tn = stk_cdiv(N, C::BN);
-  dim3 grid((unsigned)(tm * tn), (unsigned)splits, (unsigned)batch);
-  hipLaunchKernelGGL((igemm::kernel<C, P, AL, BL, EP>), grid, dim3(256), 0, s, p, M, N, K, tm, tn, k_per_split);
+  if (flat) {      // batch (= taps) fastest, then tiles, then splits, all in grid.x
+    const long total = (long)tm * tn * splits * batch;
+    if (total > 0x7fffffffL) return STK_EUNSUPPORTED;
+    hipLaunchKernelGGL((igemm::kernel<C, P, AL, BL, EP>), dim3((unsigned)total), dim3(256), 0, s, p, M, N, K, tm, tn,
+                       k_per_split, batch);
+  } else {
+    dim3 grid((unsigned)(tm * tn), (unsigned)splits, (unsigned)batch);
+    hipLaunchKernelGGL((igemm::kernel<C, P, AL, BL, EP>), grid, dim3(256), 0, s, p, M, N, K, tm, tn, k_per_split, 0);
+  }
   STK_CHECK_LAUNCH();
   return STK_OK;
 }
@@ -574,6 +611,11 @@ inline int fill_common(ConvP& p, int N, int H, int W, int C1, int C2, int Cout, 
   p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.Cin = C1 + C2; p.Cout = Cout; p.OH = OH; p.OW = OW;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.sshift = stride == 2 ? 1 : 0;
   p.HW = H * W; p.OHW = OH * OW; p.taps = KH * KW;
+  p.ohw_shift = -1; p.ow_shift = -1;
+  for (int sft = 0; sft < 31; ++sft) {
+    if ((1 << sft) == p.OHW) p.ohw_shift = sft;
+    if ((1 << sft) == p.OW) p.ow_shift = sft;
+  }
   return STK_OK;
 }
 
@@ -582,12 +624,15 @@ inline WgradPlan wgrad_plan(int Cin, int N, int Cout, int OH, int OW, int KH, in
   WgradPlan q;
   const int taps = KH * KW;
   const long K = (long)N * OH * OW;
-  q.big = (Cout >= 96 && Cin >= 96) ? 1 : 0;
+  // 128x128 tiles halve the operand traffic per FLOP, but a 1x1 layer has too few of them: with so few tiles
+  // the K split would have to be so fine that writing / re-reading the partial slabs dominates.
+  const long tiles128 = (long)stk_cdiv(Cout, 128) * stk_cdiv(Cin, 128) * taps;
+  q.big = (Cout >= 96 && Cin >= 96 && tiles128 >= 9) ? 1 : 0;
   const int T = q.big ? 128 : 64;
   const long tiles = (long)stk_cdiv(Cout, T) * stk_cdiv(Cin, T) * taps;
   const long chunks = (K + 31) / 32;
   long splits = (512 + tiles - 1) / tiles;
-  if (splits > chunks / 4) splits = chunks / 4;
+  if (splits > chunks / 16) splits = chunks / 16;      // >= 16 chunks (512 pixels) of work per block
   if (splits < 1) splits = 1;
   const long cps = (chunks + splits - 1) / splits;
   q.k_per_split = (int)(cps * 32);
@@ -692,15 +737,15 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
   hipStream_t s = (hipStream_t)stream;
   using CB = Cfg<128, 128, 32>; using CS = Cfg<64, 64, 32>;
   if (C2 > 0) {
-    if (q.big) rc = launch<CB, ConvP, AWgrad<CB>, BWgrad<CB, true>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s);
-    else rc = launch<CS, ConvP, AWgrad<CS>, BWgrad<CS, true>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s);
+    if (q.big) rc = launch<CB, ConvP, AWgrad<CB>, BWgrad<CB, true>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s, true);
+    else rc = launch<CS, ConvP, AWgrad<CS>, BWgrad<CS, true>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s, true);
   } else {
-    if (q.big) rc = launch<CB, ConvP, AWgrad<CB>, BWgrad<CB, false>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s);
-    else rc = launch<CS, ConvP, AWgrad<CS>, BWgrad<CS, false>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s);
+    if (q.big) rc = launch<CB, ConvP, AWgrad<CB>, BWgrad<CB, false>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s, true);
+    else rc = launch<CS, ConvP, AWgrad<CS>, BWgrad<CS, false>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s, true);
   }
   if (rc) return rc;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid(q.slab)), dim3(256), 0, s, ws, dw, q.slab, q.splits,
-                     q.slab, alpha);
+                     q.slab, alpha, w_layout, Cout, p.Cin, p.taps);
   STK_CHECK_LAUNCH();
   return STK_OK;
 }

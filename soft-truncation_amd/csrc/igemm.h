@@ -79,10 +79,12 @@ struct KMajor {
 //     __device__ void col(const P&, int n);                     // per output column setup
 //     __device__ void strip(const P&, int mbase, int M, bool nok, int n, const floatx16& acc);
 //                                                               // 16 rows mbase + strip_row(e) of column n
-// Grid: x = tiles (XCD-remapped, m fastest), y = split-K slice, z = batch.
+// Grid: x = tiles (XCD-remapped, m fastest), y = split-K slice, z = batch;  or, with flat_z > 0, one flat
+// x dimension of flat_z * tiles * splits blocks (see the kernel body).
 // ------------------------------------------------------------------------------------------------
 template <class C, class P, class AL, class BL, class EP>
-__global__ __launch_bounds__(256) void kernel(P p, int M, int N, int K, int tiles_m, int tiles_n, int k_per_split) {
+__global__ __launch_bounds__(256) void kernel(P p, int M, int N, int K, int tiles_m, int tiles_n, int k_per_split,
+                                              int flat_z) {
   __shared__ float lds[C::LDS_FLOATS];
   float* As = lds;
   float* Bs = lds + C::KC * C::LDA;
@@ -90,10 +92,23 @@ __global__ __launch_bounds__(256) void kernel(P p, int M, int N, int K, int tile
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int ntiles = tiles_m * tiles_n;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
+  int tile, zs, zb;
+  if (flat_z > 0) {
+    // wgrad: grid.x = flat_z (taps) x tiles x splits with the tap index fastest, so the blocks that read the
+    // SAME dy / x panels (one per tap) are neighbours in the XCD-remapped order and share them in one L2
+    // instead of fetching them from HBM once per tap.
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    zb = id % flat_z;
+    const int rest = id / flat_z;
+    tile = rest % ntiles;
+    zs = rest / ntiles;
+  } else {
+    tile = xcd_remap(blockIdx.x, ntiles);
+    zs = blockIdx.y;
+    zb = blockIdx.z;
+  }
   const int tm = tile % tiles_m, tn = tile / tiles_m;
   const int m0 = tm * C::BM, n0 = tn * C::BN;
-  const int zs = blockIdx.y, zb = blockIdx.z;
   const int k_begin = zs * k_per_split;
   const int k_end = min(K, k_begin + k_per_split);
 

@@ -173,7 +173,7 @@ class Conv(Op):
   def _kind(self, direction, M, Ncols, wgrad=False):
     """Kernel-symbol label: direction, taps and the tile variant csrc/conv.hip picks for this shape."""
     if wgrad:
-      big = M >= 96 and Ncols >= 96
+      big = M >= 96 and Ncols >= 96 and -(-M // 128) * -(-Ncols // 128) * self.KH * self.KW >= 9
     else:
       t = -(-M // 128) * -(-Ncols // 128)
       big = M >= 96 and Ncols >= 96 and t >= 192

@@ -3,7 +3,7 @@
 ``load()`` returns the product library (``csrc/libstk.so``, hand-written HIP for gfx950) and
 raises :class:`StkMissingError` when it has not been built -- there is no CPU or PyTorch
 fallback anywhere in the product path.  ``load_path()`` binds any library implementing the same
-header; tests use it to inject the oracle's ``oracle/libstk_ref.so`` as a *checker* backend for
+header; tests use it to inject the oracle's plain-C restatement as a *checker* backend for
 host-logic tests on CPU tensors.
 """
 import ctypes

@@ -1,0 +1,95 @@
+"""Worker for tests/test_ddp_gloo.py: one rank of a world_size-2 gloo job on CPU."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+import contextlib
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class ShardedDraws:
+  """Rank r of W gets rows [r*n, (r+1)*n) of the noise a single process would draw for the W*n batch."""
+
+  def __init__(self, seed, rank, world):
+    self.g = torch.Generator().manual_seed(seed)
+    self.rank, self.world = rank, world
+
+  def _cut(self, full, n):
+    return full[self.rank * n:(self.rank + 1) * n].clone()
+
+  def rand(self, *size, device=None, **kw):
+    n = size[0]
+    return self._cut(torch.empty(n * self.world, *size[1:]).uniform_(generator=self.g), n)
+
+  def randn_like(self, x, **kw):
+    n = x.shape[0]
+    return self._cut(torch.empty(n * self.world, *x.shape[1:]).normal_(generator=self.g), n)
+
+
+@contextlib.contextmanager
+def sharded_rng(seed, rank, world):
+  d = ShardedDraws(seed, rank, world)
+  saved = (torch.rand, torch.randn_like)
+  torch.rand, torch.randn_like = d.rand, d.randn_like
+  try:
+    yield
+  finally:
+    torch.rand, torch.randn_like = saved
+
+
+def build(st, lib, family='vp'):
+  from _model_util import randomize_, tiny_config
+  cfg = tiny_config(st, family)
+  cfg.optim.warmup = 2
+  sde = st.sde_lib.get_sde(cfg, None)
+  net = st.models.ncsnpp.NCSNpp(cfg, sde)
+  net.set_backend(lib)
+  randomize_(net, 0)
+  model = st.models.utils.DataParallel(net)
+  net.engine().ensure_flat()
+  opt = st.losses.get_optimizer(cfg, model.parameters())
+  opt._backend = lib
+  ema = st.models.ema.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+  ema.set_backend(lib)
+  state = dict(optimizer=opt, model=model, ema=ema, step=0)
+  step_fn = st.losses.get_step_fn(cfg, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg))
+  return cfg, state, step_fn
+
+
+def run_steps(st, lib, rank, world, steps, global_batch):
+  cfg, state, step_fn = build(st, lib)
+  st.engine.ddp.seed_everything(123)          # numpy shared -> the same t_min on every rank
+  losses = []
+  for i in range(steps):
+    full = st.datasets.synthetic_batch(cfg, global_batch, generator=torch.Generator().manual_seed(100 + i))
+    local = st.engine.ddp.shard_batch(full) if world > 1 else full
+    with sharded_rng(50 + i, rank, world):
+      losses.append(step_fn(state, local))
+  flat = state['model'].module.engine().flat
+  return torch.cat(losses), flat.data[:flat.n_train].clone(), state['ema']._shadow.clone()
+
+
+def worker(rank, world, port, outdir):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  torch.set_num_threads(2)
+  import soft_truncation_amd as st
+  lib = st.engine.lib.load_path(os.path.join(ROOT, 'oracle', 'libstk_ref.so'))
+  # 1) the bucketed all-reduce itself
+  buf = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+  nb = st.engine.ddp.allreduce_flat_(buf, 1000, bucket_mb=0.001, average=True)     # ~262-element buckets
+  assert nb == 4
+  assert torch.allclose(buf, torch.arange(1000, dtype=torch.float32) * 1.5)
+  # 2) two training steps on this rank's shard
+  losses, params, shadow = run_steps(st, lib, rank, world, steps=2, global_batch=4)
+  torch.save({'losses': losses, 'params': params, 'shadow': shadow}, os.path.join(outdir, f'rank{rank}.pt'))
+  dist.barrier()
+  dist.destroy_process_group()

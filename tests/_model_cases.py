@@ -186,3 +186,34 @@ def checkpoint_roundtrip(st, lib, tmp_path):
   assert torch.equal(state['optimizer']._m.cpu(), state2['optimizer']._m.cpu())
   for a, b in zip(state['ema'].shadow_params, state2['ema'].shadow_params):
     assert torch.equal(a.cpu(), b.cpu())
+
+
+def golden_forward_backward(st, lib, family):
+  """Product path against the committed fixtures generated from the reference itself."""
+  import os
+  g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', f'model_{family}.npz')))
+  base = {'vp': st.configs.cifar10_ddpmpp_nll_st, 'rve': st.configs.celeba_uncsnpp_st,
+          've': st.configs.celebahq_uncsnpp_st}[family]()
+  cfg = st.configs.tiny(base, nf=8, ch_mult=(1, 1, 2) if family == 've' else (1, 2), num_res_blocks=1,
+                        image_size=8, attn_resolutions=(4,), dropout=0.0)
+  dev = torch.device('cuda:0') if lib.is_device else torch.device('cpu')
+  cfg.device = dev
+  net = st.models.ncsnpp.NCSNpp(cfg, None)
+  net.load_state_dict({k[3 + len('module.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('sd.')})
+  net.set_backend(lib)
+  net = net.to(dev).eval()
+  x, cond = torch.from_numpy(g['x']).to(dev), torch.from_numpy(g['cond']).to(dev)
+  xr = x.clone().requires_grad_(True)
+  y = net(xr, cond)
+  assert rel_err(y, torch.from_numpy(g['net'])) <= TOL
+  (y * torch.from_numpy(g['go']).to(dev)).sum().backward()
+  assert rel_err(xr.grad, torch.from_numpy(g['gx'])) <= TOL
+  grads = dict(net.named_parameters())
+  scale = float(np.sqrt(g['grad_sumsq']))
+  for n in g['grad_names']:
+    got = grads[str(n)[len('module.'):]].grad.detach().cpu().numpy()
+    assert np.abs(got - g['grad.' + str(n)]).max() <= TOL * scale, n
+  sde = st.sde_lib.get_sde(cfg, None)
+  model = st.models.utils.DataParallel(net)
+  s = st.models.utils.get_score_fn(cfg, sde, model, train=False, continuous=True)(x, torch.from_numpy(g['t']).to(dev))
+  assert rel_err(s, torch.from_numpy(g['score'])) <= TOL

@@ -1,0 +1,65 @@
+"""The C-ABI boundary: both libraries export every symbol include/stk.h declares (no compute calls), the
+ctypes signature table covers the header, and the product path fails loudly when libstk.so is missing."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'stk.h')
+PRODUCT = os.path.join(ROOT, 'soft-truncation_amd', 'csrc', 'libstk.so')
+CHECKER = os.path.join(ROOT, 'oracle', 'libstk_ref.so')
+
+
+def header_symbols():
+  text = open(HEADER).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(stk_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_entries():
+  syms = header_symbols()
+  assert len(syms) >= 30
+  for must in ('stk_upfirdn2d_f32', 'stk_fused_bias_act_f32', 'stk_gn_fwd_f32', 'stk_conv2d_fwd_f32',
+               'stk_conv2d_dgrad_f32', 'stk_conv2d_wgrad_f32', 'stk_gemm_f32', 'stk_adam_f32'):
+    assert must in syms
+
+
+def test_signature_table_covers_header(st):
+  assert sorted(st.engine.lib.SIGNATURES) == header_symbols()
+
+
+@pytest.mark.parametrize('path', [PRODUCT, CHECKER], ids=['libstk.so', 'libstk_ref.so'])
+def test_library_exports_every_symbol(path, ref_lib):
+  if not os.path.exists(path):
+    import subprocess
+    subprocess.check_call(['make', '-C', os.path.dirname(path)])
+  dll = ctypes.CDLL(path)
+  for sym in header_symbols():
+    assert hasattr(dll, sym), f'{os.path.basename(path)} does not export {sym}'
+  dll.stk_backend.restype = ctypes.c_char_p
+  assert dll.stk_backend().decode() == ('hip-gfx950' if path == PRODUCT else 'cpu-ref')
+
+
+def test_missing_library_is_an_error_not_a_fallback(st, monkeypatch, tmp_path):
+  lib = st.engine.lib
+  monkeypatch.setattr(lib, 'PRODUCT_LIB', str(tmp_path / 'nope' / 'libstk.so'))
+  with pytest.raises(lib.StkMissingError):
+    lib.load()
+  # ... and that error reaches the user of the reference-style API
+  import torch
+  cfg = st.configs.tiny(st.configs.cifar10_ddpmpp_nll_st())
+  cfg.device = torch.device('cpu')
+  with pytest.raises(lib.StkMissingError):
+    st.models.utils.create_model(cfg, st.sde_lib.get_sde(cfg, None))
+
+
+def test_product_never_imports_the_oracle():
+  """No module of the package may import, load or reference anything under oracle/."""
+  pkg = os.path.join(ROOT, 'soft-truncation_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith(('.py', '.hip', '.h')):
+        text = open(os.path.join(dirpath, f)).read()
+        assert 'ref_torch' not in text and 'refimport' not in text and 'libstk_ref' not in text, os.path.join(dirpath, f)

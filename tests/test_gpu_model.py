@@ -46,3 +46,20 @@ def test_ode_sampler(st, hip_lib):
 
 def test_checkpoint_roundtrip(st, hip_lib, tmp_path):
   cases.checkpoint_roundtrip(st, hip_lib, tmp_path)
+
+
+@pytest.mark.parametrize('family', ['vp', 'rve', 've'])
+def test_golden_fixtures(st, hip_lib, family):
+  cases.golden_forward_backward(st, hip_lib, family)
+
+
+def test_product_fails_loudly_without_gpu_tensors(st, hip_lib):
+  """The HIP backend refuses CPU tensors instead of falling back."""
+  import torch
+  cfg = st.configs.tiny(st.configs.cifar10_ddpmpp_nll_st())
+  cfg.device = torch.device('cpu')
+  net = st.models.ncsnpp.NCSNpp(cfg, None)
+  with pytest.raises(RuntimeError, match='no CPU'):
+    net(torch.zeros(1, 3, 16, 16), torch.zeros(1))
+  with pytest.raises(RuntimeError, match='HIP'):
+    st.op.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2))

@@ -1,0 +1,125 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of individual C-ABI entry points on the shapes of the DDPM++ 32x32 / batch-128 step.
+
+    python tools/bench_kernels.py [--only conv] [--reps 20]
+
+Prints one line per (kernel, shape): average microseconds (HIP events on the launch stream), the
+algorithmic TFLOP/s or GB/s and the fraction of the relevant MI355X roofline (157.3 TFLOP/s fp32 MFMA,
+8.0 TB/s HBM).  Development tool: used to iterate on kernels between full bench.py runs.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+import torch
+
+import soft_truncation_amd as st
+from _util import call
+
+
+def timeit(fn, reps):
+  for _ in range(3):
+    fn()
+  torch.cuda.synchronize()
+  s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  s.record()
+  for _ in range(reps):
+    fn()
+  e.record()
+  torch.cuda.synchronize()
+  return s.elapsed_time(e) * 1e3 / reps   # us
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--only', default='')
+  ap.add_argument('--reps', type=int, default=20)
+  ap.add_argument('--batch', type=int, default=128)
+  args = ap.parse_args()
+  lib = st.engine.lib.load()
+  d = torch.device('cuda:0')
+  N = args.batch
+  rows = []
+
+  def rec(name, shape, us, flops=None, nbytes=None):
+    if flops:
+      tf = flops / us / 1e6
+      rows.append(f'{name:<22} {shape:<34} {us:10.1f} us {tf:8.1f} TF/s  {tf / 157.3:6.1%} of fp32-MFMA')
+    else:
+      gb = nbytes / us / 1e3
+      rows.append(f'{name:<22} {shape:<34} {us:10.1f} us {gb:8.0f} GB/s  {gb / 8000:6.1%} of HBM')
+    print(rows[-1], flush=True)
+
+  conv_shapes = [
+    # C1, C2, H, Cout, K
+    (128, 0, 32, 128, 3), (256, 0, 16, 256, 3), (256, 0, 8, 256, 3), (256, 0, 4, 256, 3),
+    (128, 0, 16, 256, 3), (384, 0, 32, 128, 3), (512, 0, 16, 256, 3), (512, 0, 8, 256, 3),
+    (256, 256, 16, 256, 1), (256, 0, 16, 256, 1), (128, 0, 16, 256, 1),
+  ]
+  if not args.only or 'conv' in args.only:
+    for C1, C2, H, Cout, K in conv_shapes:
+      Cin = C1 + C2
+      x1 = torch.randn(N, C1, H, H, device=d)
+      x2 = torch.randn(N, C2, H, H, device=d) if C2 else None
+      w = torch.randn(Cout, Cin, K, K, device=d) * 0.02
+      bias = torch.randn(Cout, device=d)
+      y = torch.empty(N, Cout, H, H, device=d)
+      dy = torch.randn(N, Cout, H, H, device=d)
+      dx1 = torch.empty_like(x1)
+      dx2 = torch.empty_like(x2) if C2 else None
+      dw = torch.zeros_like(w)
+      nb = int(lib.conv2d_wgrad_ws_bytes(C1, C2, N, Cout, H, H, K, K))
+      ws = torch.empty(nb // 4 + 64, device=d)
+      dims = (N, H, H, Cout, H, H, K, K, 1, K // 2)
+      flops = 2.0 * N * H * H * Cout * Cin * K * K
+      shape = f'{Cin}->{Cout} {K}x{K} @{H}x{H} b{N}' + (' dual' if C2 else '')
+      rec('conv.fwd', shape, timeit(lambda: call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, 0, bias, None, 0, None, 1.0, y, *dims), args.reps), flops)
+      rec('conv.dgrad', shape, timeit(lambda: call(lib, 'conv2d_dgrad_f32', dy, w, 0, dx1, C1, 0.0, dx2, C2, 0.0, 1.0, *dims), args.reps), flops)
+      rec('conv.wgrad', shape, timeit(lambda: call(lib, 'conv2d_wgrad_f32', x1, C1, x2, C2, dy, dw, 0, 1.0, ws, ws.numel() * 4, *dims), args.reps), flops)
+
+  if not args.only or 'gn' in args.only:
+    for C, H in [(128, 32), (256, 16), (256, 8), (384, 32), (512, 16)]:
+      G = 32
+      x = torch.randn(N, C, H, H, device=d)
+      g, b = torch.ones(C, device=d), torch.zeros(C, device=d)
+      y = torch.empty_like(x)
+      mean, rstd = torch.empty(N * G, device=d), torch.empty(N * G, device=d)
+      dy, dx = torch.randn_like(x), torch.empty_like(x)
+      dg, db = torch.zeros(C, device=d), torch.zeros(C, device=d)
+      ws = torch.empty(2 * N * C, device=d)
+      nb = x.numel() * 4
+      shape = f'C{C} @{H}x{H} b{N}'
+      rec('gn_silu.fwd', shape, timeit(lambda: call(lib, 'gn_fwd_f32', x, C, None, 0, g, b, y, mean, rstd, N, H * H, G, 1e-6, 1, 0.1, 1, None), args.reps), nbytes=2 * nb)
+      rec('gn_silu.bwd', shape, timeit(lambda: call(lib, 'gn_bwd_f32', dy, x, C, None, 0, g, b, mean, rstd, dx, 0.0, None, 0.0, dg, db, ws, N, H * H, G, 1, 0.1, 1, None), args.reps), nbytes=3 * nb)
+
+  if not args.only or 'misc' in args.only:
+    n = N * 256 * 16 * 16
+    a, b2, o = torch.randn(n, device=d), torch.randn(n, device=d), torch.empty(n, device=d)
+    rec('axpby', f'n={n}', timeit(lambda: call(lib, 'axpby_f32', a, 0.5, b2, 1.0, o, n), args.reps), nbytes=12 * n)
+    planes, H = N * 256, 16
+    x = torch.randn(planes, H, H, device=d)
+    k = torch.ones(4, 4, device=d) / 16
+    dn, up = torch.empty(planes, H // 2, H // 2, device=d), torch.empty(planes, 2 * H, 2 * H, device=d)
+    rec('upfirdn2d.down', f'{planes}x{H}x{H}', timeit(lambda: call(lib, 'upfirdn2d_f32', x, k, dn, planes, H, H, 1, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1), args.reps), nbytes=4 * (x.numel() + dn.numel()))
+    rec('upfirdn2d.up', f'{planes}x{H}x{H}', timeit(lambda: call(lib, 'upfirdn2d_f32', x, k, up, planes, H, H, 1, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1), args.reps), nbytes=4 * (x.numel() + up.numel()))
+    P = 61804419
+    p, g, m, v = (torch.randn(P, device=d) * 0.01 for _ in range(4))
+    v = v.abs()
+    ss, wsb = torch.zeros(1, device=d), torch.zeros(2048, device=d)
+    rec('sumsq', f'n={P}', timeit(lambda: call(lib, 'sumsq_f32', g, P, ss, wsb), args.reps), nbytes=4 * P)
+    rec('adam', f'n={P}', timeit(lambda: call(lib, 'adam_f32', p, g, m, v, P, 2e-4, 0.9, 0.999, 1e-8, 0.0, 0, 0.1, 0.001, ss, 1.0), args.reps), nbytes=28 * P)
+    rec('ema', f'n={P}', timeit(lambda: call(lib, 'ema_f32', m, p, P, 1e-4), args.reps), nbytes=12 * P)
+
+  out = os.path.join(ROOT, 'gpurun_out', 'bench_kernels.txt')
+  os.makedirs(os.path.dirname(out), exist_ok=True)
+  with open(out, 'w') as f:
+    f.write('\n'.join(rows) + '\n')
+
+
+if __name__ == '__main__':
+  main()

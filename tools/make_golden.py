@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE itself (its PyTorch CPU path, imported from
+/root/reference through oracle/refimport.py) on small seeded inputs.
+
+Run in the build container only (the reference never travels):   python tools/make_golden.py
+
+Every fixture is data: inputs (including every noise draw, made explicit) and the reference's outputs.
+No reference source is stored.  tests/test_oracle_golden.py then pins the restatements (sde_lib, losses,
+sampling, oracle RefNet, the C kernels of oracle/stk_ref.c) to these vectors on any machine.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+import refimport
+from _model_util import patched_rng
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+FAMILIES = {
+  'vp': ('configs.vp.CIFAR10.ddpmpp_nll_st', dict(ch_mult=(1, 2))),
+  'rve': ('configs.ve.CELEBA.uncsnpp_st', dict(ch_mult=(1, 2))),
+  've': ('configs.ve.celebahq.uncsnpp_st', dict(ch_mult=(1, 1, 2))),
+}
+
+
+def tiny(cfg, ch_mult):
+  cfg.model.nf = 8
+  cfg.model.ch_mult = ch_mult
+  cfg.model.num_res_blocks = 1
+  cfg.model.attn_resolutions = (4,)
+  cfg.model.dropout = 0.0
+  cfg.data.image_size = 8
+  cfg.optim.warmup = 2
+  return cfg
+
+
+def npy(t):
+  return t.detach().cpu().numpy().copy()
+
+
+def sde_fixture(ns):
+  out = {}
+  g = torch.Generator().manual_seed(0)
+  x = torch.randn(3, 3, 4, 4, generator=g)
+  t = torch.tensor([1e-5, 0.37, 1.0])
+  out['x'], out['t'] = npy(x), npy(t)
+  cfgs = {'vp': refimport.get_config('configs.vp.CIFAR10.ddpmpp_nll_st'),
+          've': refimport.get_config('configs.ve.celebahq.uncsnpp_st'),
+          'rve': refimport.get_config('configs.ve.CELEBA.uncsnpp_st')}
+  for name, cfg in cfgs.items():
+    sde = ns.sde_lib.get_sde(cfg, None)
+    mean, std = sde.marginal_prob(x, t)
+    drift, diff = sde.sde(x, t)
+    out[f'{name}.mean'], out[f'{name}.std'] = npy(mean), npy(std)
+    out[f'{name}.drift'], out[f'{name}.diffusion'] = npy(drift), npy(diff)
+    out[f'{name}.prior_logp'] = npy(sde.prior_logp(x))
+    if name != 'rve':
+      f, G = sde.discretize(x, t)
+      out[f'{name}.disc_f'], out[f'{name}.disc_G'] = npy(f), npy(G)
+      out[f'{name}.Z'] = npy(sde.normalizing_constant(1e-3))
+      out[f'{name}.antiderivative'] = npy(sde.antiderivative(t))
+    for tm_name, t_min in (('eps', 1e-5), ('mid', 3e-3)):
+      for imp in (True, False):
+        with patched_rng(5):
+          tt, Z = sde.get_diffusion_time(cfg, 6, torch.device('cpu'), t_min, importance_sampling=imp)
+        out[f'{name}.time.{tm_name}.{int(imp)}'] = npy(tt)
+        out[f'{name}.timeZ.{tm_name}.{int(imp)}'] = np.asarray(float(Z))
+    np.random.seed(11)
+    out[f'{name}.t_min'] = np.asarray([sde.get_t_min(cfg) for _ in range(4)], dtype=np.float64)
+  # k != 1 branch of the VP t_min draw
+  cfg = cfgs['vp']
+  cfg.training.k = 2.0
+  np.random.seed(11)
+  out['vp.t_min.k2'] = np.asarray([ns.sde_lib.get_sde(cfg, None).get_t_min(cfg) for _ in range(4)], dtype=np.float64)
+  np.savez_compressed(os.path.join(OUT, 'sde.npz'), **out)
+
+
+def op_fixture(ns):
+  out = {}
+  g = torch.Generator().manual_seed(1)
+  fir = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32) / 64.
+  x = torch.randn(2, 3, 8, 8, generator=g, requires_grad=True)
+  out['x'] = npy(x)
+  cases = {'down': (fir, 1, 2, (1, 1)), 'up': (fir * 4, 2, 1, (2, 1)), 'pre': (fir, 1, 1, (2, 2)),
+           'crop': (fir, 1, 1, (-1, 0)), 'odd': (np.arange(15, dtype=np.float32).reshape(3, 5) / 15., 3, 2, (2, 1))}
+  for name, (k, up, down, pad) in cases.items():
+    kt = torch.tensor(k)
+    y = ns.op_upfirdn2d.upfirdn2d_native(x, kt, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
+    go = torch.randn(y.shape, generator=g)
+    gx, = torch.autograd.grad((y * go).sum(), x)
+    out[f'{name}.k'], out[f'{name}.y'], out[f'{name}.go'], out[f'{name}.gx'] = k, npy(y), npy(go), npy(gx)
+    out[f'{name}.args'] = np.asarray([up, down, pad[0], pad[1]])
+  # up_or_down_sampling wrappers
+  out['uds.up'] = npy(ns.uds.upsample_2d(x, (1, 3, 3, 1), factor=2))
+  out['uds.down'] = npy(ns.uds.downsample_2d(x, (1, 3, 3, 1), factor=2))
+  w = torch.randn(5, 3, 3, 3, generator=g)
+  out['uds.w'] = npy(w)
+  out['uds.conv_down'] = npy(ns.uds.conv_downsample_2d(x, w, k=(1, 3, 3, 1)))
+  out['uds.naive_up'] = npy(ns.uds.naive_upsample_2d(x))
+  out['uds.naive_down'] = npy(ns.uds.naive_downsample_2d(x))
+  # fused_leaky_relu: the reference's CPU branch (hard-codes slope 0.2) and the kernel's formula agree at 0.2
+  b = torch.randn(3, generator=g)
+  out['flr.bias'] = npy(b)
+  out['flr.y'] = npy(ns.op_fused_act.fused_leaky_relu(x, b, 0.2, 2 ** 0.5))
+  np.savez_compressed(os.path.join(OUT, 'ops.npz'), **out)
+
+
+def model_fixture(ns, family):
+  dotted, kw = FAMILIES[family]
+  cfg = tiny(refimport.get_config(dotted), **kw)
+  torch.manual_seed(0)
+  sde = ns.sde_lib.get_sde(cfg, None)
+  model = ns.mutils.create_model(cfg, sde)
+  g = torch.Generator().manual_seed(2)
+  with torch.no_grad():
+    for p in model.parameters():
+      if p.requires_grad:
+        p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+  out = {}
+  for k, v in model.state_dict().items():
+    out['sd.' + k] = npy(v)
+  B, H = 4, cfg.data.image_size
+  x = torch.randn(B, 3, H, H, generator=g)
+  t = torch.rand(B, generator=g) * 0.9 + 0.05
+  out['x'], out['t'] = npy(x), npy(t)
+
+  # raw network + score
+  model.eval()
+  cond = t * 999 if family == 'vp' else sde.marginal_prob(x, t)[1]
+  xr = x.clone().requires_grad_(True)
+  y = model(xr, cond)
+  go = torch.randn(y.shape, generator=g)
+  (y * go).sum().backward()
+  out['cond'], out['net'], out['go'], out['gx'] = npy(cond), npy(y), npy(go), npy(xr.grad)
+  names = [n for n, p in model.named_parameters() if p.grad is not None]
+  keep = names[:6] + names[-6:] + [n for n in names if 'NIN_3' in n or 'Dense_0' in n][:6]
+  grads = dict(model.named_parameters())
+  for n in keep:
+    out['grad.' + n] = npy(grads[n].grad)
+  out['grad_names'] = np.asarray(keep)
+  out['grad_sumsq'] = np.asarray(sum(float((p.grad.double() ** 2).sum()) for p in model.parameters() if p.grad is not None))
+  out['score'] = npy(ns.mutils.get_score_fn(cfg, sde, model, train=False, continuous=True)(x, t))
+
+  # a few PC iterations with the INITIAL weights (RVE sampling raises in the reference)
+  if family in ('vp', 've'):
+    if family == 'vp':
+      cfg.sampling.method, cfg.sampling.predictor, cfg.sampling.corrector = 'pc', 'euler_maruyama', 'none'
+    n_saved = sde.N
+    sde.N = 3
+    shape = (2, 3, H, H)
+    inv = (lambda v: (v + 1.) / 2.) if cfg.data.centered else (lambda v: v)
+    fn = ns.sampling.get_sampling_fn(cfg, sde, shape, inv, 1e-3)
+    with patched_rng(11):
+      xs, nfe = fn(model)
+    out['pc.samples'], out['pc.nfe'] = npy(xs), np.asarray(nfe)
+    sde.N = n_saved
+
+  # two training steps through the reference's own step_fn (noise injected)
+  model.zero_grad()
+  opt = ns.losses.get_optimizer(cfg, model.parameters())
+  ema = ns.ema.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+  state = dict(optimizer=opt, model=model, ema=ema, step=0)
+  step_fn = ns.losses.get_step_fn(cfg, sde, train=True, optimize_fn=ns.losses.optimization_manager(cfg))
+  scaler = (lambda v: v * 2. - 1.) if cfg.data.centered else (lambda v: v)
+  for i in range(2):
+    batch = scaler(torch.rand(B, 3, H, H, generator=torch.Generator().manual_seed(100 + i)))
+    np.random.seed(7 + i)
+    with patched_rng(50 + i):
+      losses = step_fn(state, batch)
+    out[f'step{i}.batch'], out[f'step{i}.loss'] = npy(batch), npy(losses)
+  for n in keep:
+    out['after.' + n] = npy(dict(model.named_parameters())[n])
+  out['after.ema0'] = npy(ema.shadow_params[0])
+  out['after.ema_last'] = npy(ema.shadow_params[-1])
+  out['after.step'] = np.asarray(state['step'])
+
+  np.savez_compressed(os.path.join(OUT, f'model_{family}.npz'), **out)
+  print(family, 'params', sum(p.numel() for p in model.parameters()), 'keys', len(out))
+
+
+def main():
+  os.makedirs(OUT, exist_ok=True)
+  ns = refimport.load()
+  sde_fixture(ns)
+  op_fixture(ns)
+  for fam in FAMILIES:
+    model_fixture(ns, fam)
+  for f in sorted(os.listdir(OUT)):
+    print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == '__main__':
+  main()
