@@ -506,6 +506,128 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// ---- 3x3 / stride-1 / pad-1 weight gradient: all nine taps per workgroup ------------------------------------
+// The per-tap GEMM above re-reads dy and x once per tap and per tile and is bound by L2/Infinity-Cache
+// bandwidth (measured ~70 TFLOP/s).  Here one workgroup owns a 128(co) x 32(ci) x 9(taps) block of dw:
+// per 32-pixel chunk it stages dy[128 co][32 px] and ONE halo tile x[32 ci][(rows+2) x (cols+2)] in LDS and
+// feeds all nine taps from shifted views of that tile: 144 MFMAs per wave per chunk against 29 loads per
+// thread (the per-tap kernel: 64 MFMAs against 32 loads), i.e. ~4.5x fewer operand bytes per FLOP.
+//   A operand  As[px][co]   (k-major, pitch 129)             a = As[2ks + (lane>>5)][32*wave + (lane&31)]
+//   B operand  Xs[ci][tile] (pitch odd -> conflict-free)     b_tap = Xs[lane&31][loc(2ks) + (lane>>5) + kh*TW + kw]
+// COLS = pixels of a chunk that share an image row: 32 (W % 32 == 0), 16 (W == 16) or 8 (W == 8); a chunk is
+// 32/COLS full rows of one image, so it never straddles images (requires OH*OW % 32 == 0).
+template <int COLS>
+__global__ __launch_bounds__(256) void wgrad9_kernel(ConvP p, int tiles_m, int tiles_n, int k_per_split) {
+  constexpr int ROWS = 32 / COLS, TW = COLS + 2, TH = ROWS + 2, TSZ = TH * TW;
+  constexpr int XS = TSZ | 1;
+  constexpr int LDA = 129;
+  constexpr int NX = (32 * TSZ + 255) / 256;
+  constexpr int NA = 16;
+  __shared__ float lds[32 * LDA + 32 * XS];
+  float* As = lds;
+  float* Xs = lds + 32 * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fk = lane >> 5, fc = lane & 31;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = id % tiles_n;               // ci tiles fastest: neighbours share the dy panel
+  const int rest = id / tiles_n;
+  const int tm = rest % tiles_m, zs = rest / tiles_m;
+  const int m0 = tm * 128, n0 = tn * 32;
+  const int K = p.N * p.OHW;
+  const int k_begin = zs * k_per_split;
+  const int k_end = min(K, k_begin + k_per_split);
+
+  // dy rows of this thread: m = mrow + 8 i (row offsets are recomputed per chunk, not held in registers)
+  const int mrow = m0 + (tid >> 5), cout_hi = p.Cout - 1;
+  unsigned okrowsA = 0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) okrowsA |= (mrow + 8 * i < p.Cout ? 1u : 0u) << i;
+  // x-tile element e = tid + 256 i  ->  (ci = e / TSZ, lr, lc); recomputed per chunk from compile-time divisors
+  // (a few VALU ops under 9k cycles of MFMA) instead of being held in 39 registers, which keeps the kernel
+  // at two waves per SIMD.
+  const int cin_hi = p.Cin - 1;
+  floatx16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  float ra[NA], rx[NX];
+  unsigned okmA = 0, okmX = 0;
+  auto load = [&](int k0) {
+    // dy: this thread's pixel is k0 + (tid & 31)
+    const int k = k0 + (tid & 31);
+    const bool kv = k < K;
+    int b, ohw;
+    split_pixel(p, kv ? k : 0, b, ohw);
+    const int abase = b * p.Cout * p.OHW + ohw;
+    okmA = kv ? okrowsA : 0u;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = p.dy[abase + min(mrow + 8 * i, cout_hi) * p.OHW];
+    // x halo tile of the chunk (scalar origin: k0 is chunk-aligned and the chunk lies in one image)
+    int b0, ohw0, oy0, ox0;
+    split_pixel(p, k0, b0, ohw0);
+    split_row(p, ohw0, oy0, ox0);
+    const int xbase = b0 * p.Cin * p.HW + (oy0 - 1) * p.W + (ox0 - 1);
+    okmX = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + 256 * i;
+      const int ci = e / TSZ, rem = e - ci * TSZ;
+      const int lr = rem / TW, lc = rem - lr * TW;
+      const int iy = oy0 - 1 + lr, ix = ox0 - 1 + lc;
+      const bool ok = e < 32 * TSZ && n0 + ci < p.Cin && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      rx[i] = p.x1[ok ? xbase + min(n0 + ci, cin_hi) * p.HW + lr * p.W + lc : 0];
+      okmX |= (ok ? 1u : 0u) << i;
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) As[(tid & 31) * LDA + (tid >> 5) + 8 * i] = keep_if(ra[i], okmA, i);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + 256 * i;
+      const int ci = e / TSZ, rem = e - ci * TSZ;
+      if (e < 32 * TSZ) Xs[ci * XS + rem] = keep_if(rx[i], okmX, i);
+    }
+  };
+
+  if (k_begin < k_end) load(k_begin);
+  const float* arow = As + fk * LDA + wid * 32 + fc;
+  const float* xrow = Xs + fc * XS + fk;
+  for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+    store();
+    __syncthreads();
+    if (k0 + 32 < k_end) load(k0 + 32);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const float a = arow[2 * ks * LDA];
+      constexpr int dummy = 0; (void)dummy;
+      const int loc = ((2 * ks) / COLS) * TW + ((2 * ks) % COLS);
+      float bv[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) bv[t] = xrow[loc + (t / 3) * TW + (t % 3)];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // partial slab [tap][Cout][Cin] of split zs: lanes (= ci) contiguous
+  float* slab = p.part + (long)zs * p.part_stride;
+  const int n = n0 + fc;
+  if (n < p.Cin) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wid * 32 + strip_row(e) + 4 * fk;
+        if (m < p.Cout) slab[((long)t * p.Cout + m) * p.Cin + n] = acc[t][e];
+      }
+  }
+}
+
 // ---- generic batched strided GEMM --------------------------------------------------------------------------
 struct GemmP {
   const float* A; long sam, sak, sab;
@@ -619,9 +741,33 @@ inline int fill_common(ConvP& p, int N, int H, int W, int C1, int C2, int Cout, 
   return STK_OK;
 }
 
-struct WgradPlan { int big; int splits; int k_per_split; long slab; };
-inline WgradPlan wgrad_plan(int Cin, int N, int Cout, int OH, int OW, int KH, int KW) {
+struct WgradPlan { int big; int splits; int k_per_split; long slab; int mode9; };
+// mode9 (all-taps kernel) preconditions; the caller also checks stride 1, pad 1, one source, OH == H, OW == W.
+inline int wgrad9_cols(int OH, int OW, int KH, int KW) {
+  if (KH != 3 || KW != 3 || ((long)OH * OW) % 32 != 0) return 0;
+  if (OW % 32 == 0) return 32;
+  if (OW == 16 || OW == 8) return OW;
+  return 0;
+}
+inline WgradPlan wgrad_plan(int Cin, int N, int Cout, int OH, int OW, int KH, int KW, bool allow9 = true) {
   WgradPlan q;
+  q.mode9 = allow9 ? wgrad9_cols(OH, OW, KH, KW) : 0;
+  if (q.mode9) {
+    const long K = (long)N * OH * OW;
+    const long tiles = (long)stk_cdiv(Cout, 128) * stk_cdiv(Cin, 32);
+    const long chunks = K / 32;
+    // one workgroup per CU is resident (144 accumulator + ~120 other registers): aim for at most 256 blocks and
+    // never for "one wave of blocks plus a few" (264 blocks on 256 CUs ran 2x slower than 252)
+    long splits = 256 / tiles;
+    if (splits > chunks / 16) splits = chunks / 16;
+    if (splits < 1) splits = 1;
+    const long cps = (chunks + splits - 1) / splits;
+    q.big = 1;
+    q.k_per_split = (int)(cps * 32);
+    q.splits = (int)((K + q.k_per_split - 1) / q.k_per_split);
+    q.slab = (long)Cout * Cin * 9;
+    return q;
+  }
   const int taps = KH * KW;
   const long K = (long)N * OH * OW;
   // 128x128 tiles halve the operand traffic per FLOP, but a 1x1 layer has too few of them: with so few tiles
@@ -715,8 +861,10 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
 }
 
 long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW) {
-  const WgradPlan q = wgrad_plan(C1 + C2, N, Cout, OH, OW, KH, KW);
-  return (long)q.splits * q.slab * 4 + 256;
+  const WgradPlan a = wgrad_plan(C1 + C2, N, Cout, OH, OW, KH, KW, true);
+  const WgradPlan b = wgrad_plan(C1 + C2, N, Cout, OH, OW, KH, KW, false);
+  const long na = (long)a.splits * a.slab, nb = (long)b.splits * b.slab;
+  return (na > nb ? na : nb) * 4 + 256;
 }
 
 int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const float* dy, float* dw, int w_layout,
@@ -728,7 +876,8 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
   ConvP p = {};
   int rc = fill_common(p, N, H, W, C1, C2, Cout, OH, OW, KH, KW, stride, pad);
   if (rc) return rc;
-  const WgradPlan q = wgrad_plan(p.Cin, N, Cout, OH, OW, KH, KW);
+  const bool can9 = stride == 1 && pad == 1 && C2 == 0 && OH == H && OW == W && w_layout == 0;
+  const WgradPlan q = wgrad_plan(p.Cin, N, Cout, OH, OW, KH, KW, can9);
   if (ws_bytes < (long)q.splits * q.slab * 4) return STK_EINVAL;
   p.x1 = x1; p.x2 = C2 > 0 ? x2 : x1; p.dy = dy; p.w_layout = w_layout; p.part = ws; p.part_stride = q.slab;
   const long Kl = (long)N * p.OHW;
@@ -736,7 +885,15 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
   const int K = (int)Kl;
   hipStream_t s = (hipStream_t)stream;
   using CB = Cfg<128, 128, 32>; using CS = Cfg<64, 64, 32>;
-  if (C2 > 0) {
+  if (q.mode9) {
+    const int tm = stk_cdiv(Cout, 128), tn = stk_cdiv(p.Cin, 32);
+    const dim3 grid((unsigned)(tm * tn * q.splits));
+    if (q.mode9 == 32) hipLaunchKernelGGL((wgrad9_kernel<32>), grid, dim3(256), 0, s, p, tm, tn, q.k_per_split);
+    else if (q.mode9 == 16) hipLaunchKernelGGL((wgrad9_kernel<16>), grid, dim3(256), 0, s, p, tm, tn, q.k_per_split);
+    else hipLaunchKernelGGL((wgrad9_kernel<8>), grid, dim3(256), 0, s, p, tm, tn, q.k_per_split);
+    STK_CHECK_LAUNCH();
+    rc = STK_OK;
+  } else if (C2 > 0) {
     if (q.big) rc = launch<CB, ConvP, AWgrad<CB>, BWgrad<CB, true>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s, true);
     else rc = launch<CS, ConvP, AWgrad<CS>, BWgrad<CS, true>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s, true);
   } else {
