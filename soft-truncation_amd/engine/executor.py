@@ -5,10 +5,22 @@ reference's ``NCSNpp.forward`` body (models/ncsnpp.py:258-432) from autograd's p
 -- one differentiable node -- while inside it is a fixed launch sequence over pre-planned
 HBM buffers with hand-written backward kernels (engine/graph.py).
 
+hipGraphs: because the plan is static (fixed buffers, fixed launch order, no allocation, no
+host sync), the forward and the backward launch sequences of a context are captured once into
+hipGraphs and replayed afterwards -- ~650 launches per direction become one graph launch, which
+removes the host launch gaps between the ~20-500 us kernels (the reference would need a tracing
+compiler for this; here it falls out of the design).  The only per-call value inside the
+network, the dropout seed, is read from device memory (``seed_dev`` of ``stk_gn_*``), so a
+replay draws fresh masks.  ``STK_GRAPHS=0`` disables capture; attaching a kernel timer
+(events cannot be recorded inside a replay) does so too.
+
 Backend selection is explicit and never silent: the default backend is the HIP library
 (``engine.lib.load()``, raises if it is not built); a test may inject another implementation
 of include/stk.h (the oracle's CPU restatement) with ``set_backend``.
 """
+import os
+import warnings
+
 import torch
 
 from . import lib as stk_lib
@@ -18,7 +30,7 @@ from .graph import Graph, Runtime
 
 class Context:
   """Buffers of one forward call, kept until its backward has run."""
-  __slots__ = ('prog', 'act', 'gact', 'rt', 'released', 'seed_dev')
+  __slots__ = ('prog', 'act', 'gact', 'rt', 'released', 'seed_t', 'graphs', 'uses')
 
   def __init__(self, prog):
     self.prog = prog
@@ -26,7 +38,9 @@ class Context:
     self.gact = None
     self.rt = None
     self.released = False
-    self.seed_dev = None
+    self.seed_t = None        # device int64 holding the per-call dropout seed (graph mode)
+    self.graphs = {}          # ('fwd'|'bwd', training) -> torch.cuda.CUDAGraph
+    self.uses = 0
 
 
 class Program:
@@ -80,6 +94,8 @@ class Executor:
     self.programs = {}
     self._anchor = None
     self.profiler = None     # engine.profile.KernelTimer or None
+    self.use_graphs = os.environ.get('STK_GRAPHS', '1') != '0'
+    self.graph_replays = 0
 
   # -- parameters ---------------------------------------------------------------------------------
   def set_backend(self, backend):
@@ -126,6 +142,44 @@ class Executor:
       return
     c.act[t.off:t.off + t.numel].view(t.shape).copy_(value.detach().reshape(t.shape))
 
+  def _graphs_on(self):
+    return self.use_graphs and self.lib.is_device and self.profiler is None
+
+  def _runtime(self, c, training, seed, seed_dev=None):
+    prog, flat = c.prog, self.flat
+    rt = Runtime(self.lib, stk_lib.stream_ptr(flat.device), c.act.data_ptr(),
+                 c.gact.data_ptr() if c.gact is not None else 0,
+                 flat.data.data_ptr(), flat.grad.data_ptr(), prog.const.data_ptr(),
+                 prog.ws.data_ptr(), prog.graph.ws_bytes, training, seed, seed_dev)
+    rt.prof = self.profiler
+    return rt
+
+  def _replay(self, c, direction, training):
+    """Replay (capturing on first use) the hipGraph of one direction of this context."""
+    key = (direction, training)
+    g = c.graphs.get(key)
+    if g is None:
+      ops = c.prog.graph.ops
+      torch.cuda.synchronize()
+      g = torch.cuda.CUDAGraph()
+      try:
+        with torch.cuda.graph(g):
+          rt = self._runtime(c, training, 0, c.seed_t.data_ptr())   # stream = the capture stream
+          if direction == 'fwd':
+            for op in ops:
+              op.forward(rt)
+          else:
+            for op in reversed(ops):
+              op.backward(rt)
+      except Exception as e:   # capture is an optimisation: report, disable, run eagerly
+        warnings.warn(f'hipGraph capture failed ({e!r}); continuing with eager launches')
+        self.use_graphs = False
+        return False
+      c.graphs[key] = g
+    g.replay()
+    self.graph_replays += 1
+    return True
+
   def run_forward(self, x, emb_in, sigma, training, need_xgrad):
     flat = self.ensure_flat()
     B, _, H, W = x.shape
@@ -139,13 +193,22 @@ class Executor:
     seed = 0
     if training and self.model._uses_dropout():
       seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    rt = Runtime(self.lib, stk_lib.stream_ptr(flat.device), c.act.data_ptr(), 0,
-                 flat.data.data_ptr(), flat.grad.data_ptr(), prog.const.data_ptr(),
-                 prog.ws.data_ptr(), g.ws_bytes, training, seed)
-    rt.prof = self.profiler
-    for op in g.ops:
-      op.forward(rt)
-    c.rt = rt
+    c.uses += 1
+    done = False
+    if self._graphs_on() and c.uses > 1:          # first use of a context runs eagerly (warm-up)
+      if c.seed_t is None:
+        c.seed_t = torch.zeros(1, dtype=torch.int64, device=flat.device)
+      if c.gact is None and torch.is_grad_enabled():
+        c.gact = torch.empty(max(g.gact_size, 1), dtype=torch.float32, device=prog.device)
+      c.seed_t.fill_(seed)
+      done = self._replay(c, 'fwd', training)
+      if done:
+        c.rt = self._runtime(c, training, 0, c.seed_t.data_ptr())
+    if not done:
+      rt = self._runtime(c, training, seed)
+      for op in g.ops:
+        op.forward(rt)
+      c.rt = rt
     o = g.output
     out = c.act[o.off:o.off + o.numel].view(o.shape).clone()
     return out, c
@@ -155,14 +218,18 @@ class Executor:
     flat = self.flat
     if c.gact is None:
       c.gact = torch.empty(max(g.gact_size, 1), dtype=torch.float32, device=prog.device)
-    rt.gbase['act'] = c.gact.data_ptr()
-    rt.gbase['param'] = flat.grad.data_ptr()
-    rt.stream = stk_lib.stream_ptr(flat.device)
-    rt.prof = self.profiler
     o = g.output
     c.gact[o.goff:o.goff + o.numel].view(o.shape).copy_(gout)
-    for op in reversed(g.ops):
-      op.backward(rt)
+    done = False
+    if self._graphs_on() and rt.seed_dev is not None:
+      done = self._replay(c, 'bwd', rt.training)
+    if not done:
+      rt.gbase['act'] = c.gact.data_ptr()
+      rt.gbase['param'] = flat.grad.data_ptr()
+      rt.stream = stk_lib.stream_ptr(flat.device)
+      rt.prof = self.profiler
+      for op in reversed(g.ops):
+        op.backward(rt)
     gx = None
     xin = g.inputs['x']
     if xin.needs_grad:
