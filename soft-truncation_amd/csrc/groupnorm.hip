@@ -17,7 +17,8 @@
 //  * Dropout is a counter-based mask, a pure function of (seed, flat element index) (stk_rng.h), so the
 //    backward pass regenerates it instead of storing it.
 //  * backward: per (sample, group) workgroup computes the per-channel partial sums of d(gamma),
-//    d(beta) into a [N,C,2] scratch and dx; a second tiny kernel folds the scratch over N.
+//    d(beta) into a [N,C,2] scratch and dx; a second tiny kernel folds the scratch over N.  Groups of up to 16384
+//    elements (every group of the score network) take the flat register-resident variant.
 #include "common.h"
 
 namespace {
@@ -220,6 +221,106 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnArgs a, const float* __re
   }
 }
 
+// Flat variant for the shapes the score network has: H*W a power of two >= 16, groups of at most 16384 elements,
+// 16-byte aligned tensors.  The group is one flat run of float4 items, IPT per thread, and (du, xhat) stay in
+// registers between the reduction and the dx write, so x and dy leave HBM once and the sigmoid is evaluated once
+// (algorithmic traffic: read x, read dy, write dx).  Per-channel sums come from a segmented wave reduction (a wave
+// covers one channel or 64/(HW/4) whole channels) written to fixed LDS slots and folded in slot order -- no
+// atomics, so results are reproducible.  blockDim = 64/128/256 so small groups do not idle lanes.
+template <int IPT>
+__global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float* __restrict__ dy,
+                                                          const float* __restrict__ mean_in,
+                                                          const float* __restrict__ rstd_in, float* __restrict__ dx1,
+                                                          float beta1, float* __restrict__ dx2, float beta2,
+                                                          float* __restrict__ ws, int hw_log2) {
+  __shared__ float s_part[2048], s_ch[1024];
+  const int T = blockDim.x;
+  const int ng = blockIdx.x;
+  const int n = ng / a.G, g = ng - n * a.G;
+  const int C = a.C1 + a.C2;
+  const float mean = mean_in[ng], rstd = rstd_in[ng];
+  unsigned long long seed = a.seed;
+  if (a.drop_p > 0.f && a.seed_dev) seed += *a.seed_dev;
+  const int c0 = g * a.cpg;
+  const int L4 = (a.cpg << hw_log2) >> 2;
+  const int seglog = min(6, hw_log2 - 2);          // lanes of a wave that share a channel = 2^seglog
+  const int lane = threadIdx.x & 63;
+
+  float du[IPT][4], xh[IPT][4], gam[IPT];
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const int i = threadIdx.x + T * k;
+    const bool valid = i < L4;
+    const int e = valid ? 4 * i : 0;
+    const int c = c0 + (e >> hw_log2), off = e & (a.HW - 1);
+    const float* xp = c < a.C1 ? a.x1 + (((long)n * a.C1 + c) << hw_log2) + off
+                               : a.x2 + (((long)n * a.C2 + (c - a.C1)) << hw_log2) + off;
+    const unsigned long long flat = ((((unsigned long long)n * C + c)) << hw_log2) + off;
+    const float4 xv = *reinterpret_cast<const float4*>(xp);
+    const float4 dv = *reinterpret_cast<const float4*>(dy + flat);
+    const float ga = a.gamma[c], be = a.beta[c];
+    gam[k] = ga;
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+    float cs0 = 0.f, cs1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, flat + j, xh[k][j]);
+      du[k][j] = valid ? d : 0.f;
+      cs0 += du[k][j];
+      cs1 += du[k][j] * xh[k][j];
+    }
+    for (int o = 0; o < seglog; ++o) {
+      cs0 += __shfl_xor(cs0, 1 << o);
+      cs1 += __shfl_xor(cs1, 1 << o);
+    }
+    if (valid && (lane & ((1 << seglog) - 1)) == 0) {
+      s_part[2 * (i >> seglog)] = cs0;
+      s_part[2 * (i >> seglog) + 1] = cs1;
+    }
+  }
+  __syncthreads();
+  const int spc = (a.HW >> 2) >> seglog;            // slots per channel
+  for (int cl = threadIdx.x; cl < a.cpg; cl += T) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int q = 0; q < spc; ++q) {
+      t0 += s_part[2 * (cl * spc + q)];
+      t1 += s_part[2 * (cl * spc + q) + 1];
+    }
+    s_ch[2 * cl] = t0;
+    s_ch[2 * cl + 1] = t1;
+    ws[((long)n * C + c0 + cl) * 2 + 0] = t0;
+    ws[((long)n * C + c0 + cl) * 2 + 1] = t1;
+  }
+  __syncthreads();
+  float g0 = 0.f, g1 = 0.f;
+  for (int cl = 0; cl < a.cpg; ++cl) {
+    const float ga = a.gamma[c0 + cl];
+    g0 += ga * s_ch[2 * cl];
+    g1 += ga * s_ch[2 * cl + 1];
+  }
+  const float inv_l = 1.f / ((float)a.cpg * (float)a.HW);
+  const float m1 = g0 * inv_l, m2 = g1 * inv_l;
+
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const int i = threadIdx.x + T * k;
+    if (i >= L4) continue;
+    const int c = c0 + ((4 * i) >> hw_log2), off = (4 * i) & (a.HW - 1);
+    float* op; float ob;
+    if (c < a.C1) { op = dx1 ? dx1 + (((long)n * a.C1 + c) << hw_log2) + off : nullptr; ob = beta1; }
+    else { op = dx2 ? dx2 + (((long)n * a.C2 + (c - a.C1)) << hw_log2) + off : nullptr; ob = beta2; }
+    if (!op) continue;
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = rstd * (du[k][j] * gam[k] - m1 - xh[k][j] * m2);
+    if (ob != 0.f) {
+      const float4 old = *reinterpret_cast<const float4*>(op);
+      r[0] += ob * old.x; r[1] += ob * old.y; r[2] += ob * old.z; r[3] += ob * old.w;
+    }
+    *reinterpret_cast<float4*>(op) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
 // dgamma[c] += sum_n ws[n,c,1];  dbeta[c] += sum_n ws[n,c,0].  32 channels per block, 8-way split over n.
 __global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int N, int C) {
@@ -281,8 +382,30 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
   a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
   a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p);
   a.seed = seed; a.seed_dev = seed_dev;
-  hipLaunchKernelGGL(gn_bwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, dx1_beta,
-                     dx2, dx2_beta, ws);
+  const long L = (long)a.cpg * HW;
+  int hw_log2 = 0;
+  while ((1 << hw_log2) < HW) ++hw_log2;
+  const bool flat = (1 << hw_log2) == HW && HW >= 16 && L <= 16384 && a.cpg <= 512 && stk_aligned16(x1) &&
+                    stk_aligned16(dy) && (!x2 || stk_aligned16(x2)) && (!dx1 || stk_aligned16(dx1)) &&
+                    (!dx2 || stk_aligned16(dx2));
+  if (flat) {
+    const int L4 = (int)(L >> 2);
+    static const int tgt = getenv("STK_GN_IPT") ? atoi(getenv("STK_GN_IPT")) : 4;
+    int T = 64;
+    while (T < 1024 && T * tgt < L4) T <<= 1;
+    const int ipt = stk_cdiv(L4, T);
+#define STK_GN_FLAT(IPT)                                                                                          \
+  hipLaunchKernelGGL((gn_bwd_flat_kernel<IPT>), dim3(N * G), dim3(T), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, \
+                     dx1_beta, dx2, dx2_beta, ws, hw_log2)
+    if (ipt <= 1) STK_GN_FLAT(1);
+    else if (ipt <= 2) STK_GN_FLAT(2);
+    else if (ipt <= 3) STK_GN_FLAT(3);
+    else STK_GN_FLAT(4);
+#undef STK_GN_FLAT
+  } else {
+    hipLaunchKernelGGL(gn_bwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, dx1_beta,
+                       dx2, dx2_beta, ws);
+  }
   STK_CHECK_LAUNCH();
   if (dgamma || dbeta) {
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3(stk_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, ws, dgamma,

@@ -9,15 +9,14 @@
 //                over the taps whose upsampled coordinate is >= 0, divisible by `up` and in range.
 //
 // The op is HBM-bound (algorithmic bytes = in + out, 4x4 taps).  Design for CDNA4:
-//  * one 256-thread workgroup produces a tile of 1024 outputs of one plane: TOW = min(64, pow2(out_w))
-//    columns x 1024/TOW rows; the input window of the tile (<= 5.4K floats) is staged in LDS with
-//    coalesced row reads and zero fill, so every input element leaves HBM once and the 16 (down) or
-//    4 (up) taps per output are LDS reads;
-//  * lanes map to consecutive output columns -> coalesced 256 B stores per wave, and each thread
-//    keeps 4 output rows in registers so the taps are read from LDS once per column offset;
+//  * one 256-thread workgroup produces 1024-4096 outputs: a TOH x TOW tile (powers of two) of one plane, or -- for
+//    the small feature maps, where a whole plane is only 16-256 outputs -- the whole plane of PPB consecutive
+//    planes (one contiguous run of memory, read as float4); the input windows (<= 48 KB, LDS sized per launch)
+//    are staged in LDS with zero fill, so every input element leaves HBM once and the 16 (down) or 4 (up) taps
+//    per output are LDS reads;
+//  * lanes map to consecutive output columns -> coalesced stores; all index decodes are shifts;
 //  * up and down are template constants (1 or 2) so the divisibility tests and divisions fold away;
-//  * tiny planes (fewer than 256 outputs) and unusual factors use the direct kernel, whose reads are
-//    served by L1/L2 -- there is too little data per plane for staging to pay.
+//  * unusual factors / minor > 1 use the direct kernel, whose reads are served by L1/L2.
 #include "common.h"
 
 namespace {
@@ -66,83 +65,135 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct(UfdParams p) {
   }
 }
 
-// ---- tiled kernel: minor == 1, up_x == up_y == UP, down_x == down_y == DOWN, kh,kw <= 8 -----------
-constexpr int UFD_LDS_FLOATS = 5632;   // >= max over tile shapes of rows*(cols+1) for 8 taps, down 2
+// ---- tiled kernel: minor == 1, up_x == up_y == UP, down_x == down_y == DOWN, kh,kw <= 8 -----------------
+// A 256-thread workgroup produces 256*NQ outputs = PPB planes x (TOH x TOW) tile, all powers of two so every
+// output index decode is a shift.  Large planes: PPB = 1 and a grid of tiles per plane.  Small planes (the
+// 16x16 / 8x8 feature maps, where one plane is only 64-256 outputs): the tile is the whole plane and one
+// workgroup takes PPB consecutive planes -- which are one contiguous run of memory, read with float4 lanes.
+// LDS is sized per launch (windows + taps) so the small-window cases keep 8 workgroups per CU.
 constexpr int UFD_MAX_TAPS = 8;
+constexpr int UFD_LDS_FLOATS = 12288;   // at most 48 KB of input windows per workgroup
 
 template <int UP, int DOWN>
-__global__ __launch_bounds__(256) void upfirdn2d_tiled(UfdParams p, int tow_log2, int tiles_x, int tiles_y) {
-  __shared__ float s_in[UFD_LDS_FLOATS];
-  __shared__ float s_k[UFD_MAX_TAPS * UFD_MAX_TAPS];
+__global__ __launch_bounds__(256) void upfirdn2d_tiled(UfdParams p, int tow_log2, int toh_log2, int ppb_log2,
+                                                       int nq, int tiles_x, int tiles_y, int whole, int vec) {
+  extern __shared__ __attribute__((aligned(16))) float s_ufd[];
+  float* s_k = s_ufd;                                  // [8][8] flipped taps
+  float* s_in = s_ufd + UFD_MAX_TAPS * UFD_MAX_TAPS;   // PPB windows of rows x pitch
 
-  const int TOW = 1 << tow_log2;
-  const int TOH = 1024 >> tow_log2;
-  const int rows_per_pass = 256 >> tow_log2;      // thread rows per pass; 4 passes cover TOH
-
+  const int TOW = 1 << tow_log2, TOH = 1 << toh_log2, PPB = 1 << ppb_log2;
   int tile = blockIdx.x;
   const int tx_tile = tile % tiles_x; tile /= tiles_x;
   const int ty_tile = tile % tiles_y;
-  const int plane = tile / tiles_y;
+  const int plane0 = (tile / tiles_y) << ppb_log2;
   const int oy0 = ty_tile * TOH, ox0 = tx_tile * TOW;
 
-  // taps, flipped once: s_k[ky][kx] = k[kh-1-ky][kw-1-kx]
-  if (threadIdx.x < p.kh * p.kw) {
-    const int ky = threadIdx.x / p.kw, kx = threadIdx.x % p.kw;
-    s_k[ky * UFD_MAX_TAPS + kx] = p.k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
-  }
+  // taps, flipped once: s_k[ky][kx] = k[kh-1-ky][kw-1-kx]; the load is issued now, stored after the staging
+  // loads are in flight
+  float kv = 0.f;
+  const int tky = threadIdx.x / p.kw, tkx = threadIdx.x % p.kw;
+  if (threadIdx.x < p.kh * p.kw) kv = p.k[(p.kh - 1 - tky) * p.kw + (p.kw - 1 - tkx)];
 
-  // input window of this tile, in input coordinates (may start negative / end past the image)
+  // input window of the tile, in input coordinates (may start negative / end past the image)
   const int iy_lo = floor_div(oy0 * DOWN - p.pad_y0, UP);
   const int iy_hi = floor_div((oy0 + TOH - 1) * DOWN + p.kh - 1 - p.pad_y0, UP);
   const int ix_lo = floor_div(ox0 * DOWN - p.pad_x0, UP);
   const int ix_hi = floor_div((ox0 + TOW - 1) * DOWN + p.kw - 1 - p.pad_x0, UP);
   const int rows = iy_hi - iy_lo + 1, cols = ix_hi - ix_lo + 1;
-  const int pitch = cols | 1;   // odd pitch: column-strided reads of the down-2 case stay 2-way at worst
+  const int pitch = cols | 1;            // odd pitch keeps the column-strided reads of the down-2 case cheap
+  const int win = rows * pitch;
+  const unsigned plane_in = (unsigned)(p.in_h * p.in_w);
 
-  const float* src = p.in + (long)plane * p.in_h * p.in_w;
-  for (int e = threadIdx.x; e < rows * cols; e += 256) {
-    const int r = e / cols, c = e - r * cols;
-    const int iy = iy_lo + r, ix = ix_lo + c;
-    float v = 0.f;
-    if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = src[(long)iy * p.in_w + ix];
-    s_in[r * pitch + c] = v;
+  if (whole) {
+    // Whole planes: the PPB input planes are one contiguous run.  Zero the windows (halo), then scatter the run.
+    const int nz = (PPB * win + 3) >> 2;
+    for (int i = threadIdx.x; i < nz; i += 256) reinterpret_cast<float4*>(s_in)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nplanes = min(PPB, p.major - plane0);
+    const unsigned total = (unsigned)nplanes * plane_in;
+    const float* src = p.in + (long)plane0 * plane_in;
+    if (vec) {
+      for (unsigned base = 0; base < total; base += 256 * 4 * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned e = base + 4 * (threadIdx.x + 256 * j);
+          v[j] = *reinterpret_cast<const float4*>(src + (e < total ? e : 0));
+        }
+        if (base == 0) {
+          if (threadIdx.x < p.kh * p.kw) s_k[tky * UFD_MAX_TAPS + tkx] = kv;
+          __syncthreads();               // zero fill done before the scatter
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned e = base + 4 * (threadIdx.x + 256 * j);
+          if (e >= total) continue;
+          const unsigned pl = e / plane_in, rem = e - pl * plane_in;
+          const int iy = (int)(rem / (unsigned)p.in_w), ix = (int)(rem - (unsigned)iy * p.in_w);
+          const int r = iy - iy_lo, c = ix - ix_lo;
+          if (r < 0 || r >= rows) continue;
+          float* d = s_in + pl * win + r * pitch + c;
+          const float t[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (c + q >= 0 && c + q < cols) d[q] = t[q];
+        }
+      }
+    } else {
+      if (threadIdx.x < p.kh * p.kw) s_k[tky * UFD_MAX_TAPS + tkx] = kv;
+      __syncthreads();
+      for (unsigned e = threadIdx.x; e < total; e += 256) {
+        const unsigned pl = e / plane_in, rem = e - pl * plane_in;
+        const int iy = (int)(rem / (unsigned)p.in_w), ix = (int)(rem - (unsigned)iy * p.in_w);
+        const int r = iy - iy_lo, c = ix - ix_lo;
+        if (r >= 0 && r < rows && c >= 0 && c < cols) s_in[pl * win + r * pitch + c] = src[e];
+      }
+    }
+  } else {
+    // One tile of a large plane (PPB == 1): coalesced row reads of the window with zero fill, 8 loads in flight.
+    if (threadIdx.x < p.kh * p.kw) s_k[tky * UFD_MAX_TAPS + tkx] = kv;
+    const float* src = p.in + (long)plane0 * plane_in;
+    const unsigned total = (unsigned)(rows * cols);
+    for (unsigned base = 0; base < total; base += 256 * 8) {
+      float v[8]; int dst[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned e = base + threadIdx.x + 256 * j;
+        const unsigned r = e / (unsigned)cols, c = e - r * (unsigned)cols;
+        const int iy = iy_lo + (int)r, ix = ix_lo + (int)c;
+        const bool ok = e < total && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        const float t = src[ok ? iy * p.in_w + ix : 0];
+        v[j] = ok ? t : 0.f;
+        dst[j] = e < total ? (int)(r * pitch + c) : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (dst[j] >= 0) s_in[dst[j]] = v[j];
+    }
   }
   __syncthreads();
 
-  const int tx = threadIdx.x & (TOW - 1);
-  const int ty = threadIdx.x >> tow_log2;
-  const int ox = ox0 + tx;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  int rbase[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) rbase[q] = (oy0 + ty + q * rows_per_pass) * DOWN - p.pad_y0;
-  const int ux0 = ox * DOWN - p.pad_x0;
-
-  for (int ky = 0; ky < p.kh; ++ky) {
-    for (int kx = 0; kx < p.kw; ++kx) {
-      const int ux = ux0 + kx;
-      if (UP > 1 && (ux & (UP - 1))) continue;          // lands on an inserted zero
-      const int c = floor_div(ux, UP) - ix_lo;
-      const float w = s_k[ky * UFD_MAX_TAPS + kx];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int uy = rbase[q] + ky;
-        if (UP > 1 && (uy & (UP - 1))) continue;
-        const int r = floor_div(uy, UP) - iy_lo;
-        acc[q] += s_in[r * pitch + c] * w;
-      }
+  const long plane_out = (long)p.out_h * p.out_w;
+#pragma unroll 4
+  for (int q = 0; q < nq; ++q) {
+    const int o = threadIdx.x + 256 * q;
+    const int tx = o & (TOW - 1);
+    const int ty = (o >> tow_log2) & (TOH - 1);
+    const int pl = o >> (tow_log2 + toh_log2);
+    const int plane = plane0 + pl;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    const float* w_in = s_in + pl * win;
+    const int uy0 = oy * DOWN - p.pad_y0, ux0 = ox * DOWN - p.pad_x0;
+    float acc = 0.f;
+    // only taps whose upsampled coordinate is a real sample: ky = (-uy0) mod UP, stepping by UP
+    const int ky0 = (UP - (uy0 & (UP - 1))) & (UP - 1), kx0 = (UP - (ux0 & (UP - 1))) & (UP - 1);
+    for (int ky = ky0; ky < p.kh; ky += UP) {
+      const float* row = w_in + (floor_div(uy0 + ky, UP) - iy_lo) * pitch - ix_lo;
+      for (int kx = kx0; kx < p.kw; kx += UP)
+        acc += row[floor_div(ux0 + kx, UP)] * s_k[ky * UFD_MAX_TAPS + kx];
     }
-  }
-
-  if (ox < p.out_w) {
-    float* dst = p.out + (long)plane * p.out_h * p.out_w;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int oy = oy0 + ty + q * rows_per_pass;
-      if (oy < p.out_h) {
-        float* o = dst + (long)oy * p.out_w + ox;
-        *o = (p.beta != 0.f ? p.beta * *o : 0.f) + acc[q];
-      }
+    if (plane < p.major && oy < p.out_h && ox < p.out_w) {
+      float* d = p.out + plane * plane_out + (long)oy * p.out_w + ox;
+      *d = (p.beta != 0.f ? p.beta * *d : 0.f) + acc;
     }
   }
 }
@@ -163,21 +214,38 @@ int launch(const float* input, const float* kernel, float* out, float beta, int 
 
   const bool tiled_ok = minor == 1 && up_x == up_y && down_x == down_y && kh <= UFD_MAX_TAPS && kw <= UFD_MAX_TAPS &&
                         ((up_x == 1 && (down_x == 1 || down_x == 2)) || (up_x == 2 && down_x == 1)) &&
-                        (long)p.out_h * p.out_w >= 256;
+                        (long)in_h * in_w < 0x7fffffffL;
   if (tiled_ok) {
-    int tow_log2 = 4;                       // TOW in {16, 32, 64}
+    // tile = TOH x TOW outputs (powers of two, <= 1024 in total, TOW <= 64), PPB planes per workgroup
+    int tow_log2 = 2, toh_log2 = 2;
     while (tow_log2 < 6 && (1 << tow_log2) < p.out_w) ++tow_log2;
-    const int TOW = 1 << tow_log2, TOH = 1024 >> tow_log2;
+    while (toh_log2 + tow_log2 < 10 && (1 << toh_log2) < p.out_h) ++toh_log2;
+    const int TOW = 1 << tow_log2, TOH = 1 << toh_log2;
     const int tiles_x = stk_cdiv(p.out_w, TOW), tiles_y = stk_cdiv(p.out_h, TOH);
-    const long nblk = (long)major * tiles_x * tiles_y;
-    if (nblk <= 0x7fffffffL) {
+    const int whole = tiles_x * tiles_y == 1;
+    // outputs per workgroup: 1024 (4 per thread); 4096 for whole-plane upsampling, whose input is 4x smaller
+    int out_log2 = (whole && up_x == 2) ? 12 : 10;
+    int ppb_log2 = whole ? out_log2 - tow_log2 - toh_log2 : 0;
+    // LDS budget: PPB windows of rows x (cols | 1) floats
+    const int up = up_x, down = down_x;
+    const int rows = ((TOH - 1) * down + kh - 1) / up + 2, cols = ((TOW - 1) * down + kw - 1) / up + 2;
+    while (ppb_log2 > 0 && ((long)(1 << ppb_log2) * rows * (cols | 1) > UFD_LDS_FLOATS || (1 << ppb_log2) > 2 * major))
+      --ppb_log2;
+    const int nq = (1 << (ppb_log2 + tow_log2 + toh_log2)) >> 8;
+    const long groups = ((long)major + (1 << ppb_log2) - 1) >> ppb_log2;
+    const long nblk = groups * tiles_x * tiles_y;
+    if ((long)rows * (cols | 1) <= UFD_LDS_FLOATS && nblk <= 0x7fffffffL && nq >= 1) {
+      const int vec = whole && (((long)in_h * in_w) & 3) == 0 && (in_w & 3) == 0 && stk_aligned16(input);
+      const size_t shm = (UFD_MAX_TAPS * UFD_MAX_TAPS + (((size_t)(1 << ppb_log2) * rows * (cols | 1) + 3) & ~(size_t)3)) *
+                         sizeof(float);
       dim3 grid((unsigned)nblk), block(256);
-      if (up_x == 1 && down_x == 1)
-        hipLaunchKernelGGL((upfirdn2d_tiled<1, 1>), grid, block, 0, stream, p, tow_log2, tiles_x, tiles_y);
-      else if (up_x == 1)
-        hipLaunchKernelGGL((upfirdn2d_tiled<1, 2>), grid, block, 0, stream, p, tow_log2, tiles_x, tiles_y);
-      else
-        hipLaunchKernelGGL((upfirdn2d_tiled<2, 1>), grid, block, 0, stream, p, tow_log2, tiles_x, tiles_y);
+#define STK_UFD(U, D)                                                                                               \
+  hipLaunchKernelGGL((upfirdn2d_tiled<U, D>), grid, block, shm, stream, p, tow_log2, toh_log2, ppb_log2, nq, tiles_x, \
+                     tiles_y, whole, vec)
+      if (up_x == 1 && down_x == 1) STK_UFD(1, 1);
+      else if (up_x == 1) STK_UFD(1, 2);
+      else STK_UFD(2, 1);
+#undef STK_UFD
       STK_CHECK_LAUNCH();
       return STK_OK;
     }
