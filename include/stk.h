@@ -87,7 +87,7 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
                    unsigned long long seed, const unsigned long long* seed_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Convolution as implicit GEMM on the fp32 MFMA path.  Input = concat(x1[N,C1,H,W], x2[N,C2,H,W]).
+ * Convolution as implicit GEMM on the matrix cores.  Input = concat(x1[N,C1,H,W], x2[N,C2,H,W]).
  * w_layout 0: w[Cout][Cin][KH][KW] (nn.Conv2d);  w_layout 1: w[Cin][Cout] (NIN, KH=KW=1).
  * Any input coordinate outside [0,H)x[0,W) reads as zero, so OH/OW together with `pad`
  * (top/left) also express asymmetric padding.
@@ -97,16 +97,25 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
  *   dgrad: dx{1,2} = beta{1,2}*dx{1,2} + alpha * conv_transpose(dy, w)   (dx split by channel)
  *   wgrad: dw += alpha * sum_{n,oy,ox} dy * x        (same layout as w)
  *          ws: scratch of stk_conv2d_wgrad_ws_bytes(...) bytes for the split-K partial slabs.
+ * fwd / dgrad scratch: with ws of at least stk_conv2d_{fwd,dgrad}_ws_bytes(...) bytes (0 = the shape does not
+ * qualify) a 3x3 / stride-1 / pad-1 layer runs on the bf16 matrix pipe with every fp32 operand split exactly
+ * into three bf16 terms and the six significant partial products accumulated in fp32 (error at the level of
+ * fp32 rounding, same as the f32-input MFMA path); ws holds the re-laid-out, split weights of this call.
+ * ws = NULL / too small selects the f32-input MFMA path (v_mfma_f32_32x32x2_f32) for every shape.
  * ------------------------------------------------------------------------------------------ */
+long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW,
+                             int stride, int pad);
+long stk_conv2d_dgrad_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW,
+                               int stride, int pad);
 int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2,
                        const float* w, int w_layout, const float* bias,
                        const float* temb, int temb_stride, const float* res, float out_div,
                        float* y, int N, int H, int W, int Cout, int OH, int OW,
-                       int KH, int KW, int stride, int pad, void* stream);
+                       int KH, int KW, int stride, int pad, void* ws, long ws_bytes, void* stream);
 int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout,
                          float* dx1, int C1, float beta1, float* dx2, int C2, float beta2,
                          float alpha, int N, int H, int W, int Cout, int OH, int OW,
-                         int KH, int KW, int stride, int pad, void* stream);
+                         int KH, int KW, int stride, int pad, void* ws, long ws_bytes, void* stream);
 long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW);
 int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const float* dy,
                          float* dw, int w_layout, float alpha, float* ws, long ws_bytes,

@@ -485,6 +485,8 @@ struct EpWgrad {      // partial slab of split zs as [tap][Cout][Cin] (coalesced
   }
 };
 
+#include "conv_x3.h"
+
 // dw (in the weight's own layout) += alpha * sum over splits of slab[tap][co][ci]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                             long n, int splits, long stride, float alpha, int layout,
@@ -741,6 +743,34 @@ inline int fill_common(ConvP& p, int N, int H, int W, int C1, int C2, int Cout, 
   return STK_OK;
 }
 
+// The bf16 three-way-split kernel (conv_x3.h) takes 3x3 / stride 1 / pad 1 layers whose channel count is a multiple
+// of the 32-wide k chunk (and, for a concat input, whose first source is too) when there are at least 64 tiles of
+// 128 x 128 (at ~2.5x the f32-input rate a quarter-filled chip still beats the 64 x 64 f32-input kernel).
+inline bool x3_ok(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
+  return p.taps == 9 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W && Kc % 32 == 0 &&
+         (S2 == 0 || S1 % 32 == 0) && M >= 96 && Ng <= 0x7fffffffL &&
+         (long)stk_cdiv(M, 128) * stk_cdiv(Ng, 128) >= 64;
+}
+template <class EP>
+int launch_x3(const ConvP& p, const float* s1, int S1, const float* s2, int S2, int M, long Ng, int transpose,
+              void* ws, hipStream_t s) {
+  x3::Src q;
+  q.s1 = s1; q.s2 = S2 > 0 ? s2 : s1; q.S1 = S1; q.S2 = S2; q.Kc = S1 + S2; q.Mpad = x3::pad128(M);
+  unsigned short* wp = reinterpret_cast<unsigned short*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  q.wp = wp;
+  const long n = (long)q.Mpad * q.Kc;
+  hipLaunchKernelGGL(x3::wprep_kernel, dim3((unsigned)stk_cdiv(n, 256)), dim3(256), 0, s, p.w, wp, p.Cout, p.Cin, q.Mpad,
+                     transpose);
+  STK_CHECK_LAUNCH();
+  const int tm = q.Mpad / 128, tn = stk_cdiv((int)Ng, 128);
+  if (S2 > 0)
+    hipLaunchKernelGGL((x3::conv3x3_kernel<EP, true>), dim3((unsigned)(tm * tn)), dim3(256), 0, s, p, q, M, (int)Ng, tm, tn);
+  else
+    hipLaunchKernelGGL((x3::conv3x3_kernel<EP, false>), dim3((unsigned)(tm * tn)), dim3(256), 0, s, p, q, M, (int)Ng, tm, tn);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+
 struct WgradPlan { int big; int splits; int k_per_split; long slab; int mode9; };
 // mode9 (all-taps kernel) preconditions; the caller also checks stride 1, pad 1, one source, OH == H, OW == W.
 inline int wgrad9_cols(int OH, int OW, int KH, int KW) {
@@ -794,7 +824,7 @@ extern "C" {
 int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* w, int w_layout,
                        const float* bias, const float* temb, int temb_stride, const float* res, float out_div,
                        float* y, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad,
-                       void* stream) {
+                       void* ws, long ws_bytes, void* stream) {
   if (!x1 || !w || !y || (C2 > 0 && !x2) || out_div == 0.f || (w_layout != 0 && w_layout != 1) ||
       (w_layout == 1 && (KH != 1 || KW != 1)))
     return STK_EINVAL;
@@ -807,6 +837,8 @@ int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const f
   const long Ng = (long)N * p.OHW;
   const bool big = use_big_tile(Cout, Ng, 1);
   hipStream_t s = (hipStream_t)stream;
+  if (ws && w_layout == 0 && x3_ok(p, p.Cin, C1, C2, Cout, Ng) && ws_bytes >= x3::wp_bytes(Cout, p.Cin) + 256)
+    return launch_x3<EpFwd>(p, x1, C1, x2, C2, Cout, Ng, 0, ws, s);
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;
     if (C2 > 0) {
@@ -831,7 +863,7 @@ int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const f
 
 int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* dx1, int C1, float beta1, float* dx2,
                          int C2, float beta2, float alpha, int N, int H, int W, int Cout, int OH, int OW, int KH,
-                         int KW, int stride, int pad, void* stream) {
+                         int KW, int stride, int pad, void* ws, long ws_bytes, void* stream) {
   if (!dy || !w || (!dx1 && !dx2) || (w_layout != 0 && w_layout != 1) || (w_layout == 1 && (KH != 1 || KW != 1)))
     return STK_EINVAL;
   ConvP p = {};
@@ -844,6 +876,8 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
   const long Ng = (long)N * p.HW;
   const bool big = use_big_tile(Cin, Ng, 1);
   hipStream_t s = (hipStream_t)stream;
+  if (ws && w_layout == 0 && x3_ok(p, Cout, Cout, 0, Cin, Ng) && ws_bytes >= x3::wp_bytes(Cin, Cout) + 256)
+    return launch_x3<EpDgrad>(p, dy, Cout, nullptr, 0, Cin, Ng, 1, ws, s);
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;
     if (big) return launch<CB, ConvP, ADgrad9<CB>, BDgrad<CB, 9>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
@@ -858,6 +892,18 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
   if (K % 8 != 0) return launch<CS, ConvP, ADgradNinGen<CS>, BDgrad<CS, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
   if (big) return launch<CB, ConvP, ADgradNin<CB>, BDgrad<CB, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
   return launch<CS, ConvP, ADgradNin<CS>, BDgrad<CS, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
+}
+
+long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
+  ConvP p = {};
+  if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, stride, pad)) return 0;
+  return x3_ok(p, C1 + C2, C1, C2, Cout, (long)N * H * W) ? x3::wp_bytes(Cout, C1 + C2) + 256 : 0;
+}
+
+long stk_conv2d_dgrad_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
+  ConvP p = {};
+  if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, stride, pad)) return 0;
+  return x3_ok(p, Cout, Cout, 0, C1 + C2, (long)N * H * W) ? x3::wp_bytes(C1 + C2, Cout) + 256 : 0;
 }
 
 long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW) {

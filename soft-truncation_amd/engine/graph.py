@@ -187,7 +187,7 @@ class Conv(Op):
     rt.timed(self._kind('fwd', self.Cout, self.N * self.OH * self.OW), self.flops, rt.lib.conv2d_fwd_f32,
              rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.w), self.w_layout,
              rt.v(self.bias), temb, self.temb_stride, rt.v(self.res), self.out_div,
-             rt.v(self.y), *self._dims(), rt.stream)
+             rt.v(self.y), *self._dims(), rt.ws, rt.ws_bytes, rt.stream)
 
   def backward(self, rt):
     gy = rt.g(self.y)
@@ -213,11 +213,13 @@ class Conv(Op):
       rt.timed(self._kind('dgrad', self.C1 + self.C2, self.N * self.H * self.W), self.flops, lib.conv2d_dgrad_f32,
                gy, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
-               alpha, *self._dims(), rt.stream)
+               alpha, *self._dims(), rt.ws, rt.ws_bytes, rt.stream)
 
   def ws_bytes(self, lib):
+    shape = (self.C1, self.C2, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self.stride, self.pad)
     return max(int(lib.conv2d_wgrad_ws_bytes(self.C1, self.C2, self.N, self.Cout, self.OH, self.OW,
                                              self.KH, self.KW)),
+               int(lib.conv2d_fwd_ws_bytes(*shape)), int(lib.conv2d_dgrad_ws_bytes(*shape)),
                4 * self.N * self.Cout)
 
 

@@ -267,6 +267,9 @@ CONV_CASES = [
   (5, 40, 0, 4, 4, 56, 1, 1, 0, 4, 4, 1, False, False, False),          # NIN, ragged channels
   (2, 20, 12, 12, 10, 24, 3, 1, 1, 12, 10, 0, True, True, False),       # ragged everything
   (130, 128, 0, 4, 4, 128, 3, 1, 1, 4, 4, 0, True, False, True),        # many tiny images per tile
+  (8, 128, 0, 32, 32, 128, 3, 1, 1, 32, 32, 0, True, True, True),       # >= 64 tiles: bf16 three-way-split kernel
+  (40, 64, 96, 16, 16, 160, 3, 1, 1, 16, 16, 0, False, True, False),    # split kernel: concat input, ragged Cout
+  (17, 96, 0, 24, 24, 128, 3, 1, 1, 24, 24, 0, True, False, False),     # split kernel: ragged pixel tiles
 ]
 
 
@@ -274,8 +277,11 @@ def _conv_id(c):
   return f'N{c[0]}_C{c[1]}+{c[2]}_{c[3]}x{c[4]}_o{c[5]}_k{c[6]}s{c[7]}p{c[8]}_l{c[11]}'
 
 
+@pytest.mark.parametrize('scratch', [True, False], ids=['ws', 'nows'])
 @pytest.mark.parametrize('case', CONV_CASES, ids=_conv_id)
-def test_conv(ref_lib, hip_lib, case):
+def test_conv(ref_lib, hip_lib, case, scratch):
+  """scratch=True hands fwd / dgrad their workspace (shapes that qualify then take the bf16 three-way-split
+  kernel); scratch=False keeps every shape on the f32-input MFMA kernels.  Same tolerance for both."""
   N, C1, C2, H, W, Cout, K, stride, pad, OH, OW, layout, use_temb, use_res, use_div = case
   Cin = C1 + C2
   x1 = rnd(N, C1, H, W, seed=1)
@@ -298,15 +304,19 @@ def test_conv(ref_lib, hip_lib, case):
     if use_temb:
       tt = to(temb)
       tp = tt.data_ptr() + 4 * 8            # a column slice of a wider [N, TS] tensor
+    shape = (C1, C2, N, H, W, Cout, K, K, stride, pad)
+    fb = max(int(lib.conv2d_fwd_ws_bytes(*shape)), int(lib.conv2d_dgrad_ws_bytes(*shape))) if scratch else 0
+    fws = to(torch.zeros(fb // 4 + 64)) if fb else None
     y = to(torch.zeros(N, Cout, OH, OW))
-    call(lib, 'conv2d_fwd_f32', a1, C1, a2, C2, ww, layout, to(bias), tp, TS if use_temb else 0, to(res), div, y, *dims)
+    call(lib, 'conv2d_fwd_f32', a1, C1, a2, C2, ww, layout, to(bias), tp, TS if use_temb else 0, to(res), div, y, *dims,
+         fws, fb)
     o['y'] = y
     y2 = to(torch.zeros(N, Cout, OH, OW))
-    call(lib, 'conv2d_fwd_f32', a1, C1, a2, C2, ww, layout, None, None, 0, None, 1.0, y2, *dims)
+    call(lib, 'conv2d_fwd_f32', a1, C1, a2, C2, ww, layout, None, None, 0, None, 1.0, y2, *dims, fws, fb)
     o['y_plain'] = y2
     d = to(dy)
     dx1, dx2 = to(g1.clone()), (to(g2.clone()) if C2 else None)
-    call(lib, 'conv2d_dgrad_f32', d, ww, layout, dx1, C1, 0.0, dx2, C2, 1.0, 0.5, *dims)
+    call(lib, 'conv2d_dgrad_f32', d, ww, layout, dx1, C1, 0.0, dx2, C2, 1.0, 0.5, *dims, fws, fb)
     o['dx1'] = dx1
     if C2:
       o['dx2'] = dx2
@@ -336,10 +346,14 @@ def test_conv_adjoint_full_size(hip_lib):
   w = (rnd(C, C, 3, 3, seed=2) / 34.).to(d)
   g = rnd(N, C, H, H, seed=3).to(d)
   dims = (N, H, H, C, H, H, 3, 3, 1, 1)
+  shape = (C, 0, N, H, H, C, 3, 3, 1, 1)
+  fb = max(int(hip_lib.conv2d_fwd_ws_bytes(*shape)), int(hip_lib.conv2d_dgrad_ws_bytes(*shape)))
+  assert fb > 0                                     # this is the shape the split kernel exists for
+  fws = torch.zeros(fb // 4 + 64, device=d)
   y = torch.empty_like(x)
-  call(hip_lib, 'conv2d_fwd_f32', x, C, None, 0, w, 0, None, None, 0, None, 1.0, y, *dims)
+  call(hip_lib, 'conv2d_fwd_f32', x, C, None, 0, w, 0, None, None, 0, None, 1.0, y, *dims, fws, fb)
   dx = torch.empty_like(x)
-  call(hip_lib, 'conv2d_dgrad_f32', g, w, 0, dx, C, 0.0, None, 0, 0.0, 1.0, *dims)
+  call(hip_lib, 'conv2d_dgrad_f32', g, w, 0, dx, C, 0.0, None, 0, 0.0, 1.0, *dims, fws, fb)
   ws = torch.zeros(int(hip_lib.conv2d_wgrad_ws_bytes(C, 0, N, C, H, H, 3, 3)) // 4 + 64, device=d)
   dw = torch.zeros_like(w)
   call(hip_lib, 'conv2d_wgrad_f32', x, C, None, 0, g, dw, 0, 1.0, ws, ws.numel() * 4, *dims)

@@ -78,8 +78,14 @@ def main():
       dims = (N, H, H, Cout, H, H, K, K, 1, K // 2)
       flops = 2.0 * N * H * H * Cout * Cin * K * K
       shape = f'{Cin}->{Cout} {K}x{K} @{H}x{H} b{N}' + (' dual' if C2 else '')
-      rec('conv.fwd', shape, timeit(lambda: call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, 0, bias, None, 0, None, 1.0, y, *dims), args.reps), flops)
-      rec('conv.dgrad', shape, timeit(lambda: call(lib, 'conv2d_dgrad_f32', dy, w, 0, dx1, C1, 0.0, dx2, C2, 0.0, 1.0, *dims), args.reps), flops)
+      shp = (C1, C2, N, H, H, Cout, K, K, 1, K // 2)
+      fb = max(int(lib.conv2d_fwd_ws_bytes(*shp)), int(lib.conv2d_dgrad_ws_bytes(*shp)))
+      fws = torch.empty(fb // 4 + 64, device=d)
+      rec('conv.fwd.f32in', shape, timeit(lambda: call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, 0, bias, None, 0, None, 1.0, y, *dims, None, 0), args.reps), flops)
+      rec('conv.dgrad.f32in', shape, timeit(lambda: call(lib, 'conv2d_dgrad_f32', dy, w, 0, dx1, C1, 0.0, dx2, C2, 0.0, 1.0, *dims, None, 0), args.reps), flops)
+      if fb:
+        rec('conv.fwd.x3', shape, timeit(lambda: call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, 0, bias, None, 0, None, 1.0, y, *dims, fws, fb), args.reps), flops)
+        rec('conv.dgrad.x3', shape, timeit(lambda: call(lib, 'conv2d_dgrad_f32', dy, w, 0, dx1, C1, 0.0, dx2, C2, 0.0, 1.0, *dims, fws, fb), args.reps), flops)
       rec('conv.wgrad', shape, timeit(lambda: call(lib, 'conv2d_wgrad_f32', x1, C1, x2, C2, dy, dw, 0, 1.0, ws, ws.numel() * 4, *dims), args.reps), flops)
 
   if not args.only or 'gn' in args.only:
