@@ -744,12 +744,13 @@ inline int fill_common(ConvP& p, int N, int H, int W, int C1, int C2, int Cout, 
 }
 
 // The bf16 three-way-split kernel (conv_x3.h) takes 3x3 / stride 1 / pad 1 layers whose channel count is a multiple
-// of the 32-wide k chunk (and, for a concat input, whose first source is too) when there are at least 64 tiles of
-// 128 x 128 (at ~2.5x the f32-input rate a quarter-filled chip still beats the 64 x 64 f32-input kernel).
+// of the 32-wide k chunk (and, for a concat input, whose first source is too) when there are at least 192 tiles of
+// 128 x 128 (measured: with 128 tiles -- 8x8 maps at batch 128 -- one workgroup per CU has nothing to overlap with
+// and the 64 x 64 f32-input kernel is faster).
 inline bool x3_ok(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
   return p.taps == 9 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W && Kc % 32 == 0 &&
          (S2 == 0 || S1 % 32 == 0) && M >= 96 && Ng <= 0x7fffffffL &&
-         (long)stk_cdiv(M, 128) * stk_cdiv(Ng, 128) >= 64;
+         (long)stk_cdiv(M, 128) * stk_cdiv(Ng, 128) >= 192;
 }
 template <class EP>
 int launch_x3(const ConvP& p, const float* s1, int S1, const float* s2, int S2, int M, long Ng, int transpose,

@@ -172,31 +172,54 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvP p, Src q, int M, int
   const unsigned char* a_rd = As + (wm0 + fc) * PITCH + fk * 16;
   const unsigned char* b_rd = Bs + (wn0 + fc) * PITCH + fk * 16;
 
-  load(0);
-  for (int c = 0; c < nchunks; ++c) {
-    store();
-    __syncthreads();
-    if (c + 1 < nchunks) load(c + 1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 a[2][3], b[2][3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          a[i][s] = *reinterpret_cast<const bf16x8*>(a_rd + s * PLANE + i * 32 * PITCH + kk * 32);
-          b[i][s] = *reinterpret_cast<const bf16x8*>(b_rd + s * PLANE + i * 32 * PITCH + kk * 32);
-        }
-      // six products per tile, smallest terms first; the four tiles interleave so that consecutive MFMAs
-      // never wait on the same accumulator
+  // Pipeline (LDS single-buffered, two barriers per chunk):
+  //   B1: chunk c is in LDS          -> read the kk = 0 fragments, 24 MFMAs, read the kk = 1 fragments
+  //   B2: nobody reads LDS any more  -> 24 MFMAs of kk = 1 INTERLEAVED with the split + LDS write of chunk c + 1
+  //                                     (whose global loads were issued one full iteration earlier), then the
+  //                                     global loads of chunk c + 2 are issued.
+  // So the conversion VALU and the LDS stores run in the shadow of the matrix pipe of the same wave, and a global
+  // load has a whole chunk period (~3k cycles) to land.
+#define STK_X3_FRAGS(KK)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s = 0; s < 3; ++s) {         \
+    a[i][s] = *reinterpret_cast<const bf16x8*>(a_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);          \
+    b[i][s] = *reinterpret_cast<const bf16x8*>(b_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);          \
+  }
+  // six products per tile, smallest terms first; the four tiles interleave so that consecutive MFMAs never
+  // wait on the same accumulator
 #define STK_X3_PROD(SA, SB)                                                                             \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][SA], b[j][SB], acc[i][j], 0, 0, 0);
-      STK_X3_PROD(2, 0) STK_X3_PROD(1, 1) STK_X3_PROD(0, 2) STK_X3_PROD(1, 0) STK_X3_PROD(0, 1) STK_X3_PROD(0, 0)
-#undef STK_X3_PROD
+#define STK_X3_MFMAS STK_X3_PROD(2, 0) STK_X3_PROD(1, 1) STK_X3_PROD(0, 2) STK_X3_PROD(1, 0) STK_X3_PROD(0, 1) STK_X3_PROD(0, 0)
+  load(0);
+  store();
+  load(min(1, nchunks - 1));
+  bf16x8 a[2][3], b[2][3];
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    __syncthreads();                                   // B1
+    STK_X3_FRAGS(0)
+    STK_X3_MFMAS
+    STK_X3_FRAGS(1)
+    __syncthreads();                                   // B2
+    STK_X3_MFMAS
+    store();                                           // chunk c + 1
+    load(min(c + 2, nchunks - 1));                     // (the last iteration re-loads the last chunk: harmless)
+    // one MFMA, then a slice of the staging work: ~150 VALU, 12 LDS writes, 22 global loads over 24 MFMAs
+#pragma unroll
+    for (int g = 0; g < 24; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);     // VALU
+      if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
     }
-    __syncthreads();
   }
+  __syncthreads();
+  STK_X3_FRAGS(0)
+  STK_X3_MFMAS
+  STK_X3_FRAGS(1)
+  STK_X3_MFMAS
+#undef STK_X3_MFMAS
+#undef STK_X3_PROD
+#undef STK_X3_FRAGS
 
   EP ep;
   ep.init(p, 0, 0);

@@ -267,9 +267,9 @@ CONV_CASES = [
   (5, 40, 0, 4, 4, 56, 1, 1, 0, 4, 4, 1, False, False, False),          # NIN, ragged channels
   (2, 20, 12, 12, 10, 24, 3, 1, 1, 12, 10, 0, True, True, False),       # ragged everything
   (130, 128, 0, 4, 4, 128, 3, 1, 1, 4, 4, 0, True, False, True),        # many tiny images per tile
-  (8, 128, 0, 32, 32, 128, 3, 1, 1, 32, 32, 0, True, True, True),       # >= 64 tiles: bf16 three-way-split kernel
-  (40, 64, 96, 16, 16, 160, 3, 1, 1, 16, 16, 0, False, True, False),    # split kernel: concat input, ragged Cout
-  (17, 96, 0, 24, 24, 128, 3, 1, 1, 24, 24, 0, True, False, False),     # split kernel: ragged pixel tiles
+  (24, 128, 0, 32, 32, 128, 3, 1, 1, 32, 32, 0, True, True, True),      # >= 192 tiles: bf16 three-way-split kernel
+  (48, 64, 96, 16, 16, 160, 3, 1, 1, 16, 16, 0, False, True, False),    # split kernel: concat input, ragged Cout
+  (43, 96, 0, 24, 24, 128, 3, 1, 1, 24, 24, 0, True, False, False),     # split kernel: ragged pixel tiles
 ]
 
 
