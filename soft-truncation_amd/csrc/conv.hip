@@ -763,13 +763,37 @@ int launch_x3(const ConvP& p, const float* s1, int S1, const float* s2, int S2, 
   hipLaunchKernelGGL(x3::wprep_kernel, dim3((unsigned)stk_cdiv(n, 256)), dim3(256), 0, s, p.w, wp, p.Cout, p.Cin, q.Mpad,
                      transpose);
   STK_CHECK_LAUNCH();
-  const int tm = q.Mpad / 128, tn = stk_cdiv((int)Ng, 128);
+  const int tm = q.Mpad / 128, tn = stk_cdiv((int)Ng, 128), nch = 9 * (q.Kc / x3::KC);
   if (S2 > 0)
-    hipLaunchKernelGGL((x3::conv3x3_kernel<EP, true>), dim3((unsigned)(tm * tn)), dim3(256), 0, s, p, q, M, (int)Ng, tm, tn);
+    hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<true>, EP>), dim3((unsigned)(tm * tn)), dim3(256), 0, s,
+                       p, q, M, (int)Ng, tm, tn, nch, nch, 0);
   else
-    hipLaunchKernelGGL((x3::conv3x3_kernel<EP, false>), dim3((unsigned)(tm * tn)), dim3(256), 0, s, p, q, M, (int)Ng, tm, tn);
+    hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<false>, EP>), dim3((unsigned)(tm * tn)), dim3(256), 0, s,
+                       p, q, M, (int)Ng, tm, tn, nch, nch, 0);
   STK_CHECK_LAUNCH();
   return STK_OK;
+}
+
+// Weight gradient on the split kernel: 3x3 / stride 1 / pad 1, power-of-two maps of >= 8 columns and >= 32 pixels,
+// enough channels to fill 128-wide tiles.  One GEMM per tap, K (= pixels) split so that <= 512 workgroups run.
+struct X3WgradPlan { int ok; int splits; int chunks_per_split; long slab; };
+inline X3WgradPlan x3_wgrad_plan(int Cin, int N, int Cout, int H, int W, int OH, int OW, int KH, int KW, int stride, int pad) {
+  X3WgradPlan q = {0, 0, 0, 0};
+  const long K = (long)N * H * W;
+  const bool pow2 = (W & (W - 1)) == 0 && ((H * W) & (H * W - 1)) == 0;
+  if (KH != 3 || KW != 3 || stride != 1 || pad != 1 || OH != H || OW != W || !pow2 || W < 8 || H * W < 32 ||
+      Cin < 64 || Cout < 64 || K > 0x7fffffffL || K % 32)
+    return q;
+  const long tiles = 9L * stk_cdiv(Cout, 128) * stk_cdiv(Cin, 128);
+  const long chunks = K / 32;
+  long splits = 512 / tiles;
+  if (splits > chunks / 8) splits = chunks / 8;
+  if (splits < 1) splits = 1;
+  q.chunks_per_split = (int)((chunks + splits - 1) / splits);
+  q.splits = (int)((chunks + q.chunks_per_split - 1) / q.chunks_per_split);
+  q.slab = (long)Cout * Cin * 9;
+  q.ok = 1;
+  return q;
 }
 
 struct WgradPlan { int big; int splits; int k_per_split; long slab; int mode9; };
@@ -910,8 +934,10 @@ long stk_conv2d_dgrad_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, in
 long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW) {
   const WgradPlan a = wgrad_plan(C1 + C2, N, Cout, OH, OW, KH, KW, true);
   const WgradPlan b = wgrad_plan(C1 + C2, N, Cout, OH, OW, KH, KW, false);
-  const long na = (long)a.splits * a.slab, nb = (long)b.splits * b.slab;
-  return (na > nb ? na : nb) * 4 + 256;
+  const X3WgradPlan x = x3_wgrad_plan(C1 + C2, N, Cout, OH, OW, OH, OW, KH, KW, 1, 1);
+  const long na = (long)a.splits * a.slab, nb = (long)b.splits * b.slab, nx = x.ok ? (long)x.splits * x.slab : 0;
+  const long m = na > nb ? na : nb;
+  return (m > nx ? m : nx) * 4 + 256;
 }
 
 int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const float* dy, float* dw, int w_layout,
@@ -923,6 +949,26 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
   ConvP p = {};
   int rc = fill_common(p, N, H, W, C1, C2, Cout, OH, OW, KH, KW, stride, pad);
   if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const X3WgradPlan xq = x3_wgrad_plan(p.Cin, N, Cout, H, W, OH, OW, KH, KW, stride, pad);
+  if (xq.ok && w_layout == 0 && ws_bytes >= (long)xq.splits * xq.slab * 4) {
+    p.x1 = x1; p.x2 = C2 > 0 ? x2 : x1; p.dy = dy; p.w_layout = w_layout; p.part = ws; p.part_stride = xq.slab;
+    x3::Src q = {};
+    const int tm = stk_cdiv(Cout, 128), tn = stk_cdiv(p.Cin, 128);
+    const int nch = (int)((long)N * p.HW / 32);
+    const dim3 grid((unsigned)(9 * tm * tn * xq.splits));
+    if (C2 > 0)
+      hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false>, x3::RowsLoader<true, true>, EpWgrad>), grid, dim3(256),
+                         0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, 9);
+    else
+      hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false>, x3::RowsLoader<true, false>, EpWgrad>), grid, dim3(256),
+                         0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, 9);
+    STK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid(xq.slab)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
+                       xq.slab, alpha, w_layout, Cout, p.Cin, p.taps);
+    STK_CHECK_LAUNCH();
+    return STK_OK;
+  }
   const bool can9 = stride == 1 && pad == 1 && C2 == 0 && OH == H && OW == W && w_layout == 0;
   const WgradPlan q = wgrad_plan(p.Cin, N, Cout, OH, OW, KH, KW, can9);
   if (ws_bytes < (long)q.splits * q.slab * 4) return STK_EINVAL;
@@ -930,7 +976,6 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
   const long Kl = (long)N * p.OHW;
   if (Kl > 0x7fffffffL) return STK_EUNSUPPORTED;
   const int K = (int)Kl;
-  hipStream_t s = (hipStream_t)stream;
   using CB = Cfg<128, 128, 32>; using CS = Cfg<64, 64, 32>;
   if (q.mode9) {
     const int tm = stk_cdiv(Cout, 128), tn = stk_cdiv(p.Cin, 32);

@@ -23,6 +23,11 @@
 //     per lane = 8 consecutive k of one row) and the staging writes are bank-conflict free;
 //   * 128 x 128 tile, 4 waves of 64 x 64 (2 x 2 MFMA tiles): per 16-k step 12 ds_read_b128 and 24 MFMAs per wave,
 //     small terms first so the accumulation order is fixed.
+//
+// Weight gradient (same kernel, other loaders):  dw[tap][co, ci] = sum_pixels dy[co, px] * x[ci, px + tap shift]:
+// both operands have k = pixels contiguous in NCHW, so a thread stages 16 consecutive pixels of one channel (the x
+// operand shifted by the tap, halo masked); one GEMM per tap, split over K into partial slabs that
+// splitk_reduce_kernel sums in a fixed order (no float atomics).
 #pragma once
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -78,86 +83,181 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w,
   }
 }
 
-template <class EP, bool DUAL>
-__global__ __launch_bounds__(256) void conv3x3_kernel(ConvP p, Src q, int M, int Nn, int tiles_m, int tiles_n) {
+// Split 16 fp32 values (invalid ones zeroed by mask bit) into three bf16 planes and write them as 16 consecutive
+// k of LDS row `row` at k offset `k0` (0 or 16):  2 x ds_write_b128 per plane.
+__device__ __forceinline__ void split_store16(const float (&r)[16], unsigned okm, unsigned char* tile, int row, int k0) {
+  unsigned pk[3][8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float v0 = igemm::keep_if(r[2 * u], okm, 2 * u), v1 = igemm::keep_if(r[2 * u + 1], okm, 2 * u + 1);
+    const float r0 = v0 - hi_part(v0), r1 = v1 - hi_part(v1);
+    const float t0 = r0 - hi_part(r0), t1 = r1 - hi_part(r1);
+    pk[0][u] = pack_hi(v0, v1);
+    pk[1][u] = pack_hi(r0, r1);
+    pk[2][u] = pack_hi(t0, t1);
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    unsigned char* d = tile + s * PLANE + row * PITCH + k0 * 2;
+    *reinterpret_cast<u32x4*>(d) = u32x4{pk[s][0], pk[s][1], pk[s][2], pk[s][3]};
+    *reinterpret_cast<u32x4*>(d + 16) = u32x4{pk[s][4], pk[s][5], pk[s][6], pk[s][7]};
+  }
+}
+
+// ---- loaders: init(p, q, tile origin, tid, zb) / load(p, q, chunk) / store(LDS operand tile) ------------------
+// forward / dgrad A: prepared weights, six 16-byte pieces per chunk (split j>>1, row (tid>>2) + 64 (j&1), segment tid&3)
+struct WpLoader {
+  const unsigned short* base; long plane; int row, seg, cpt;
+  u32x4 r[6];
+  __device__ __forceinline__ void init(const ConvP&, const Src& q, int m0, int tid, int) {
+    row = tid >> 2; seg = tid & 3; cpt = q.Kc / KC;
+    plane = 9L * q.Mpad * q.Kc;
+    base = q.wp + ((long)(m0 + row) * q.Kc + seg * 8);
+  }
+  __device__ __forceinline__ void load(const ConvP&, const Src& q, int c) {
+    const int tap = c / cpt, cc = c - tap * cpt;                 // scalar
+    const unsigned short* s = base + ((long)tap * q.Mpad * q.Kc + cc * KC);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) r[j] = *reinterpret_cast<const u32x4*>(s + (j >> 1) * plane + (long)(j & 1) * 64 * q.Kc);
+  }
+  __device__ __forceinline__ void store(unsigned char* t) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4*>(t + (j >> 1) * PLANE + (row + 64 * (j & 1)) * PITCH + seg * 16) = r[j];
+  }
+};
+
+// forward / dgrad B: activations, lanes along pixels; a thread holds 16 channels of one tap-shifted pixel
+template <bool DUAL>
+struct ActLoader {
+  int nl, kg, tb1, tb2, cpt; unsigned mask, bok;
+  float r[16];
+  __device__ __forceinline__ void init(const ConvP& p, const Src& q, int n0, int tid, int) {
+    nl = tid & 127;
+    kg = __builtin_amdgcn_readfirstlane(tid >> 7);      // which 16 of the chunk's 32 channels
+    cpt = q.Kc / KC;
+    mask = 0; tb1 = 0; tb2 = 0; bok = 0;
+    const int n = n0 + nl;
+    if (n < p.N * p.HW) {
+      const int b = n / p.HW, hw = n - b * p.HW;
+      const int y = hw / p.W, x = hw - y * p.W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+      }
+      tb1 = b * q.S1 * p.HW + hw;
+      tb2 = b * q.S2 * p.HW + hw;
+    }
+  }
+  __device__ __forceinline__ void load(const ConvP& p, const Src& q, int c) {
+    const int tap = c / cpt, cc = c - tap * cpt;                 // scalar
+    const int ci0 = cc * KC + kg * 16;
+    const bool first = !DUAL || ci0 < q.S1;
+    const uintptr_t tensor = first ? (uintptr_t)q.s1 : (uintptr_t)q.s2;
+    const gfloat* plane = (const gfloat*)(tensor + (uintptr_t)(first ? ci0 : ci0 - q.S1) * (uintptr_t)p.HW * 4u);
+    bok = (mask >> tap) & 1u;
+    const int off = bok ? (first ? tb1 : tb2) + (tap / 3 - 1) * p.W + (tap % 3 - 1) : 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = (plane + (long)i * p.HW)[off];
+  }
+  __device__ __forceinline__ void store(unsigned char* t) { split_store16(r, bok ? 0xffffu : 0u, t, nl, kg * 16); }
+};
+
+// wgrad operands: rows = channels, k = pixels (contiguous in NCHW).  Thread (row = tid>>1, half = tid&1) holds the
+// 16 consecutive pixels k0 + 16*half .. +15 of its channel, shifted by the tap for the x operand.  Requires W a
+// power of two >= 8 and H*W a power of two >= 32, so a 16-pixel run is one row segment (W >= 16) or two rows (W = 8).
+template <bool SHIFT, bool DUAL>
+struct RowsLoader {
+  const float* rowp;      // this thread's channel plane of image 0 (any valid plane when the row is out of range)
+  long bstride;           // elements between images in this thread's tensor
+  int row, half, dy, dx; bool rowok; unsigned okm;
+  float r[16];
+  __device__ __forceinline__ void init(const ConvP& p, const Src&, int o0, int tid, int zb) {
+    row = tid >> 1; half = tid & 1; okm = 0;
+    dy = SHIFT ? zb / 3 - 1 : 0; dx = SHIFT ? zb % 3 - 1 : 0;
+    const int ch = o0 + row;
+    if (SHIFT) {                                   // x: channel of the concat input
+      rowok = ch < p.Cin;
+      const int c = rowok ? ch : 0;
+      const bool first = !DUAL || c < p.C1;
+      rowp = (first ? p.x1 : p.x2) + (long)(first ? c : c - p.C1) * p.HW;
+      bstride = (long)(first ? p.C1 : p.C2) * p.HW;
+    } else {                                       // dy: output channel
+      rowok = ch < p.Cout;
+      rowp = p.dy + (long)(rowok ? ch : 0) * p.HW;
+      bstride = (long)p.Cout * p.HW;
+    }
+  }
+  __device__ __forceinline__ void load(const ConvP& p, const Src&, int c) {
+    const int k = c * KC + half * 16;              // first pixel of the run (global pixel index)
+    const bool kin = rowok && k < p.N * p.HW;      // N*H*W is a multiple of 16: a run is inside or outside as a whole
+    const int b = k >> p.ohw_shift, hw = k & (p.HW - 1);
+    const int y = hw >> p.ow_shift, x0 = hw & (p.W - 1);
+    unsigned m = 0;
+    if (!SHIFT) {
+      m = 0xffffu;
+    } else if (p.W >= 16) {                        // one row segment
+      const bool yok = (unsigned)(y + dy) < (unsigned)p.H;
+      m = yok ? 0xffffu : 0u;
+      if (dx < 0 && x0 == 0) m &= ~1u;
+      if (dx > 0 && x0 + 16 == p.W) m &= ~0x8000u;
+    } else {                                       // W == 8: two full rows
+      const bool y0 = (unsigned)(y + dy) < (unsigned)p.H, y1 = (unsigned)(y + 1 + dy) < (unsigned)p.H;
+      m = (y0 ? 0x00ffu : 0u) | (y1 ? 0xff00u : 0u);
+      if (dx < 0) m &= ~0x0101u;
+      if (dx > 0) m &= ~0x8080u;
+    }
+    okm = kin ? m : 0u;
+    // The run is contiguous in memory.  Masked elements must still be read from inside the tensor: the four
+    // possible edge elements and the two 6-element interiors each fall back to the start of the plane.
+    const long o = okm ? (long)b * bstride + hw + dy * p.W + dx : 0;
+    const float* s = rowp + o;
+    const float* s_lo = (okm & 0x007eu) ? s : rowp;
+    const float* s_hi = (okm & 0x7e00u) ? s : rowp;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j == 0 || j == 7 || j == 8 || j == 15) {
+        const float* e = ((okm >> j) & 1u) ? s : rowp;
+        r[j] = e[j];
+      } else {
+        r[j] = (j < 8 ? s_lo : s_hi)[j];
+      }
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* t) { split_store16(r, okm, t, row, half * 16); }
+};
+
+// ---- the kernel: out tile 128 x 128, 4 waves of 64 x 64, chunks of 32 k ---------------------------------------
+// Grid: tiles (XCD-remapped);  with taps_z > 0 (wgrad) one flat dimension of taps x tiles x splits, tap fastest so
+// that the nine blocks reading the same dy / x panels are neighbours on one XCD's L2.
+template <class AL, class BL, class EP>
+__global__ __launch_bounds__(256) void gemm_kernel(ConvP p, Src q, int M, int Nn, int tiles_m, int tiles_n,
+                                                   int nchunks_total, int chunks_per_split, int taps_z) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   unsigned char* As = lds;
   unsigned char* Bs = lds + OPER;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int ntiles = tiles_m * tiles_n;
+  int tile, zb = 0, zs = 0;
+  if (taps_z > 0) {
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    zb = id % taps_z;
+    const int rest = id / taps_z;
+    tile = rest % ntiles;
+    zs = rest / ntiles;
+  } else {
+    tile = xcd_remap(blockIdx.x, ntiles);
+  }
   const int tm = tile % tiles_m, tn = tile / tiles_m;
   const int m0 = tm * 128, n0 = tn * 128;
-  const int HW = p.HW, W = p.W;
+  const int c_begin = zs * chunks_per_split;
+  const int c_last = min(nchunks_total, c_begin + chunks_per_split) - 1;     // >= c_begin by construction
 
-  // ---- B loader state: this thread's pixel and its 9-tap halo mask
-  const int nl = tid & 127;
-  const int kg = __builtin_amdgcn_readfirstlane(tid >> 7);      // which 16 of the chunk's 32 channels
-  unsigned mask = 0; int tb1 = 0, tb2 = 0;
-  {
-    const int n = n0 + nl;
-    if (n < Nn) {
-      const int b = n / HW, hw = n - b * HW;
-      const int y = hw / W, x = hw - y * W;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < W) mask |= 1u << t;
-      }
-      tb1 = b * q.S1 * HW + hw;
-      tb2 = b * q.S2 * HW + hw;
-    }
-  }
-  // ---- A loader state: six 16-byte pieces per chunk: (split j>>1, row (tid>>2) + 64 (j&1), segment tid&3)
-  const int a_row = tid >> 2, a_seg = tid & 3;
-  const long a_plane = 9L * q.Mpad * q.Kc;                       // elements per split plane
-  const unsigned short* a_base = q.wp + ((long)(m0 + a_row) * q.Kc + a_seg * 8);
-
-  const int cpt = q.Kc / KC;          // chunks per tap
-  const int nchunks = 9 * cpt;
-
-  float rb[16]; u32x4 ra[6]; unsigned bok = 0;
-  auto load = [&](int c) {
-    const int tap = c / cpt, cc = c - tap * cpt;                 // scalar
-    // weights
-    const unsigned short* s = a_base + ((long)tap * q.Mpad * q.Kc + cc * KC);
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      ra[j] = *reinterpret_cast<const u32x4*>(s + (j >> 1) * a_plane + (long)(j & 1) * 64 * q.Kc);
-    // activations: 16 channels of one tap-shifted pixel; unconditional loads from a safe offset
-    const int ci0 = cc * KC + kg * 16;
-    const bool first = !DUAL || ci0 < q.S1;
-    const uintptr_t tensor = first ? (uintptr_t)q.s1 : (uintptr_t)q.s2;
-    const gfloat* plane = (const gfloat*)(tensor + (uintptr_t)(first ? ci0 : ci0 - q.S1) * (uintptr_t)HW * 4u);
-    bok = (mask >> tap) & 1u;
-    const int off = bok ? (first ? tb1 : tb2) + (tap / 3 - 1) * W + (tap % 3 - 1) : 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) rb[i] = (plane + (long)i * HW)[off];
-  };
-  auto store = [&]() {
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      *reinterpret_cast<u32x4*>(As + (j >> 1) * PLANE + (a_row + 64 * (j & 1)) * PITCH + a_seg * 16) = ra[j];
-    const unsigned zm = bok ? 0xffffffffu : 0u;
-    unsigned pk[3][8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float v0 = __uint_as_float(__float_as_uint(rb[2 * u]) & zm);
-      const float v1 = __uint_as_float(__float_as_uint(rb[2 * u + 1]) & zm);
-      const float r0 = v0 - hi_part(v0), r1 = v1 - hi_part(v1);
-      const float t0 = r0 - hi_part(r0), t1 = r1 - hi_part(r1);
-      pk[0][u] = pack_hi(v0, v1);
-      pk[1][u] = pack_hi(r0, r1);
-      pk[2][u] = pack_hi(t0, t1);
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      unsigned char* d = Bs + s * PLANE + nl * PITCH + kg * 32;
-      *reinterpret_cast<u32x4*>(d) = u32x4{pk[s][0], pk[s][1], pk[s][2], pk[s][3]};
-      *reinterpret_cast<u32x4*>(d + 16) = u32x4{pk[s][4], pk[s][5], pk[s][6], pk[s][7]};
-    }
-  };
+  AL al; BL bl;
+  al.init(p, q, m0, tid, zb);
+  bl.init(p, q, n0, tid, zb);
 
   floatx16 acc[2][2];
 #pragma unroll
@@ -190,24 +290,24 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvP p, Src q, int M, int
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][SA], b[j][SB], acc[i][j], 0, 0, 0);
 #define STK_X3_MFMAS STK_X3_PROD(2, 0) STK_X3_PROD(1, 1) STK_X3_PROD(0, 2) STK_X3_PROD(1, 0) STK_X3_PROD(0, 1) STK_X3_PROD(0, 0)
-  load(0);
-  store();
-  load(min(1, nchunks - 1));
+  al.load(p, q, c_begin); bl.load(p, q, c_begin);
+  al.store(As); bl.store(Bs);
+  al.load(p, q, min(c_begin + 1, c_last)); bl.load(p, q, min(c_begin + 1, c_last));
   bf16x8 a[2][3], b[2][3];
-  for (int c = 0; c + 1 < nchunks; ++c) {
+  for (int c = c_begin; c < c_last; ++c) {
     __syncthreads();                                   // B1
     STK_X3_FRAGS(0)
     STK_X3_MFMAS
     STK_X3_FRAGS(1)
     __syncthreads();                                   // B2
     STK_X3_MFMAS
-    store();                                           // chunk c + 1
-    load(min(c + 2, nchunks - 1));                     // (the last iteration re-loads the last chunk: harmless)
-    // one MFMA, then a slice of the staging work: ~150 VALU, 12 LDS writes, 22 global loads over 24 MFMAs
+    al.store(As); bl.store(Bs);                        // chunk c + 1
+    al.load(p, q, min(c + 2, c_last)); bl.load(p, q, min(c + 2, c_last));   // (the last iteration re-loads: harmless)
+    // one MFMA, then a slice of the staging work (VALU, LDS writes, global loads) over the 24 MFMAs
 #pragma unroll
     for (int g = 0; g < 24; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);     // VALU
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // VALU
       if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
     }
@@ -222,7 +322,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvP p, Src q, int M, int
 #undef STK_X3_FRAGS
 
   EP ep;
-  ep.init(p, 0, 0);
+  ep.init(p, zb, zs);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn0 + j * 32 + fc;

@@ -270,6 +270,8 @@ CONV_CASES = [
   (24, 128, 0, 32, 32, 128, 3, 1, 1, 32, 32, 0, True, True, True),      # >= 192 tiles: bf16 three-way-split kernel
   (48, 64, 96, 16, 16, 160, 3, 1, 1, 16, 16, 0, False, True, False),    # split kernel: concat input, ragged Cout
   (43, 96, 0, 24, 24, 128, 3, 1, 1, 24, 24, 0, True, False, False),     # split kernel: ragged pixel tiles
+  (6, 64, 0, 8, 8, 96, 3, 1, 1, 8, 8, 0, False, False, False),          # split wgrad: 8-wide maps (runs span two rows)
+  (3, 32, 64, 8, 8, 72, 3, 1, 1, 8, 8, 0, False, False, False),         # split wgrad: 8-wide, concat, ragged Cout
 ]
 
 
