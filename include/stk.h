@@ -105,6 +105,11 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
  * ------------------------------------------------------------------------------------------ */
 long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW,
                              int stride, int pad);
+/* Which kernel family a call with full scratch takes (for profiling labels): dir 0 fwd, 1 dgrad, 2 wgrad;
+ * returns 0 / 1 = f32-input MFMA with 64 / 128 tiles, 2 = bf16 three-way split, 3 = f32-input all-taps wgrad,
+ * < 0 = unsupported shape. */
+int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, int OH, int OW,
+                       int KH, int KW, int stride, int pad, int w_layout);
 long stk_conv2d_dgrad_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW,
                                int stride, int pad);
 int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2,

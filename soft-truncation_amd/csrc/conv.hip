@@ -919,6 +919,29 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
   return launch<CS, ConvP, ADgradNin<CS>, BDgrad<CS, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
 }
 
+/* which kernel family a call with full scratch takes: 0/1 = f32-input MFMA with 64/128 tiles, 2 = bf16 three-way
+ * split, 3 = f32-input all-taps weight gradient.  dir: 0 fwd, 1 dgrad, 2 wgrad. */
+int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW,
+                       int stride, int pad, int w_layout) {
+  ConvP p = {};
+  if (fill_common(p, N, H, W, C1, C2, Cout, OH, OW, KH, KW, stride, pad)) return -1;
+  const int Cin = C1 + C2;
+  if (dir == 0) {
+    const long Ng = (long)N * p.OHW;
+    if (w_layout == 0 && x3_ok(p, Cin, C1, C2, Cout, Ng)) return 2;
+    return use_big_tile(Cout, Ng, 1) && !(p.taps == 1 && w_layout == 0 && (Cin % 8)) ? 1 : 0;
+  }
+  if (dir == 1) {
+    const long Ng = (long)N * p.HW;
+    if (w_layout == 0 && x3_ok(p, Cout, Cout, 0, Cin, Ng)) return 2;
+    return use_big_tile(Cin, Ng, 1) && !(p.taps == 1 && w_layout == 1 && (Cout % 8)) ? 1 : 0;
+  }
+  if (w_layout == 0 && x3_wgrad_plan(Cin, N, Cout, H, W, OH, OW, KH, KW, stride, pad).ok) return 2;
+  const bool can9 = stride == 1 && pad == 1 && C2 == 0 && OH == H && OW == W && w_layout == 0;
+  const WgradPlan q = wgrad_plan(Cin, N, Cout, OH, OW, KH, KW, can9);
+  return q.mode9 ? 3 : q.big;
+}
+
 long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, stride, pad)) return 0;

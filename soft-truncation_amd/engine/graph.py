@@ -170,21 +170,27 @@ class Conv(Op):
     # algorithmic FLOPs of one launch (1 MAC = 2 FLOP); identical for fwd, dgrad and wgrad
     self.flops = 2.0 * N * OH * OW * Cout * (C1 + C2) * KH * KW
 
-  def _kind(self, direction, M, Ncols, wgrad=False):
-    """Kernel-symbol label: direction, taps and the tile variant csrc/conv.hip picks for this shape."""
-    if wgrad:
-      big = M >= 96 and Ncols >= 96 and -(-M // 128) * -(-Ncols // 128) * self.KH * self.KW >= 9
-    else:
-      t = -(-M // 128) * -(-Ncols // 128)
-      big = M >= 96 and Ncols >= 96 and t >= 192
-    return f'conv{self.KH}x{self.KW}.{direction}.{"t128" if big else "t64"}'
+  _VARIANT = {0: 't64', 1: 't128', 2: 'x3', 3: 't128'}
+
+  def _kind(self, lib, direction):
+    """Kernel label for the profiler: direction, taps and the kernel family csrc/conv.hip picks for this shape
+    (t64 / t128 = f32-input MFMA tiles, x3 = bf16 three-way split)."""
+    key = '_kind_' + direction
+    k = getattr(self, key, None)
+    if k is None:
+      v = int(lib.conv2d_variant({'fwd': 0, 'dgrad': 1, 'wgrad': 2}[direction], self.C1, self.C2, self.N, self.H,
+                                 self.W, self.Cout, self.OH, self.OW, self.KH, self.KW, self.stride, self.pad,
+                                 self.w_layout))
+      k = f'conv{self.KH}x{self.KW}.{direction}.{self._VARIANT.get(v, "t64")}'
+      setattr(self, key, k)
+    return k
 
   def _dims(self):
     return (self.N, self.H, self.W, self.Cout, self.OH, self.OW, self.KH, self.KW, self.stride, self.pad)
 
   def forward(self, rt):
     temb = rt.v(self.temb) + 4 * self.temb_col if self.temb is not None else None
-    rt.timed(self._kind('fwd', self.Cout, self.N * self.OH * self.OW), self.flops, rt.lib.conv2d_fwd_f32,
+    rt.timed(self._kind(rt.lib, 'fwd'), self.flops, rt.lib.conv2d_fwd_f32,
              rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.w), self.w_layout,
              rt.v(self.bias), temb, self.temb_stride, rt.v(self.res), self.out_div,
              rt.v(self.y), *self._dims(), rt.ws, rt.ws_bytes, rt.stream)
@@ -205,12 +211,12 @@ class Conv(Op):
                         rt.ws, rt.stream)
     gw = rt.g(self.w)
     if gw is not None:
-      rt.timed(self._kind('wgrad', self.Cout, self.C1 + self.C2, wgrad=True), self.flops, lib.conv2d_wgrad_f32,
+      rt.timed(self._kind(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_f32,
                rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, gy, gw, self.w_layout, alpha,
                rt.ws, rt.ws_bytes, *self._dims(), rt.stream)
     g1, g2 = rt.g(self.x1), rt.g(self.x2)
     if g1 is not None or g2 is not None:
-      rt.timed(self._kind('dgrad', self.C1 + self.C2, self.N * self.H * self.W), self.flops, lib.conv2d_dgrad_f32,
+      rt.timed(self._kind(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_f32,
                gy, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
                alpha, *self._dims(), rt.ws, rt.ws_bytes, rt.stream)
