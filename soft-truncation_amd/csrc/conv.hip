@@ -748,7 +748,8 @@ inline int fill_common(ConvP& p, int N, int H, int W, int C1, int C2, int Cout, 
 // 128 x 128 (measured: with 128 tiles -- 8x8 maps at batch 128 -- one workgroup per CU has nothing to overlap with
 // and the 64 x 64 f32-input kernel is faster).
 inline bool x3_ok(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
-  return p.taps == 9 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W && Kc % 32 == 0 &&
+  const long big = (long)p.N * p.HW * 4 * (S1 > S2 ? S1 : S2);       // buffer loads: 32-bit byte offsets, bit 31 = dead lane
+  return big < 0x7fffffffL && p.taps == 9 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W && Kc % 32 == 0 &&
          (S2 == 0 || S1 % 32 == 0) && M >= 96 && Ng <= 0x7fffffffL &&
          (long)stk_cdiv(M, 128) * stk_cdiv(Ng, 128) >= 192;
 }
@@ -777,9 +778,13 @@ int launch_x3(const ConvP& p, const float* s1, int S1, const float* s2, int S2, 
 // Weight gradient on the split kernel: 3x3 / stride 1 / pad 1, power-of-two maps of >= 8 columns and >= 32 pixels,
 // enough channels to fill 128-wide tiles.  One GEMM per tap, K (= pixels) split so that <= 512 workgroups run.
 struct X3WgradPlan { int ok; int splits; int chunks_per_split; long slab; };
-inline X3WgradPlan x3_wgrad_plan(int Cin, int N, int Cout, int H, int W, int OH, int OW, int KH, int KW, int stride, int pad) {
+inline X3WgradPlan x3_wgrad_plan(int C1, int C2, int N, int Cout, int H, int W, int OH, int OW, int KH, int KW, int stride,
+                                 int pad) {
   X3WgradPlan q = {0, 0, 0, 0};
+  const int Cin = C1 + C2;
   const long K = (long)N * H * W;
+  const int cmax = Cout > C1 ? (Cout > C2 ? Cout : C2) : (C1 > C2 ? C1 : C2);
+  if (K * cmax * 4 >= 0x7fffffffL || (C2 > 0 && C1 % 32)) return q;    // 32-bit buffer offsets; a wave's rows share a tensor
   const bool pow2 = (W & (W - 1)) == 0 && ((H * W) & (H * W - 1)) == 0;
   if (KH != 3 || KW != 3 || stride != 1 || pad != 1 || OH != H || OW != W || !pow2 || W < 8 || H * W < 32 ||
       Cin < 64 || Cout < 64 || K > 0x7fffffffL || K % 32)
@@ -936,7 +941,7 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
     if (w_layout == 0 && x3_ok(p, Cout, Cout, 0, Cin, Ng)) return 2;
     return use_big_tile(Cin, Ng, 1) && !(p.taps == 1 && w_layout == 1 && (Cout % 8)) ? 1 : 0;
   }
-  if (w_layout == 0 && x3_wgrad_plan(Cin, N, Cout, H, W, OH, OW, KH, KW, stride, pad).ok) return 2;
+  if (w_layout == 0 && x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad).ok) return 2;
   const bool can9 = stride == 1 && pad == 1 && C2 == 0 && OH == H && OW == W && w_layout == 0;
   const WgradPlan q = wgrad_plan(Cin, N, Cout, OH, OW, KH, KW, can9);
   return q.mode9 ? 3 : q.big;
@@ -957,7 +962,7 @@ long stk_conv2d_dgrad_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, in
 long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW) {
   const WgradPlan a = wgrad_plan(C1 + C2, N, Cout, OH, OW, KH, KW, true);
   const WgradPlan b = wgrad_plan(C1 + C2, N, Cout, OH, OW, KH, KW, false);
-  const X3WgradPlan x = x3_wgrad_plan(C1 + C2, N, Cout, OH, OW, OH, OW, KH, KW, 1, 1);
+  const X3WgradPlan x = x3_wgrad_plan(C1, C2, N, Cout, OH, OW, OH, OW, KH, KW, 1, 1);
   const long na = (long)a.splits * a.slab, nb = (long)b.splits * b.slab, nx = x.ok ? (long)x.splits * x.slab : 0;
   const long m = na > nb ? na : nb;
   return (m > nx ? m : nx) * 4 + 256;
@@ -973,7 +978,7 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
   int rc = fill_common(p, N, H, W, C1, C2, Cout, OH, OW, KH, KW, stride, pad);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const X3WgradPlan xq = x3_wgrad_plan(p.Cin, N, Cout, H, W, OH, OW, KH, KW, stride, pad);
+  const X3WgradPlan xq = x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad);
   if (xq.ok && w_layout == 0 && ws_bytes >= (long)xq.splits * xq.slab * 4) {
     p.x1 = x1; p.x2 = C2 > 0 ? x2 : x1; p.dy = dy; p.w_layout = w_layout; p.part = ws; p.part_stride = xq.slab;
     x3::Src q = {};

@@ -105,20 +105,35 @@ __device__ __forceinline__ void split_store16(const float (&r)[16], unsigned okm
 }
 
 // ---- loaders: init(p, q, tile origin, tid, zb) / load(p, q, chunk) / store(LDS operand tile) ------------------
+// All global reads are raw BUFFER loads: a wave-uniform resource (tensor base + size in SGPRs), one 32-bit
+// per-lane byte offset and a scalar offset per load, so a chunk's loads cost no per-load address VALU; and a read
+// outside the tensor returns 0 instead of faulting, which is how halo lanes are zeroed (offset bit 31 set) and why
+// a shifted 16-pixel run may start one element before / end one element after its tensor.
+// (Buffer offsets are 32-bit: the host side keeps these kernels to tensors below 2 GB.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
 // forward / dgrad A: prepared weights, six 16-byte pieces per chunk (split j>>1, row (tid>>2) + 64 (j&1), segment tid&3)
 struct WpLoader {
-  const unsigned short* base; long plane; int row, seg, cpt;
+  __amdgpu_buffer_rsrc_t rs; unsigned voff, plane2, half2; int row, seg, cpt;
   u32x4 r[6];
   __device__ __forceinline__ void init(const ConvP&, const Src& q, int m0, int tid, int) {
     row = tid >> 2; seg = tid & 3; cpt = q.Kc / KC;
-    plane = 9L * q.Mpad * q.Kc;
-    base = q.wp + ((long)(m0 + row) * q.Kc + seg * 8);
+    plane2 = 9u * q.Mpad * q.Kc * 2u;                   // bytes per split plane
+    half2 = 64u * q.Kc * 2u;                            // bytes between row r and row r + 64
+    rs = make_rsrc(q.wp, 3L * plane2);
+    voff = ((unsigned)(m0 + row) * q.Kc + seg * 8) * 2u;
   }
   __device__ __forceinline__ void load(const ConvP&, const Src& q, int c) {
     const int tap = c / cpt, cc = c - tap * cpt;                 // scalar
-    const unsigned short* s = base + ((long)tap * q.Mpad * q.Kc + cc * KC);
+    const unsigned so = ((unsigned)tap * q.Mpad * q.Kc + cc * KC) * 2u;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) r[j] = *reinterpret_cast<const u32x4*>(s + (j >> 1) * plane + (long)(j & 1) * 64 * q.Kc);
+    for (int j = 0; j < 6; ++j)
+      r[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)(so + (j >> 1) * plane2 + (j & 1) * half2), 0));
   }
   __device__ __forceinline__ void store(unsigned char* t) {
 #pragma unroll
@@ -129,13 +144,16 @@ struct WpLoader {
 // forward / dgrad B: activations, lanes along pixels; a thread holds 16 channels of one tap-shifted pixel
 template <bool DUAL>
 struct ActLoader {
-  int nl, kg, tb1, tb2, cpt; unsigned mask, bok;
+  __amdgpu_buffer_rsrc_t rs1, rs2;
+  int nl, kg, tb1, tb2, cpt; unsigned mask;
   float r[16];
   __device__ __forceinline__ void init(const ConvP& p, const Src& q, int n0, int tid, int) {
     nl = tid & 127;
     kg = __builtin_amdgcn_readfirstlane(tid >> 7);      // which 16 of the chunk's 32 channels
     cpt = q.Kc / KC;
-    mask = 0; tb1 = 0; tb2 = 0; bok = 0;
+    rs1 = make_rsrc(q.s1, (long)p.N * q.S1 * p.HW * 4);
+    rs2 = make_rsrc(q.s2, (long)p.N * (DUAL ? q.S2 : q.S1) * p.HW * 4);
+    mask = 0; tb1 = 0; tb2 = 0;
     const int n = n0 + nl;
     if (n < p.N * p.HW) {
       const int b = n / p.HW, hw = n - b * p.HW;
@@ -152,24 +170,27 @@ struct ActLoader {
   __device__ __forceinline__ void load(const ConvP& p, const Src& q, int c) {
     const int tap = c / cpt, cc = c - tap * cpt;                 // scalar
     const int ci0 = cc * KC + kg * 16;
-    const bool first = !DUAL || ci0 < q.S1;
-    const uintptr_t tensor = first ? (uintptr_t)q.s1 : (uintptr_t)q.s2;
-    const gfloat* plane = (const gfloat*)(tensor + (uintptr_t)(first ? ci0 : ci0 - q.S1) * (uintptr_t)p.HW * 4u);
-    bok = (mask >> tap) & 1u;
-    const int off = bok ? (first ? tb1 : tb2) + (tap / 3 - 1) * p.W + (tap % 3 - 1) : 0;
+    const bool first = !DUAL || ci0 < q.S1;                      // scalar: a chunk never straddles the two sources
+    const __amdgpu_buffer_rsrc_t rs = first ? rs1 : rs2;
+    const unsigned so = (unsigned)(first ? ci0 : ci0 - q.S1) * p.HW * 4u;
+    // halo / out-of-range lanes: offset bit 31 -> outside the buffer -> the load returns 0 (no select, no branch)
+    const unsigned dead = (((mask >> tap) & 1u) ^ 1u) << 31;
+    const unsigned vo = (unsigned)(((first ? tb1 : tb2) + (tap / 3 - 1) * p.W + (tap % 3 - 1)) * 4) | dead;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = (plane + (long)i * p.HW)[off];
+    for (int i = 0; i < 16; ++i) r[i] = bload(rs, vo, so + (unsigned)i * p.HW * 4u);
   }
-  __device__ __forceinline__ void store(unsigned char* t) { split_store16(r, bok ? 0xffffu : 0u, t, nl, kg * 16); }
+  __device__ __forceinline__ void store(unsigned char* t) { split_store16(r, 0xffffu, t, nl, kg * 16); }
 };
 
 // wgrad operands: rows = channels, k = pixels (contiguous in NCHW).  Thread (row = tid>>1, half = tid&1) holds the
 // 16 consecutive pixels k0 + 16*half .. +15 of its channel, shifted by the tap for the x operand.  Requires W a
-// power of two >= 8 and H*W a power of two >= 32, so a 16-pixel run is one row segment (W >= 16) or two rows (W = 8).
+// power of two >= 8 and H*W a power of two >= 32, so a 16-pixel run is one row segment (W >= 16) or two rows (W = 8);
+// with a concat input the first source must hold a multiple of 32 channels (a wave's 32 rows share one tensor).
 template <bool SHIFT, bool DUAL>
 struct RowsLoader {
-  const float* rowp;      // this thread's channel plane of image 0 (any valid plane when the row is out of range)
-  long bstride;           // elements between images in this thread's tensor
+  __amdgpu_buffer_rsrc_t rs;
+  int rowoff;             // element offset of this thread's channel plane inside image 0 of its tensor
+  int bstride;            // elements between images in this thread's tensor
   int row, half, dy, dx; bool rowok; unsigned okm;
   float r[16];
   __device__ __forceinline__ void init(const ConvP& p, const Src&, int o0, int tid, int zb) {
@@ -179,13 +200,15 @@ struct RowsLoader {
     if (SHIFT) {                                   // x: channel of the concat input
       rowok = ch < p.Cin;
       const int c = rowok ? ch : 0;
-      const bool first = !DUAL || c < p.C1;
-      rowp = (first ? p.x1 : p.x2) + (long)(first ? c : c - p.C1) * p.HW;
-      bstride = (long)(first ? p.C1 : p.C2) * p.HW;
+      const bool first = !DUAL || __builtin_amdgcn_readfirstlane(o0 + (tid >> 6) * 32) < p.C1;   // wave-uniform
+      rs = first ? make_rsrc(p.x1, (long)p.N * p.C1 * p.HW * 4) : make_rsrc(p.x2, (long)p.N * p.C2 * p.HW * 4);
+      rowoff = (first ? c : (c >= p.C1 ? c - p.C1 : 0)) * p.HW;
+      bstride = (first ? p.C1 : p.C2) * p.HW;
     } else {                                       // dy: output channel
       rowok = ch < p.Cout;
-      rowp = p.dy + (long)(rowok ? ch : 0) * p.HW;
-      bstride = (long)p.Cout * p.HW;
+      rs = make_rsrc(p.dy, (long)p.N * p.Cout * p.HW * 4);
+      rowoff = (rowok ? ch : 0) * p.HW;
+      bstride = p.Cout * p.HW;
     }
   }
   __device__ __forceinline__ void load(const ConvP& p, const Src&, int c) {
@@ -208,20 +231,23 @@ struct RowsLoader {
       if (dx > 0) m &= ~0x8080u;
     }
     okm = kin ? m : 0u;
-    // The run is contiguous in memory.  Masked elements must still be read from inside the tensor: the four
-    // possible edge elements and the two 6-element interiors each fall back to the start of the plane.
-    const long o = okm ? (long)b * bstride + hw + dy * p.W + dx : 0;
-    const float* s = rowp + o;
-    const float* s_lo = (okm & 0x007eu) ? s : rowp;
-    const float* s_hi = (okm & 0x7e00u) ? s : rowp;
+    // The run is contiguous in memory, but its element offsets may be negative where they are masked: column -1 of
+    // the first row of the tensor (element 0; element 8 when W = 8), or the whole first half when W = 8 and the row
+    // above the image is addressed.  A negative voffset plus an immediate is NOT wrapped back into the buffer by
+    // the range check, so the run is read as four pieces -- [0], [1..7], [8], [9..15] -- each from its own offset
+    // clamped at 0 (a clamped piece is entirely masked), immediates only inside a piece.  The offsets are made
+    // opaque because hipcc otherwise rewrites max(o + 1, 0) * 4 + imm as max(o, -1) * 4 + (imm + 4), i.e. back into
+    // the negative-base form.  A run that ends past the tensor reads 0 there (range check).
+    const int o = (kin ? b * bstride + rowoff + hw : 0) + dy * p.W + dx;
+    unsigned o0 = (unsigned)(max(o, 0) * 4), o1 = (unsigned)(max(o + 1, 0) * 4);
+    unsigned o8 = (unsigned)(max(o + 8, 0) * 4), o9 = (unsigned)(max(o + 9, 0) * 4);
+    asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o8), "+v"(o9));
+    r[0] = bload(rs, o0, 0);
+    r[8] = bload(rs, o8, 0);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (j == 0 || j == 7 || j == 8 || j == 15) {
-        const float* e = ((okm >> j) & 1u) ? s : rowp;
-        r[j] = e[j];
-      } else {
-        r[j] = (j < 8 ? s_lo : s_hi)[j];
-      }
+    for (int j = 1; j < 8; ++j) {
+      r[j] = bload(rs, o1 + (unsigned)(j - 1) * 4u, 0);
+      r[j + 8] = bload(rs, o9 + (unsigned)(j - 1) * 4u, 0);
     }
   }
   __device__ __forceinline__ void store(unsigned char* t) { split_store16(r, okm, t, row, half * 16); }
