@@ -766,10 +766,10 @@ int launch_x3(const ConvP& p, const float* s1, int S1, const float* s2, int S2, 
   STK_CHECK_LAUNCH();
   const int tm = q.Mpad / 128, tn = stk_cdiv((int)Ng, 128), nch = 9 * (q.Kc / x3::KC);
   if (S2 > 0)
-    hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<true>, EP>), dim3((unsigned)(tm * tn)), dim3(256), 0, s,
+    hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<true>, EP, true>), dim3((unsigned)(tm * tn)), dim3(256), 0, s,
                        p, q, M, (int)Ng, tm, tn, nch, nch, 0);
   else
-    hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<false>, EP>), dim3((unsigned)(tm * tn)), dim3(256), 0, s,
+    hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<false>, EP, true>), dim3((unsigned)(tm * tn)), dim3(256), 0, s,
                        p, q, M, (int)Ng, tm, tn, nch, nch, 0);
   STK_CHECK_LAUNCH();
   return STK_OK;
@@ -986,10 +986,10 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
     const int nch = (int)((long)N * p.HW / 32);
     const dim3 grid((unsigned)(9 * tm * tn * xq.splits));
     if (C2 > 0)
-      hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false>, x3::RowsLoader<true, true>, EpWgrad>), grid, dim3(256),
+      hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false>, x3::RowsLoader<true, true>, EpWgrad, false>), grid, dim3(256),
                          0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, 9);
     else
-      hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false>, x3::RowsLoader<true, false>, EpWgrad>), grid, dim3(256),
+      hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false>, x3::RowsLoader<true, false>, EpWgrad, false>), grid, dim3(256),
                          0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, 9);
     STK_CHECK_LAUNCH();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid(xq.slab)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,

@@ -83,26 +83,33 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w,
   }
 }
 
-// Split 16 fp32 values (invalid ones zeroed by mask bit) into three bf16 planes and write them as 16 consecutive
-// k of LDS row `row` at k offset `k0` (0 or 16):  2 x ds_write_b128 per plane.
-__device__ __forceinline__ void split_store16(const float (&r)[16], unsigned okm, unsigned char* tile, int row, int k0) {
+// Staging is cut into 24 slices so that the kernel can place one slice after each MFMA of a 24-MFMA group (the
+// hipcc scheduler, left alone, runs the whole staging phase first and the MFMAs after it).  A loader provides
+//     st(g, tile)        slice g of "registers of the current chunk -> LDS"
+//     ld(g, p, q, c)     slice g of "global -> registers for chunk c"
+// and st(g) of a chunk always precedes ld(g) of the next one, so a register is reloaded only after its slice
+// consumed it.
+//
+// Splitter shared by the converting loaders: 16 fp32 values of one LDS row (16 consecutive k at k offset k0) ->
+// three bf16 planes.  Slices 0..7 convert one pair each (invalid elements zeroed by mask bit), slices 8..13 write
+// one 16-byte piece each (2 x ds_write_b128 per plane).
+struct Split16 {
   unsigned pk[3][8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const float v0 = igemm::keep_if(r[2 * u], okm, 2 * u), v1 = igemm::keep_if(r[2 * u + 1], okm, 2 * u + 1);
-    const float r0 = v0 - hi_part(v0), r1 = v1 - hi_part(v1);
-    const float t0 = r0 - hi_part(r0), t1 = r1 - hi_part(r1);
-    pk[0][u] = pack_hi(v0, v1);
-    pk[1][u] = pack_hi(r0, r1);
-    pk[2][u] = pack_hi(t0, t1);
+  __device__ __forceinline__ void st(int g, const float (&r)[16], unsigned okm, unsigned char* tile, int row, int k0) {
+    if (g < 8) {
+      const float v0 = igemm::keep_if(r[2 * g], okm, 2 * g), v1 = igemm::keep_if(r[2 * g + 1], okm, 2 * g + 1);
+      const float r0 = v0 - hi_part(v0), r1 = v1 - hi_part(v1);
+      const float t0 = r0 - hi_part(r0), t1 = r1 - hi_part(r1);
+      pk[0][g] = pack_hi(v0, v1);
+      pk[1][g] = pack_hi(r0, r1);
+      pk[2][g] = pack_hi(t0, t1);
+    } else if (g < 14) {
+      const int s = (g - 8) >> 1, h = (g - 8) & 1;
+      *reinterpret_cast<u32x4*>(tile + s * PLANE + row * PITCH + k0 * 2 + h * 16) =
+          u32x4{pk[s][4 * h], pk[s][4 * h + 1], pk[s][4 * h + 2], pk[s][4 * h + 3]};
+    }
   }
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    unsigned char* d = tile + s * PLANE + row * PITCH + k0 * 2;
-    *reinterpret_cast<u32x4*>(d) = u32x4{pk[s][0], pk[s][1], pk[s][2], pk[s][3]};
-    *reinterpret_cast<u32x4*>(d + 16) = u32x4{pk[s][4], pk[s][5], pk[s][6], pk[s][7]};
-  }
-}
+};
 
 // ---- loaders: init(p, q, tile origin, tid, zb) / load(p, q, chunk) / store(LDS operand tile) ------------------
 // All global reads are raw BUFFER loads: a wave-uniform resource (tensor base + size in SGPRs), one 32-bit
@@ -128,16 +135,14 @@ struct WpLoader {
     rs = make_rsrc(q.wp, 3L * plane2);
     voff = ((unsigned)(m0 + row) * q.Kc + seg * 8) * 2u;
   }
-  __device__ __forceinline__ void load(const ConvP&, const Src& q, int c) {
+  __device__ __forceinline__ void ld(int g, const ConvP&, const Src& q, int c) {
+    if (g >= 6) return;
     const int tap = c / cpt, cc = c - tap * cpt;                 // scalar
     const unsigned so = ((unsigned)tap * q.Mpad * q.Kc + cc * KC) * 2u;
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      r[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)(so + (j >> 1) * plane2 + (j & 1) * half2), 0));
+    r[g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)(so + (g >> 1) * plane2 + (g & 1) * half2), 0));
   }
-  __device__ __forceinline__ void store(unsigned char* t) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4*>(t + (j >> 1) * PLANE + (row + 64 * (j & 1)) * PITCH + seg * 16) = r[j];
+  __device__ __forceinline__ void st(int g, unsigned char* t) {
+    if (g < 6) *reinterpret_cast<u32x4*>(t + (g >> 1) * PLANE + (row + 64 * (g & 1)) * PITCH + seg * 16) = r[g];
   }
 };
 
@@ -146,7 +151,7 @@ template <bool DUAL>
 struct ActLoader {
   __amdgpu_buffer_rsrc_t rs1, rs2;
   int nl, kg, tb1, tb2, cpt; unsigned mask;
-  float r[16];
+  float r[16]; Split16 sp;
   __device__ __forceinline__ void init(const ConvP& p, const Src& q, int n0, int tid, int) {
     nl = tid & 127;
     kg = __builtin_amdgcn_readfirstlane(tid >> 7);      // which 16 of the chunk's 32 channels
@@ -167,7 +172,9 @@ struct ActLoader {
       tb2 = b * q.S2 * p.HW + hw;
     }
   }
-  __device__ __forceinline__ void load(const ConvP& p, const Src& q, int c) {
+  // slices 8..23 load one channel each (its register was consumed by conversion slice (g - 8) / 2 <= 7)
+  __device__ __forceinline__ void ld(int g, const ConvP& p, const Src& q, int c) {
+    if (g < 8) return;
     const int tap = c / cpt, cc = c - tap * cpt;                 // scalar
     const int ci0 = cc * KC + kg * 16;
     const bool first = !DUAL || ci0 < q.S1;                      // scalar: a chunk never straddles the two sources
@@ -176,10 +183,9 @@ struct ActLoader {
     // halo / out-of-range lanes: offset bit 31 -> outside the buffer -> the load returns 0 (no select, no branch)
     const unsigned dead = (((mask >> tap) & 1u) ^ 1u) << 31;
     const unsigned vo = (unsigned)(((first ? tb1 : tb2) + (tap / 3 - 1) * p.W + (tap % 3 - 1)) * 4) | dead;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = bload(rs, vo, so + (unsigned)i * p.HW * 4u);
+    r[g - 8] = bload(rs, vo, so + (unsigned)(g - 8) * p.HW * 4u);
   }
-  __device__ __forceinline__ void store(unsigned char* t) { split_store16(r, 0xffffu, t, nl, kg * 16); }
+  __device__ __forceinline__ void st(int g, unsigned char* t) { sp.st(g, r, 0xffffu, t, nl, kg * 16); }
 };
 
 // wgrad operands: rows = channels, k = pixels (contiguous in NCHW).  Thread (row = tid>>1, half = tid&1) holds the
@@ -192,7 +198,7 @@ struct RowsLoader {
   int rowoff;             // element offset of this thread's channel plane inside image 0 of its tensor
   int bstride;            // elements between images in this thread's tensor
   int row, half, dy, dx; bool rowok; unsigned okm;
-  float r[16];
+  float r[16]; Split16 sp;
   __device__ __forceinline__ void init(const ConvP& p, const Src&, int o0, int tid, int zb) {
     row = tid >> 1; half = tid & 1; okm = 0;
     dy = SHIFT ? zb / 3 - 1 : 0; dx = SHIFT ? zb % 3 - 1 : 0;
@@ -211,52 +217,65 @@ struct RowsLoader {
       bstride = p.Cout * p.HW;
     }
   }
-  __device__ __forceinline__ void load(const ConvP& p, const Src&, int c) {
-    const int k = c * KC + half * 16;              // first pixel of the run (global pixel index)
-    const bool kin = rowok && k < p.N * p.HW;      // N*H*W is a multiple of 16: a run is inside or outside as a whole
-    const int b = k >> p.ohw_shift, hw = k & (p.HW - 1);
-    const int y = hw >> p.ow_shift, x0 = hw & (p.W - 1);
-    unsigned m = 0;
-    if (!SHIFT) {
-      m = 0xffffu;
-    } else if (p.W >= 16) {                        // one row segment
-      const bool yok = (unsigned)(y + dy) < (unsigned)p.H;
-      m = yok ? 0xffffu : 0u;
-      if (dx < 0 && x0 == 0) m &= ~1u;
-      if (dx > 0 && x0 + 16 == p.W) m &= ~0x8000u;
-    } else {                                       // W == 8: two full rows
-      const bool y0 = (unsigned)(y + dy) < (unsigned)p.H, y1 = (unsigned)(y + 1 + dy) < (unsigned)p.H;
-      m = (y0 ? 0x00ffu : 0u) | (y1 ? 0xff00u : 0u);
-      if (dx < 0) m &= ~0x0101u;
-      if (dx > 0) m &= ~0x8080u;
-    }
-    okm = kin ? m : 0u;
-    // The run is contiguous in memory, but its element offsets may be negative where they are masked: column -1 of
-    // the first row of the tensor (element 0; element 8 when W = 8), or the whole first half when W = 8 and the row
-    // above the image is addressed.  A negative voffset plus an immediate is NOT wrapped back into the buffer by
-    // the range check, so the run is read as four pieces -- [0], [1..7], [8], [9..15] -- each from its own offset
-    // clamped at 0 (a clamped piece is entirely masked), immediates only inside a piece.  The offsets are made
-    // opaque because hipcc otherwise rewrites max(o + 1, 0) * 4 + imm as max(o, -1) * 4 + (imm + 4), i.e. back into
-    // the negative-base form.  A run that ends past the tensor reads 0 there (range check).
-    const int o = (kin ? b * bstride + rowoff + hw : 0) + dy * p.W + dx;
-    unsigned o0 = (unsigned)(max(o, 0) * 4), o1 = (unsigned)(max(o + 1, 0) * 4);
-    unsigned o8 = (unsigned)(max(o + 8, 0) * 4), o9 = (unsigned)(max(o + 9, 0) * 4);
-    asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o8), "+v"(o9));
-    r[0] = bload(rs, o0, 0);
-    r[8] = bload(rs, o8, 0);
+  // slice 14 computes the next run's mask and offsets, slices 15..19 issue its loads (all 16 registers were
+  // consumed by the conversion slices 0..7); the mask in use by those slices is replaced at slice 14.
+  unsigned o0, o1, o8, o9;
+  __device__ __forceinline__ void ld(int g, const ConvP& p, const Src&, int c) {
+    if (g == 14) {
+      const int k = c * KC + half * 16;              // first pixel of the run (global pixel index)
+      const bool kin = rowok && k < p.N * p.HW;      // N*H*W is a multiple of 16: a run is inside or outside as a whole
+      const int b = k >> p.ohw_shift, hw = k & (p.HW - 1);
+      const int y = hw >> p.ow_shift, x0 = hw & (p.W - 1);
+      unsigned m = 0;
+      if (!SHIFT) {
+        m = 0xffffu;
+      } else if (p.W >= 16) {                        // one row segment
+        const bool yok = (unsigned)(y + dy) < (unsigned)p.H;
+        m = yok ? 0xffffu : 0u;
+        if (dx < 0 && x0 == 0) m &= ~1u;
+        if (dx > 0 && x0 + 16 == p.W) m &= ~0x8000u;
+      } else {                                       // W == 8: two full rows
+        const bool y0 = (unsigned)(y + dy) < (unsigned)p.H, y1 = (unsigned)(y + 1 + dy) < (unsigned)p.H;
+        m = (y0 ? 0x00ffu : 0u) | (y1 ? 0xff00u : 0u);
+        if (dx < 0) m &= ~0x0101u;
+        if (dx > 0) m &= ~0x8080u;
+      }
+      okm = kin ? m : 0u;
+      // The run is contiguous in memory, but its element offsets may be negative where they are masked: column -1
+      // of the first row of the tensor (element 0; element 8 when W = 8), or the whole first half when W = 8 and
+      // the row above the image is addressed.  A negative voffset plus an immediate is NOT wrapped back into the
+      // buffer by the range check, so the run is read as four pieces -- [0], [1..7], [8], [9..15] -- each from its
+      // own offset clamped at 0 (a clamped piece is entirely masked), immediates only inside a piece.  The offsets
+      // are made opaque because hipcc otherwise rewrites max(o + 1, 0) * 4 + imm as max(o, -1) * 4 + (imm + 4),
+      // i.e. back into the negative-base form.  A run that ends past the tensor reads 0 there (range check).
+      const int o = (kin ? b * bstride + rowoff + hw : 0) + dy * p.W + dx;
+      o0 = (unsigned)(max(o, 0) * 4); o1 = (unsigned)(max(o + 1, 0) * 4);
+      o8 = (unsigned)(max(o + 8, 0) * 4); o9 = (unsigned)(max(o + 9, 0) * 4);
+      asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o8), "+v"(o9));
+    } else if (g == 15) {
+      r[0] = bload(rs, o0, 0);
+      r[8] = bload(rs, o8, 0);
+    } else if (g == 16) {
 #pragma unroll
-    for (int j = 1; j < 8; ++j) {
-      r[j] = bload(rs, o1 + (unsigned)(j - 1) * 4u, 0);
-      r[j + 8] = bload(rs, o9 + (unsigned)(j - 1) * 4u, 0);
+      for (int j = 1; j < 5; ++j) r[j] = bload(rs, o1 + (unsigned)(j - 1) * 4u, 0);
+    } else if (g == 17) {
+#pragma unroll
+      for (int j = 5; j < 8; ++j) r[j] = bload(rs, o1 + (unsigned)(j - 1) * 4u, 0);
+    } else if (g == 18) {
+#pragma unroll
+      for (int j = 9; j < 13; ++j) r[j] = bload(rs, o9 + (unsigned)(j - 9) * 4u, 0);
+    } else if (g == 19) {
+#pragma unroll
+      for (int j = 13; j < 16; ++j) r[j] = bload(rs, o9 + (unsigned)(j - 9) * 4u, 0);
     }
   }
-  __device__ __forceinline__ void store(unsigned char* t) { split_store16(r, okm, t, row, half * 16); }
+  __device__ __forceinline__ void st(int g, unsigned char* t) { sp.st(g, r, okm, t, row, half * 16); }
 };
 
 // ---- the kernel: out tile 128 x 128, 4 waves of 64 x 64, chunks of 32 k ---------------------------------------
 // Grid: tiles (XCD-remapped);  with taps_z > 0 (wgrad) one flat dimension of taps x tiles x splits, tap fastest so
 // that the nine blocks reading the same dy / x panels are neighbours on one XCD's L2.
-template <class AL, class BL, class EP>
+template <class AL, class BL, class EP, bool HAND>
 __global__ __launch_bounds__(256) void gemm_kernel(ConvP p, Src q, int M, int Nn, int tiles_m, int tiles_n,
                                                    int nchunks_total, int chunks_per_split, int taps_z) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
@@ -300,51 +319,77 @@ __global__ __launch_bounds__(256) void gemm_kernel(ConvP p, Src q, int M, int Nn
 
   // Pipeline (LDS single-buffered, two barriers per chunk):
   //   B1: chunk c is in LDS          -> read the kk = 0 fragments, 24 MFMAs, read the kk = 1 fragments
-  //   B2: nobody reads LDS any more  -> 24 MFMAs of kk = 1 INTERLEAVED with the split + LDS write of chunk c + 1
-  //                                     (whose global loads were issued one full iteration earlier), then the
-  //                                     global loads of chunk c + 2 are issued.
-  // So the conversion VALU and the LDS stores run in the shadow of the matrix pipe of the same wave, and a global
-  // load has a whole chunk period (~3k cycles) to land.
+  //   B2: nobody reads LDS any more  -> 24 MFMAs of kk = 1, each followed by ONE SLICE of the staging of chunk c + 1
+  //                                     (split + LDS write; its global loads were issued one iteration earlier) and
+  //                                     of the global loads of chunk c + 2, pinned in place by sched_barrier.
+  // So the conversion VALU, the LDS stores and the load issue run in the shadow of the matrix pipe of the same wave
+  // (~6 other instructions fit in the 32 cycles of one MFMA), and a global load has a whole chunk period to land.
 #define STK_X3_FRAGS(KK)                                                                               \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s = 0; s < 3; ++s) {         \
     a[i][s] = *reinterpret_cast<const bf16x8*>(a_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);          \
     b[i][s] = *reinterpret_cast<const bf16x8*>(b_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);          \
   }
   // six products per tile, smallest terms first; the four tiles interleave so that consecutive MFMAs never
-  // wait on the same accumulator
-#define STK_X3_PROD(SA, SB)                                                                             \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][SA], b[j][SB], acc[i][j], 0, 0, 0);
-#define STK_X3_MFMAS STK_X3_PROD(2, 0) STK_X3_PROD(1, 1) STK_X3_PROD(0, 2) STK_X3_PROD(1, 0) STK_X3_PROD(0, 1) STK_X3_PROD(0, 0)
-  al.load(p, q, c_begin); bl.load(p, q, c_begin);
-  al.store(As); bl.store(Bs);
-  al.load(p, q, min(c_begin + 1, c_last)); bl.load(p, q, min(c_begin + 1, c_last));
+  // wait on the same accumulator.  MFMA g of a group: product g / 4, tile (g / 2) & 1, g & 1.
+  constexpr int SA[6] = {2, 1, 0, 1, 0, 0}, SB[6] = {0, 1, 2, 0, 1, 0};
+#define STK_X3_MFMA(G)                                                                                                \
+  acc[((G) >> 1) & 1][(G) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[((G) >> 1) & 1][SA[(G) >> 2]], b[(G) & 1][SB[(G) >> 2]], \
+                                                                         acc[((G) >> 1) & 1][(G) & 1], 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 24; ++g) { al.ld(g, p, q, c_begin); bl.ld(g, p, q, c_begin); }
+  {
+    const int c1 = min(c_begin + 1, c_last);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) { al.st(g, As); bl.st(g, Bs); al.ld(g, p, q, c1); bl.ld(g, p, q, c1); }
+  }
   bf16x8 a[2][3], b[2][3];
   for (int c = c_begin; c < c_last; ++c) {
     __syncthreads();                                   // B1
     STK_X3_FRAGS(0)
-    STK_X3_MFMAS
+#pragma unroll
+    for (int g = 0; g < 24; ++g) { STK_X3_MFMA(g) }
     STK_X3_FRAGS(1)
     __syncthreads();                                   // B2
-    STK_X3_MFMAS
-    al.store(As); bl.store(Bs);                        // chunk c + 1
-    al.load(p, q, min(c + 2, c_last)); bl.load(p, q, min(c + 2, c_last));   // (the last iteration re-loads: harmless)
-    // one MFMA, then a slice of the staging work (VALU, LDS writes, global loads) over the 24 MFMAs
+    const int c2 = min(c + 2, c_last);                 // (the last iteration re-loads the last chunk: harmless)
+    if (HAND) {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < 24; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // VALU
-      if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+      for (int g = 0; g < 24; ++g) {
+        STK_X3_MFMA(g)
+        al.st(g, As); bl.st(g, Bs);                    // chunk c + 1: registers -> LDS
+        al.ld(g, p, q, c2); bl.ld(g, p, q, c2);        // chunk c + 2: global -> registers
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // Two converting loaders (weight gradient): ~26 VALU per slice do not fit behind one MFMA; pinning them there
+      // measured 20-25% slower than handing the scheduler the whole phase with a coarse pipeline hint.
+#pragma unroll
+      for (int g = 0; g < 24; ++g) { STK_X3_MFMA(g) }
+#pragma unroll
+      for (int g = 0; g < 24; ++g) al.st(g, As);
+#pragma unroll
+      for (int g = 0; g < 24; ++g) bl.st(g, Bs);
+#pragma unroll
+      for (int g = 0; g < 24; ++g) al.ld(g, p, q, c2);
+#pragma unroll
+      for (int g = 0; g < 24; ++g) bl.ld(g, p, q, c2);
+#pragma unroll
+      for (int g = 0; g < 24; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // VALU
+        if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+      }
     }
   }
   __syncthreads();
   STK_X3_FRAGS(0)
-  STK_X3_MFMAS
+#pragma unroll
+  for (int g = 0; g < 24; ++g) { STK_X3_MFMA(g) }
   STK_X3_FRAGS(1)
-  STK_X3_MFMAS
-#undef STK_X3_MFMAS
-#undef STK_X3_PROD
+#pragma unroll
+  for (int g = 0; g < 24; ++g) { STK_X3_MFMA(g) }
+#undef STK_X3_MFMA
 #undef STK_X3_FRAGS
 
   EP ep;
