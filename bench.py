@@ -39,6 +39,30 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md dense bf16 MFMA peak
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
+# rocprofv3 symbol of the kernel behind a profiler label (for the committed PMC summary, see traffic_of)
+KERNEL_SYMBOL = {
+  'conv3x3.wgrad.x3': 'gemm_kernel<RowsLoader<false, false>, RowsLoader<true, false>, EpWgrad, false>',
+  'conv3x3.fwd.x3': 'gemm_kernel<WpLoader, ActLoader<false>, EpFwd, true>',
+  'conv3x3.dgrad.x3': 'gemm_kernel<WpLoader, ActLoader<false>, EpDgrad, true>',
+}
+
+
+def traffic_of(kind):
+  """HBM-side bytes per launch of the kernel behind `kind`, from the newest committed PMC summary
+  (profiles/rNN_traffic.json, written by tools/profile_round.sh + tools/profile_summary.py: separate rocprofv3
+  --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled per the gfx950 note of
+  MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process, hence the file."""
+  import glob
+  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
+  sym = KERNEL_SYMBOL.get(kind)
+  if not files or sym is None:
+    return None, None
+  rec = json.load(open(files[-1])).get(sym)
+  if rec is None:
+    return None, None
+  return (rec['fetch_MB'] + rec['write_MB']) * 1e6, os.path.relpath(files[-1], ROOT)
+
+
 def kernel_peak(kind):
   return PEAK_X3_TFLOPS if kind.endswith('.x3') else PEAK_F32_MFMA_TFLOPS
 TRAIN_FLOPS_PER_IMG = {'cifar10_ddpmpp_nll_st': 65.072e9, 'imagenet32_ddpmpp_st': 65.072e9,
@@ -186,8 +210,10 @@ def main():
       if summ:
         dom = max(summ, key=lambda k: summ[k]['total_ms'])
         a = summ[dom]
+        traffic, traffic_src = traffic_of(dom)
         out['roofline'] = {'bound': 'mfma', 'achieved': a['tflops'], 'peak': kernel_peak(dom), 'unit': 'TFLOP/s',
-                           'frac': a['tflops'] / kernel_peak(dom), 'traffic': None, 'kernel': dom,
+                           'frac': a['tflops'] / kernel_peak(dom), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
+                           'traffic_source': traffic_src, 'kernel': dom,
                            'peak_note': ('bf16 MFMA dense peak / 6 products per fp32 product' if dom.endswith('.x3')
                                          else 'f32-input MFMA peak'),
                            'avg_us': a['avg_us'], 'launches': a['count'], 'flops_per_launch': a['flops_per_launch'],

@@ -12,11 +12,13 @@
 // GEMM view (both directions share the kernel):   out[m, n] = sum_k  Wp[m, k] * act[k, n]
 //     forward  m = co, n = (b, y, x), k = (tap, ci):   act = x[b, ci, y + kh - 1, x + kw - 1]
 //     dgrad    m = ci, n = (b, y, x), k = (tap', co):  act = dy[b, co, y + kh' - 1, x + kw' - 1], tap' = 8 - tap
-// K is ordered TAP-MAJOR so that a 32-wide k chunk is one tap and 32 consecutive channels: the tap (hence the
-// halo test and the pixel shift) is uniform over the chunk and a thread's 16 loads differ only by a scalar
-// channel-plane offset.
+// K is ordered (32-channel group, tap, channel in group): a 32-wide k chunk is one tap and 32 consecutive channels,
+// so the tap (hence the halo test and the pixel shift) is uniform over the chunk and a thread's 16 loads differ only
+// by a scalar channel-plane offset; and the nine chunks of a channel group follow each other, so the nine shifted
+// reads of the same 32 x (128 + halo) activation patch hit L1 / L2 (with the taps outermost they were 9 sweeps over
+// all channels and measured 3-6x the algorithmic bytes at the memory side).
 //
-//   * weights are re-laid out and split ONCE per call by wprep_kernel into Wp[split][tap][row (padded to 128)][k]
+//   * weights are re-laid out and split ONCE per call by wprep_kernel into Wp[split][k / 32][tap][row (padded to 128)][k % 32]
 //     bf16 (<= 14 MB, L2 resident): the A loader is six 16-byte copies per thread and chunk, no conversion;
 //   * activations are split in the B loader when they are written to LDS (and/sub/perm, ~6 VALU per element);
 //   * LDS tiles are [split][row][32 k] bf16 with an 80-byte row pitch: the MFMA operand reads (one ds_read_b128
@@ -52,15 +54,19 @@ __device__ __forceinline__ unsigned pack_hi(float lo, float hi) {
   return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
 }
 
-// Wp[split][tap][row][k] = split_s( transpose ? w[(k*Cin + row)*9 + 8 - tap] : w[(row*Cin + k)*9 + tap] ),
-// rows >= the real row count are zero.  One thread per (row, k): reads its 9 taps (36 contiguous bytes).
+// Wp[split][k / 32][tap][row][k % 32] = split_s( transpose ? w[(k*Cin + row)*9 + 8 - tap] : w[(row*Cin + k)*9 + tap] ),
+// rows >= the real row count are zero: one (channel group, tap) is a dense [Mpad][32] bf16 block, i.e. the A tile of
+// one chunk is 8 KB of consecutive memory per plane.  One thread per (row, k): reads its 9 taps (36 contiguous bytes).
 __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                                     int Cout, int Cin, int Mpad, int transpose) {
   const int Kd = transpose ? Cout : Cin, R = transpose ? Cin : Cout;
   const long total = (long)Mpad * Kd;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int row = (int)(i / Kd), k = (int)(i - (long)row * Kd);
+  // k fastest inside a group of 32 so that the 2-byte stores of a wave are contiguous
+  const int kl = (int)(i & 31);
+  const long rest = i >> 5;
+  const int row = (int)(rest % Mpad), cc = (int)(rest / Mpad), k = cc * 32 + kl;
   float v[9];
   if (row < R) {
     const float* s = w + (transpose ? ((long)k * Cin + row) : ((long)row * Cin + k)) * 9;
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w,
     const float a = v[transpose ? 8 - t : t];
     const float h0 = hi_part(a), r1 = a - h0;
     const float h1 = hi_part(r1), h2 = r1 - h1;           // h2 has <= 8 significant bits: exact in bf16
-    const long o = ((long)t * Mpad + row) * Kd + k;
+    const long o = (((long)cc * 9 + t) * Mpad + row) * 32 + kl;
     out[o] = (unsigned short)(__float_as_uint(h0) >> 16);
     out[plane + o] = (unsigned short)(__float_as_uint(h1) >> 16);
     out[2 * plane + o] = (unsigned short)(__float_as_uint(h2) >> 16);
@@ -126,20 +132,19 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 
 // forward / dgrad A: prepared weights, six 16-byte pieces per chunk (split j>>1, row (tid>>2) + 64 (j&1), segment tid&3)
 struct WpLoader {
-  __amdgpu_buffer_rsrc_t rs; unsigned voff, plane2, half2; int row, seg, cpt;
+  __amdgpu_buffer_rsrc_t rs; unsigned voff, plane2, chunk2; int row, seg;
   u32x4 r[6];
   __device__ __forceinline__ void init(const ConvP&, const Src& q, int m0, int tid, int) {
-    row = tid >> 2; seg = tid & 3; cpt = q.Kc / KC;
+    row = tid >> 2; seg = tid & 3;
     plane2 = 9u * q.Mpad * q.Kc * 2u;                   // bytes per split plane
-    half2 = 64u * q.Kc * 2u;                            // bytes between row r and row r + 64
+    chunk2 = (unsigned)q.Mpad * KC * 2u;                // bytes per (channel group, tap) block = per chunk
     rs = make_rsrc(q.wp, 3L * plane2);
-    voff = ((unsigned)(m0 + row) * q.Kc + seg * 8) * 2u;
+    voff = ((unsigned)(m0 + row) * KC + seg * 8) * 2u;
   }
-  __device__ __forceinline__ void ld(int g, const ConvP&, const Src& q, int c) {
+  __device__ __forceinline__ void ld(int g, const ConvP&, const Src&, int c) {
     if (g >= 6) return;
-    const int tap = c / cpt, cc = c - tap * cpt;                 // scalar
-    const unsigned so = ((unsigned)tap * q.Mpad * q.Kc + cc * KC) * 2u;
-    r[g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)(so + (g >> 1) * plane2 + (g & 1) * half2), 0));
+    r[g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                         rs, (int)voff, (int)((unsigned)c * chunk2 + (g >> 1) * plane2 + (g & 1) * 64u * KC * 2u), 0));
   }
   __device__ __forceinline__ void st(int g, unsigned char* t) {
     if (g < 6) *reinterpret_cast<u32x4*>(t + (g >> 1) * PLANE + (row + 64 * (g & 1)) * PITCH + seg * 16) = r[g];
@@ -150,12 +155,11 @@ struct WpLoader {
 template <bool DUAL>
 struct ActLoader {
   __amdgpu_buffer_rsrc_t rs1, rs2;
-  int nl, kg, tb1, tb2, cpt; unsigned mask;
+  int nl, kg, tb1, tb2; unsigned mask;
   float r[16]; Split16 sp;
   __device__ __forceinline__ void init(const ConvP& p, const Src& q, int n0, int tid, int) {
     nl = tid & 127;
     kg = __builtin_amdgcn_readfirstlane(tid >> 7);      // which 16 of the chunk's 32 channels
-    cpt = q.Kc / KC;
     rs1 = make_rsrc(q.s1, (long)p.N * q.S1 * p.HW * 4);
     rs2 = make_rsrc(q.s2, (long)p.N * (DUAL ? q.S2 : q.S1) * p.HW * 4);
     mask = 0; tb1 = 0; tb2 = 0;
@@ -175,7 +179,7 @@ struct ActLoader {
   // slices 8..23 load one channel each (its register was consumed by conversion slice (g - 8) / 2 <= 7)
   __device__ __forceinline__ void ld(int g, const ConvP& p, const Src& q, int c) {
     if (g < 8) return;
-    const int tap = c / cpt, cc = c - tap * cpt;                 // scalar
+    const int cc = c / 9, tap = c - cc * 9;                      // scalar: chunk = (32-channel group, tap), tap fastest
     const int ci0 = cc * KC + kg * 16;
     const bool first = !DUAL || ci0 < q.S1;                      // scalar: a chunk never straddles the two sources
     const __amdgpu_buffer_rsrc_t rs = first ? rs1 : rs2;

@@ -362,8 +362,11 @@ def test_conv_adjoint_full_size(hip_lib):
   a = (y.double() * g.double()).sum().item()
   b = (x.double() * dx.double()).sum().item()
   c = (w.double() * dw.double()).sum().item()
-  tol = 2e-5 * max(abs(a), 1.0)
-  assert abs(a - b) <= tol and abs(a - c) <= tol, (a, b, c)
+  # The three inner products cancel heavily (16.7 M terms of either sign sum to a few hundred), so the tolerance is
+  # set against the sum of |terms|: each term carries ~1e-6 relative error, random in sign -> ~1e-9 of that sum;
+  # 1e-8 leaves a decade of margin and is still ~1e5 times smaller than what a dropped tap or tile would change.
+  tol = 1e-8 * (y.double().abs() * g.double().abs()).sum().item()
+  assert abs(a - b) <= tol and abs(a - c) <= tol, (a, b, c, tol)
 
 
 # ---------------------------------------------------------------------------------------------------
