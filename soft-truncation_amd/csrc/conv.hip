@@ -743,40 +743,47 @@ inline int fill_common(ConvP& p, int N, int H, int W, int C1, int C2, int Cout, 
   return STK_OK;
 }
 
-// The bf16 three-way-split kernel (conv_x3.h) takes 3x3 / stride 1 / pad 1 layers whose channel count is a multiple
-// of the 32-wide k chunk (and, for a concat input, whose first source is too) when there are at least 192 tiles of
-// 128 x 128 (measured: with 128 tiles -- 8x8 maps at batch 128 -- one workgroup per CU has nothing to overlap with
-// and the 64 x 64 f32-input kernel is faster).
+// The bf16 three-way-split kernel (conv_x3.h) takes 3x3 / stride 1 / pad 1 and 1x1 / stride 1 layers whose channel
+// count is a multiple of the 32-wide k chunk (and, for a concat input, whose first source is too) when there are at
+// least 192 tiles of 128 x 128 (measured: with 128 tiles -- 8x8 maps at batch 128 -- one workgroup per CU has nothing
+// to overlap with and the 64 x 64 f32-input kernel is faster).
 inline bool x3_ok(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
   const long big = (long)p.N * p.HW * 4 * (S1 > S2 ? S1 : S2);       // buffer loads: 32-bit byte offsets, bit 31 = dead lane
-  return big < 0x7fffffffL && p.taps == 9 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W && Kc % 32 == 0 &&
+  const bool geom = (p.taps == 9 && p.pad == 1) || (p.taps == 1 && p.pad == 0);
+  return big < 0x7fffffffL && geom && p.stride == 1 && p.OH == p.H && p.OW == p.W && Kc % 32 == 0 &&
          (S2 == 0 || S1 % 32 == 0) && M >= 96 && Ng <= 0x7fffffffL &&
          (long)stk_cdiv(M, 128) * stk_cdiv(Ng, 128) >= 192;
 }
+// dgrad = 1: rows are input channels, k output channels, taps flipped
 template <class EP>
-int launch_x3(const ConvP& p, const float* s1, int S1, const float* s2, int S2, int M, long Ng, int transpose,
-              void* ws, hipStream_t s) {
+int launch_x3(const ConvP& p, const float* s1, int S1, const float* s2, int S2, int M, long Ng, int dgrad, void* ws,
+              hipStream_t s) {
   x3::Src q;
-  q.s1 = s1; q.s2 = S2 > 0 ? s2 : s1; q.S1 = S1; q.S2 = S2; q.Kc = S1 + S2; q.Mpad = x3::pad128(M);
+  q.s1 = s1; q.s2 = S2 > 0 ? s2 : s1; q.S1 = S1; q.S2 = S2; q.Kc = S1 + S2; q.Mpad = x3::pad128(M); q.taps = p.taps;
   unsigned short* wp = reinterpret_cast<unsigned short*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   q.wp = wp;
   const long n = (long)q.Mpad * q.Kc;
-  hipLaunchKernelGGL(x3::wprep_kernel, dim3((unsigned)stk_cdiv(n, 256)), dim3(256), 0, s, p.w, wp, p.Cout, p.Cin, q.Mpad,
-                     transpose);
+  long sm, sk;
+  if (p.w_layout == 0) { sm = dgrad ? p.taps : (long)p.Cin * p.taps; sk = dgrad ? (long)p.Cin * p.taps : p.taps; }
+  else { sm = dgrad ? p.Cout : 1; sk = dgrad ? 1 : p.Cout; }          // NIN w[Cin][Cout]
+  hipLaunchKernelGGL(x3::wprep_kernel, dim3((unsigned)stk_cdiv(n, 256)), dim3(256), 0, s, p.w, wp, M, q.Kc, q.Mpad, sm, sk,
+                     p.taps, dgrad);
   STK_CHECK_LAUNCH();
-  const int tm = q.Mpad / 128, tn = stk_cdiv((int)Ng, 128), nch = 9 * (q.Kc / x3::KC);
-  if (S2 > 0)
-    hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<true>, EP, true>), dim3((unsigned)(tm * tn)), dim3(256), 0, s,
-                       p, q, M, (int)Ng, tm, tn, nch, nch, 0);
-  else
-    hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<false>, EP, true>), dim3((unsigned)(tm * tn)), dim3(256), 0, s,
-                       p, q, M, (int)Ng, tm, tn, nch, nch, 0);
+  const int tm = q.Mpad / 128, tn = stk_cdiv((int)Ng, 128), nch = p.taps * (q.Kc / x3::KC);
+  const dim3 grid((unsigned)(tm * tn));
+#define STK_X3_LAUNCH(DUAL, TAPS)                                                                                    \
+  hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<DUAL, TAPS>, EP, true>), grid, dim3(256), 0, s, p, q, M, \
+                     (int)Ng, tm, tn, nch, nch, 0)
+  if (p.taps == 9) { if (S2 > 0) STK_X3_LAUNCH(true, 9); else STK_X3_LAUNCH(false, 9); }
+  else { if (S2 > 0) STK_X3_LAUNCH(true, 1); else STK_X3_LAUNCH(false, 1); }
+#undef STK_X3_LAUNCH
   STK_CHECK_LAUNCH();
   return STK_OK;
 }
 
-// Weight gradient on the split kernel: 3x3 / stride 1 / pad 1, power-of-two maps of >= 8 columns and >= 32 pixels,
-// enough channels to fill 128-wide tiles.  One GEMM per tap, K (= pixels) split so that <= 512 workgroups run.
+// Weight gradient on the split kernel: 3x3 / stride 1 / pad 1 or 1x1 / stride 1, power-of-two maps of >= 8 columns and
+// >= 32 pixels, enough channels to fill 128-wide tiles.  One GEMM per tap, K (= pixels) split so that <= 512
+// workgroups run.
 struct X3WgradPlan { int ok; int splits; int chunks_per_split; long slab; };
 inline X3WgradPlan x3_wgrad_plan(int C1, int C2, int N, int Cout, int H, int W, int OH, int OW, int KH, int KW, int stride,
                                  int pad) {
@@ -786,17 +793,22 @@ inline X3WgradPlan x3_wgrad_plan(int C1, int C2, int N, int Cout, int H, int W, 
   const int cmax = Cout > C1 ? (Cout > C2 ? Cout : C2) : (C1 > C2 ? C1 : C2);
   if (K * cmax * 4 >= 0x7fffffffL || (C2 > 0 && C1 % 32)) return q;    // 32-bit buffer offsets; a wave's rows share a tensor
   const bool pow2 = (W & (W - 1)) == 0 && ((H * W) & (H * W - 1)) == 0;
-  if (KH != 3 || KW != 3 || stride != 1 || pad != 1 || OH != H || OW != W || !pow2 || W < 8 || H * W < 32 ||
-      Cin < 64 || Cout < 64 || K > 0x7fffffffL || K % 32)
+  const bool geom = (KH == 3 && KW == 3 && pad == 1) || (KH == 1 && KW == 1 && pad == 0);
+  if (!geom || stride != 1 || OH != H || OW != W || !pow2 || W < 8 || H * W < 32 || Cin < 64 || Cout < 64 ||
+      K > 0x7fffffffL || K % 32)
     return q;
-  const long tiles = 9L * stk_cdiv(Cout, 128) * stk_cdiv(Cin, 128);
+  const int taps = KH * KW;
+  const long tiles = (long)taps * stk_cdiv(Cout, 128) * stk_cdiv(Cin, 128);
+  // a 1x1 layer with few tiles needs so many K splits that writing / re-reading the partial slabs eats the gain
+  // (measured: 256->256 even, 128->256 slower than the f32-input kernel)
+  if (taps == 1 && tiles < 6) return q;
   const long chunks = K / 32;
   long splits = 512 / tiles;
   if (splits > chunks / 8) splits = chunks / 8;
   if (splits < 1) splits = 1;
   q.chunks_per_split = (int)((chunks + splits - 1) / splits);
   q.splits = (int)((chunks + q.chunks_per_split - 1) / q.chunks_per_split);
-  q.slab = (long)Cout * Cin * 9;
+  q.slab = (long)Cout * Cin * taps;
   q.ok = 1;
   return q;
 }
@@ -867,7 +879,7 @@ int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const f
   const long Ng = (long)N * p.OHW;
   const bool big = use_big_tile(Cout, Ng, 1);
   hipStream_t s = (hipStream_t)stream;
-  if (ws && w_layout == 0 && x3_ok(p, p.Cin, C1, C2, Cout, Ng) && ws_bytes >= x3::wp_bytes(Cout, p.Cin) + 256)
+  if (ws && x3_ok(p, p.Cin, C1, C2, Cout, Ng) && ws_bytes >= x3::wp_bytes(Cout, p.Cin, p.taps) + 256)
     return launch_x3<EpFwd>(p, x1, C1, x2, C2, Cout, Ng, 0, ws, s);
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;
@@ -906,7 +918,7 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
   const long Ng = (long)N * p.HW;
   const bool big = use_big_tile(Cin, Ng, 1);
   hipStream_t s = (hipStream_t)stream;
-  if (ws && w_layout == 0 && x3_ok(p, Cout, Cout, 0, Cin, Ng) && ws_bytes >= x3::wp_bytes(Cin, Cout) + 256)
+  if (ws && x3_ok(p, Cout, Cout, 0, Cin, Ng) && ws_bytes >= x3::wp_bytes(Cin, Cout, p.taps) + 256)
     return launch_x3<EpDgrad>(p, dy, Cout, nullptr, 0, Cin, Ng, 1, ws, s);
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;
@@ -933,15 +945,15 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
   const int Cin = C1 + C2;
   if (dir == 0) {
     const long Ng = (long)N * p.OHW;
-    if (w_layout == 0 && x3_ok(p, Cin, C1, C2, Cout, Ng)) return 2;
+    if (x3_ok(p, Cin, C1, C2, Cout, Ng)) return 2;
     return use_big_tile(Cout, Ng, 1) && !(p.taps == 1 && w_layout == 0 && (Cin % 8)) ? 1 : 0;
   }
   if (dir == 1) {
     const long Ng = (long)N * p.HW;
-    if (w_layout == 0 && x3_ok(p, Cout, Cout, 0, Cin, Ng)) return 2;
+    if (x3_ok(p, Cout, Cout, 0, Cin, Ng)) return 2;
     return use_big_tile(Cin, Ng, 1) && !(p.taps == 1 && w_layout == 1 && (Cout % 8)) ? 1 : 0;
   }
-  if (w_layout == 0 && x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad).ok) return 2;
+  if (x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad).ok) return 2;
   const bool can9 = stride == 1 && pad == 1 && C2 == 0 && OH == H && OW == W && w_layout == 0;
   const WgradPlan q = wgrad_plan(Cin, N, Cout, OH, OW, KH, KW, can9);
   return q.mode9 ? 3 : q.big;
@@ -950,19 +962,19 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
 long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, stride, pad)) return 0;
-  return x3_ok(p, C1 + C2, C1, C2, Cout, (long)N * H * W) ? x3::wp_bytes(Cout, C1 + C2) + 256 : 0;
+  return x3_ok(p, C1 + C2, C1, C2, Cout, (long)N * H * W) ? x3::wp_bytes(Cout, C1 + C2, p.taps) + 256 : 0;
 }
 
 long stk_conv2d_dgrad_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, stride, pad)) return 0;
-  return x3_ok(p, Cout, Cout, 0, C1 + C2, (long)N * H * W) ? x3::wp_bytes(C1 + C2, Cout) + 256 : 0;
+  return x3_ok(p, Cout, Cout, 0, C1 + C2, (long)N * H * W) ? x3::wp_bytes(C1 + C2, Cout, p.taps) + 256 : 0;
 }
 
 long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW) {
   const WgradPlan a = wgrad_plan(C1 + C2, N, Cout, OH, OW, KH, KW, true);
   const WgradPlan b = wgrad_plan(C1 + C2, N, Cout, OH, OW, KH, KW, false);
-  const X3WgradPlan x = x3_wgrad_plan(C1, C2, N, Cout, OH, OW, OH, OW, KH, KW, 1, 1);
+  const X3WgradPlan x = x3_wgrad_plan(C1, C2, N, Cout, OH, OW, OH, OW, KH, KW, 1, KH == 3 ? 1 : 0);
   const long na = (long)a.splits * a.slab, nb = (long)b.splits * b.slab, nx = x.ok ? (long)x.splits * x.slab : 0;
   const long m = na > nb ? na : nb;
   return (m > nx ? m : nx) * 4 + 256;
@@ -979,18 +991,18 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const X3WgradPlan xq = x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad);
-  if (xq.ok && w_layout == 0 && ws_bytes >= (long)xq.splits * xq.slab * 4) {
+  if (xq.ok && ws_bytes >= (long)xq.splits * xq.slab * 4) {
     p.x1 = x1; p.x2 = C2 > 0 ? x2 : x1; p.dy = dy; p.w_layout = w_layout; p.part = ws; p.part_stride = xq.slab;
     x3::Src q = {};
     const int tm = stk_cdiv(Cout, 128), tn = stk_cdiv(p.Cin, 128);
     const int nch = (int)((long)N * p.HW / 32);
-    const dim3 grid((unsigned)(9 * tm * tn * xq.splits));
+    const dim3 grid((unsigned)(p.taps * tm * tn * xq.splits));
     if (C2 > 0)
       hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false>, x3::RowsLoader<true, true>, EpWgrad, false>), grid, dim3(256),
-                         0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, 9);
+                         0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, p.taps);
     else
       hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false>, x3::RowsLoader<true, false>, EpWgrad, false>), grid, dim3(256),
-                         0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, 9);
+                         0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, p.taps);
     STK_CHECK_LAUNCH();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid(xq.slab)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
                        xq.slab, alpha, w_layout, Cout, p.Cin, p.taps);

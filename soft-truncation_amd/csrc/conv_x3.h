@@ -46,6 +46,7 @@ constexpr int LDS_BYTES = 2 * OPER;    // 61440
 struct Src {             // the activation operand: channel-concat of two NCHW tensors
   const float* s1; const float* s2; int S1, S2;
   const unsigned short* wp; int Mpad; int Kc;     // prepared weights, padded row count, channels (= S1 + S2)
+  int taps;                                       // 9 (3x3, pad 1) or 1 (1x1)
 };
 
 __device__ __forceinline__ float hi_part(float v) { return __uint_as_float(__float_as_uint(v) & 0xffff0000u); }
@@ -54,12 +55,14 @@ __device__ __forceinline__ unsigned pack_hi(float lo, float hi) {
   return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
 }
 
-// Wp[split][k / 32][tap][row][k % 32] = split_s( transpose ? w[(k*Cin + row)*9 + 8 - tap] : w[(row*Cin + k)*9 + tap] ),
-// rows >= the real row count are zero: one (channel group, tap) is a dense [Mpad][32] bf16 block, i.e. the A tile of
-// one chunk is 8 KB of consecutive memory per plane.  One thread per (row, k): reads its 9 taps (36 contiguous bytes).
-__global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                                    int Cout, int Cin, int Mpad, int transpose) {
-  const int Kd = transpose ? Cout : Cin, R = transpose ? Cin : Cout;
+// Wp[split][k / 32][tap][row][k % 32] = split_s( W(row, k, tap) ), rows >= R are zero: one (channel group, tap) is a
+// dense [Mpad][32] bf16 block, i.e. the A tile of one chunk is 8 KB of consecutive memory per plane.
+// W(row, k, tap) = w[row*sm + k*sk + (flip ? taps-1-tap : tap)]:
+//     forward  [Cout,Cin,kh,kw]: sm = Cin*taps, sk = taps      NIN [Cin,Cout]: sm = 1, sk = Cout
+//     dgrad    [Cout,Cin,kh,kw]: sm = taps, sk = Cin*taps, flip   NIN: sm = Cout, sk = 1
+// One thread per (row, k): reads its taps (contiguous).
+__global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int R,
+                                                    int Kd, int Mpad, long sm, long sk, int taps, int flip) {
   const long total = (long)Mpad * Kd;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -67,22 +70,13 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w,
   const int kl = (int)(i & 31);
   const long rest = i >> 5;
   const int row = (int)(rest % Mpad), cc = (int)(rest / Mpad), k = cc * 32 + kl;
-  float v[9];
-  if (row < R) {
-    const float* s = w + (transpose ? ((long)k * Cin + row) : ((long)row * Cin + k)) * 9;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) v[t] = s[t];
-  } else {
-#pragma unroll
-    for (int t = 0; t < 9; ++t) v[t] = 0.f;
-  }
-  const long plane = 9L * Mpad * Kd;
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const float a = v[transpose ? 8 - t : t];
+  const long plane = (long)taps * Mpad * Kd;
+  const float* s = w + (row < R ? row * sm + k * sk : 0);
+  for (int t = 0; t < taps; ++t) {
+    const float a = row < R ? s[flip ? taps - 1 - t : t] : 0.f;
     const float h0 = hi_part(a), r1 = a - h0;
     const float h1 = hi_part(r1), h2 = r1 - h1;           // h2 has <= 8 significant bits: exact in bf16
-    const long o = (((long)cc * 9 + t) * Mpad + row) * 32 + kl;
+    const long o = (((long)cc * taps + t) * Mpad + row) * 32 + kl;
     out[o] = (unsigned short)(__float_as_uint(h0) >> 16);
     out[plane + o] = (unsigned short)(__float_as_uint(h1) >> 16);
     out[2 * plane + o] = (unsigned short)(__float_as_uint(h2) >> 16);
@@ -136,7 +130,7 @@ struct WpLoader {
   u32x4 r[6];
   __device__ __forceinline__ void init(const ConvP&, const Src& q, int m0, int tid, int) {
     row = tid >> 2; seg = tid & 3;
-    plane2 = 9u * q.Mpad * q.Kc * 2u;                   // bytes per split plane
+    plane2 = (unsigned)q.taps * q.Mpad * q.Kc * 2u;     // bytes per split plane
     chunk2 = (unsigned)q.Mpad * KC * 2u;                // bytes per (channel group, tap) block = per chunk
     rs = make_rsrc(q.wp, 3L * plane2);
     voff = ((unsigned)(m0 + row) * KC + seg * 8) * 2u;
@@ -152,7 +146,7 @@ struct WpLoader {
 };
 
 // forward / dgrad B: activations, lanes along pixels; a thread holds 16 channels of one tap-shifted pixel
-template <bool DUAL>
+template <bool DUAL, int TAPS>
 struct ActLoader {
   __amdgpu_buffer_rsrc_t rs1, rs2;
   int nl, kg, tb1, tb2; unsigned mask;
@@ -167,8 +161,9 @@ struct ActLoader {
     if (n < p.N * p.HW) {
       const int b = n / p.HW, hw = n - b * p.HW;
       const int y = hw / p.W, x = hw - y * p.W;
+      if (TAPS == 1) mask = 1u;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      for (int t = 0; t < (TAPS == 9 ? 9 : 0); ++t) {
         const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
         if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
       }
@@ -179,14 +174,15 @@ struct ActLoader {
   // slices 8..23 load one channel each (its register was consumed by conversion slice (g - 8) / 2 <= 7)
   __device__ __forceinline__ void ld(int g, const ConvP& p, const Src& q, int c) {
     if (g < 8) return;
-    const int cc = c / 9, tap = c - cc * 9;                      // scalar: chunk = (32-channel group, tap), tap fastest
+    const int cc = TAPS == 9 ? c / 9 : c, tap = c - cc * TAPS;   // scalar: chunk = (32-channel group, tap), tap fastest
     const int ci0 = cc * KC + kg * 16;
     const bool first = !DUAL || ci0 < q.S1;                      // scalar: a chunk never straddles the two sources
     const __amdgpu_buffer_rsrc_t rs = first ? rs1 : rs2;
     const unsigned so = (unsigned)(first ? ci0 : ci0 - q.S1) * p.HW * 4u;
     // halo / out-of-range lanes: offset bit 31 -> outside the buffer -> the load returns 0 (no select, no branch)
     const unsigned dead = (((mask >> tap) & 1u) ^ 1u) << 31;
-    const unsigned vo = (unsigned)(((first ? tb1 : tb2) + (tap / 3 - 1) * p.W + (tap % 3 - 1)) * 4) | dead;
+    const int shift = TAPS == 9 ? (tap / 3 - 1) * p.W + (tap % 3 - 1) : 0;
+    const unsigned vo = (unsigned)(((first ? tb1 : tb2) + shift) * 4) | dead;
     r[g - 8] = bload(rs, vo, so + (unsigned)(g - 8) * p.HW * 4u);
   }
   __device__ __forceinline__ void st(int g, unsigned char* t) { sp.st(g, r, 0xffffu, t, nl, kg * 16); }
@@ -205,7 +201,7 @@ struct RowsLoader {
   float r[16]; Split16 sp;
   __device__ __forceinline__ void init(const ConvP& p, const Src&, int o0, int tid, int zb) {
     row = tid >> 1; half = tid & 1; okm = 0;
-    dy = SHIFT ? zb / 3 - 1 : 0; dx = SHIFT ? zb % 3 - 1 : 0;
+    dy = SHIFT ? zb / 3 - 1 : 0; dx = SHIFT ? zb % 3 - 1 : 0;     // (a 1x1 layer passes the centre tap, zb = 4)
     const int ch = o0 + row;
     if (SHIFT) {                                   // x: channel of the concat input
       rowok = ch < p.Cin;
@@ -305,8 +301,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(ConvP p, Src q, int M, int Nn
   const int c_last = min(nchunks_total, c_begin + chunks_per_split) - 1;     // >= c_begin by construction
 
   AL al; BL bl;
-  al.init(p, q, m0, tid, zb);
-  bl.init(p, q, n0, tid, zb);
+  al.init(p, q, m0, tid, taps_z == 1 ? 4 : zb);      // 1x1 weight gradient: the (unshifted) centre tap
+  bl.init(p, q, n0, tid, taps_z == 1 ? 4 : zb);
 
   floatx16 acc[2][2];
 #pragma unroll
@@ -409,7 +405,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ConvP p, Src q, int M, int Nn
 }
 
 inline int pad128(int v) { return (v + 127) / 128 * 128; }
-// bytes of prepared weights for an M x Kc 3x3 layer
-inline long wp_bytes(int M, int Kc) { return 3L * 9 * pad128(M) * Kc * 2; }
+// bytes of prepared weights for an M x Kc layer
+inline long wp_bytes(int M, int Kc, int taps) { return 3L * taps * pad128(M) * Kc * 2; }
 
 }  // namespace x3

@@ -272,6 +272,9 @@ CONV_CASES = [
   (43, 96, 0, 24, 24, 128, 3, 1, 1, 24, 24, 0, True, False, False),     # split kernel: ragged pixel tiles
   (6, 64, 0, 8, 8, 96, 3, 1, 1, 8, 8, 0, False, False, False),          # split wgrad: 8-wide maps (runs span two rows)
   (3, 32, 64, 8, 8, 72, 3, 1, 1, 8, 8, 0, False, False, False),         # split wgrad: 8-wide, concat, ragged Cout
+  (48, 256, 0, 16, 16, 256, 1, 1, 0, 16, 16, 1, False, True, True),     # split kernel: NIN (w[Cin][Cout]) + residual
+  (48, 128, 128, 16, 16, 256, 1, 1, 0, 16, 16, 0, False, False, False), # split kernel: 1x1 shortcut on a concat
+  (96, 128, 0, 16, 16, 160, 1, 1, 0, 16, 16, 1, True, False, False),    # split kernel: NIN, ragged Cout
 ]
 
 
