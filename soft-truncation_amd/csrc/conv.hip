@@ -485,6 +485,49 @@ struct EpWgrad {      // partial slab of split zs as [tap][Cout][Cin] (coalesced
   }
 };
 
+// Forward / dgrad split over K (small maps): partial tile of split zs as [M][N] (lanes = pixels, contiguous)
+struct EpSlab {
+  float* slab; int Nn;
+  __device__ void init(const ConvP& p, int, int zs) { slab = p.part + (long)zs * p.part_stride; Nn = p.N * p.HW; }
+  __device__ void col(const ConvP&, int) {}
+  __device__ void strip(const ConvP&, int mbase, int M, bool nok, int n, const floatx16& acc) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = mbase + strip_row(e);
+      if (nok && m < M) slab[(long)m * Nn + n] = acc[e];
+    }
+  }
+};
+// sum of the split slabs in a fixed order, then the same epilogue arithmetic as EpFwd / EpDgrad
+__global__ __launch_bounds__(256) void slab_fwd_kernel(ConvP p, int splits, int M, int Nn) {
+  const long total = (long)M * Nn, gstride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+    const int m = (int)(i / Nn), n = (int)(i - (long)m * Nn);
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += p.part[(long)z * p.part_stride + i];
+    const int b = n / p.OHW;
+    const long idx = ((long)b * p.Cout + m) * p.OHW + (n - b * p.OHW);
+    if (p.bias) v += p.bias[m];
+    if (p.temb) v += p.temb[(long)b * p.temb_stride + m];
+    if (p.res) v += p.res[idx];
+    if (p.use_div) v *= p.inv_div;
+    p.y[idx] = v;
+  }
+}
+__global__ __launch_bounds__(256) void slab_dgrad_kernel(ConvP p, int splits, int M, int Nn) {
+  const long total = (long)M * Nn, gstride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+    const int m = (int)(i / Nn), n = (int)(i - (long)m * Nn);
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += p.part[(long)z * p.part_stride + i];
+    const int b = n / p.HW, hw = n - b * p.HW;
+    float* d; float beta;
+    if (m < p.C1) { d = p.dx1 ? p.dx1 + ((long)b * p.C1 + m) * p.HW + hw : nullptr; beta = p.beta1; }
+    else { d = p.dx2 ? p.dx2 + ((long)b * p.C2 + (m - p.C1)) * p.HW + hw : nullptr; beta = p.beta2; }
+    if (d) *d = (beta != 0.f ? beta * *d : 0.f) + p.alpha * v;
+  }
+}
+
 #include "conv_x3.h"
 
 // dw (in the weight's own layout) += alpha * sum over splits of slab[tap][co][ci]
@@ -744,24 +787,44 @@ inline int fill_common(ConvP& p, int N, int H, int W, int C1, int C2, int Cout, 
 }
 
 // The bf16 three-way-split kernel (conv_x3.h) takes 3x3 / stride 1 / pad 1 and 1x1 / stride 1 layers whose channel
-// count is a multiple of the 32-wide k chunk (and, for a concat input, whose first source is too) when there are at
-// least 192 tiles of 128 x 128 (measured: with 128 tiles -- 8x8 maps at batch 128 -- one workgroup per CU has nothing
-// to overlap with and the 64 x 64 f32-input kernel is faster).
-inline bool x3_ok(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
+// count is a multiple of the 32-wide k chunk (and, for a concat input, whose first source is too).  With at least
+// 192 tiles of 128 x 128 a workgroup owns a whole output tile.  Smaller problems (the 8x8 and 4x4 maps: 128 / 32
+// tiles at batch 128, where one workgroup per CU has nothing to overlap with) are split over K into partial slabs
+// that a second kernel sums in a fixed order and finishes with the usual epilogue.
+struct X3Plan { int ok; int splits; int chunks_per_split; long slab; };
+inline X3Plan x3_plan(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
+  X3Plan r = {0, 1, 0, 0};
   const long big = (long)p.N * p.HW * 4 * (S1 > S2 ? S1 : S2);       // buffer loads: 32-bit byte offsets, bit 31 = dead lane
   const bool geom = (p.taps == 9 && p.pad == 1) || (p.taps == 1 && p.pad == 0);
-  return big < 0x7fffffffL && geom && p.stride == 1 && p.OH == p.H && p.OW == p.W && Kc % 32 == 0 &&
-         (S2 == 0 || S1 % 32 == 0) && M >= 96 && Ng <= 0x7fffffffL &&
-         (long)stk_cdiv(M, 128) * stk_cdiv(Ng, 128) >= 192;
+  if (!(big < 0x7fffffffL && geom && p.stride == 1 && p.OH == p.H && p.OW == p.W && Kc % 32 == 0 &&
+        (S2 == 0 || S1 % 32 == 0) && M >= 96 && Ng <= 0x7fffffffL))
+    return r;
+  const long tiles = (long)stk_cdiv(M, 128) * stk_cdiv(Ng, 128);
+  const int nch = p.taps * (Kc / 32);
+  r.chunks_per_split = nch;
+  if (tiles >= 192) { r.ok = 1; return r; }
+  long splits = 512 / tiles;
+  if (splits > nch / 6) splits = nch / 6;            // >= 6 chunks per workgroup, or the prologue dominates
+  if (tiles < 16 || splits < 2) return r;
+  r.chunks_per_split = (int)((nch + splits - 1) / splits);
+  r.splits = (nch + r.chunks_per_split - 1) / r.chunks_per_split;
+  r.slab = (long)M * Ng;
+  r.ok = 1;
+  return r;
+}
+inline long x3_ws_bytes(const X3Plan& r, int M, int Kc, int taps) {
+  return r.ok ? x3::wp_bytes(M, Kc, taps) + 512 + (r.splits > 1 ? r.splits * r.slab * 4 : 0) : 0;
 }
 // dgrad = 1: rows are input channels, k output channels, taps flipped
 template <class EP>
-int launch_x3(const ConvP& p, const float* s1, int S1, const float* s2, int S2, int M, long Ng, int dgrad, void* ws,
-              hipStream_t s) {
+int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2, int S2, int M, long Ng, int dgrad,
+              void* ws, hipStream_t s) {
   x3::Src q;
   q.s1 = s1; q.s2 = S2 > 0 ? s2 : s1; q.S1 = S1; q.S2 = S2; q.Kc = S1 + S2; q.Mpad = x3::pad128(M); q.taps = p.taps;
   unsigned short* wp = reinterpret_cast<unsigned short*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   q.wp = wp;
+  p.part = reinterpret_cast<float*>(((uintptr_t)wp + x3::wp_bytes(M, q.Kc, p.taps) + 255) & ~(uintptr_t)255);
+  p.part_stride = r.slab;
   const long n = (long)q.Mpad * q.Kc;
   long sm, sk;
   if (p.w_layout == 0) { sm = dgrad ? p.taps : (long)p.Cin * p.taps; sk = dgrad ? (long)p.Cin * p.taps : p.taps; }
@@ -770,12 +833,24 @@ int launch_x3(const ConvP& p, const float* s1, int S1, const float* s2, int S2, 
                      p.taps, dgrad);
   STK_CHECK_LAUNCH();
   const int tm = q.Mpad / 128, tn = stk_cdiv((int)Ng, 128), nch = p.taps * (q.Kc / x3::KC);
-  const dim3 grid((unsigned)(tm * tn));
-#define STK_X3_LAUNCH(DUAL, TAPS)                                                                                    \
-  hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<DUAL, TAPS>, EP, true>), grid, dim3(256), 0, s, p, q, M, \
-                     (int)Ng, tm, tn, nch, nch, 0)
-  if (p.taps == 9) { if (S2 > 0) STK_X3_LAUNCH(true, 9); else STK_X3_LAUNCH(false, 9); }
-  else { if (S2 > 0) STK_X3_LAUNCH(true, 1); else STK_X3_LAUNCH(false, 1); }
+  const dim3 grid((unsigned)(tm * tn * r.splits));
+#define STK_X3_LAUNCH(E, DUAL, TAPS)                                                                                \
+  hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<DUAL, TAPS>, E, true>), grid, dim3(256), 0, s, p, q, M, \
+                     (int)Ng, tm, tn, nch, r.chunks_per_split, 1)
+#define STK_X3_LAUNCH_E(E)                                                                                          \
+  if (p.taps == 9) { if (S2 > 0) STK_X3_LAUNCH(E, true, 9); else STK_X3_LAUNCH(E, false, 9); }                      \
+  else { if (S2 > 0) STK_X3_LAUNCH(E, true, 1); else STK_X3_LAUNCH(E, false, 1); }
+  if (r.splits == 1) {
+    STK_X3_LAUNCH_E(EP)
+    STK_CHECK_LAUNCH();
+    return STK_OK;
+  }
+  STK_X3_LAUNCH_E(EpSlab)
+  STK_CHECK_LAUNCH();
+  const dim3 rgrid((unsigned)stk_ew_grid((long)M * Ng));
+  if (dgrad) hipLaunchKernelGGL(slab_dgrad_kernel, rgrid, dim3(256), 0, s, p, r.splits, M, (int)Ng);
+  else hipLaunchKernelGGL(slab_fwd_kernel, rgrid, dim3(256), 0, s, p, r.splits, M, (int)Ng);
+#undef STK_X3_LAUNCH_E
 #undef STK_X3_LAUNCH
   STK_CHECK_LAUNCH();
   return STK_OK;
@@ -879,8 +954,9 @@ int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const f
   const long Ng = (long)N * p.OHW;
   const bool big = use_big_tile(Cout, Ng, 1);
   hipStream_t s = (hipStream_t)stream;
-  if (ws && x3_ok(p, p.Cin, C1, C2, Cout, Ng) && ws_bytes >= x3::wp_bytes(Cout, p.Cin, p.taps) + 256)
-    return launch_x3<EpFwd>(p, x1, C1, x2, C2, Cout, Ng, 0, ws, s);
+  const X3Plan xr = x3_plan(p, p.Cin, C1, C2, Cout, Ng);
+  if (ws && xr.ok && ws_bytes >= x3_ws_bytes(xr, Cout, p.Cin, p.taps))
+    return launch_x3<EpFwd>(p, xr, x1, C1, x2, C2, Cout, Ng, 0, ws, s);
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;
     if (C2 > 0) {
@@ -918,8 +994,9 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
   const long Ng = (long)N * p.HW;
   const bool big = use_big_tile(Cin, Ng, 1);
   hipStream_t s = (hipStream_t)stream;
-  if (ws && x3_ok(p, Cout, Cout, 0, Cin, Ng) && ws_bytes >= x3::wp_bytes(Cin, Cout, p.taps) + 256)
-    return launch_x3<EpDgrad>(p, dy, Cout, nullptr, 0, Cin, Ng, 1, ws, s);
+  const X3Plan xr = x3_plan(p, Cout, Cout, 0, Cin, Ng);
+  if (ws && xr.ok && ws_bytes >= x3_ws_bytes(xr, Cin, Cout, p.taps))
+    return launch_x3<EpDgrad>(p, xr, dy, Cout, nullptr, 0, Cin, Ng, 1, ws, s);
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;
     if (big) return launch<CB, ConvP, ADgrad9<CB>, BDgrad<CB, 9>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
@@ -945,12 +1022,12 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
   const int Cin = C1 + C2;
   if (dir == 0) {
     const long Ng = (long)N * p.OHW;
-    if (x3_ok(p, Cin, C1, C2, Cout, Ng)) return 2;
+    if (x3_plan(p, Cin, C1, C2, Cout, Ng).ok) return 2;
     return use_big_tile(Cout, Ng, 1) && !(p.taps == 1 && w_layout == 0 && (Cin % 8)) ? 1 : 0;
   }
   if (dir == 1) {
     const long Ng = (long)N * p.HW;
-    if (x3_ok(p, Cout, Cout, 0, Cin, Ng)) return 2;
+    if (x3_plan(p, Cout, Cout, 0, Cin, Ng).ok) return 2;
     return use_big_tile(Cin, Ng, 1) && !(p.taps == 1 && w_layout == 1 && (Cout % 8)) ? 1 : 0;
   }
   if (x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad).ok) return 2;
@@ -962,13 +1039,13 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
 long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, stride, pad)) return 0;
-  return x3_ok(p, C1 + C2, C1, C2, Cout, (long)N * H * W) ? x3::wp_bytes(Cout, C1 + C2, p.taps) + 256 : 0;
+  return x3_ws_bytes(x3_plan(p, C1 + C2, C1, C2, Cout, (long)N * H * W), Cout, C1 + C2, p.taps);
 }
 
 long stk_conv2d_dgrad_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, stride, pad)) return 0;
-  return x3_ok(p, Cout, Cout, 0, C1 + C2, (long)N * H * W) ? x3::wp_bytes(C1 + C2, Cout, p.taps) + 256 : 0;
+  return x3_ws_bytes(x3_plan(p, Cout, Cout, 0, C1 + C2, (long)N * H * W), C1 + C2, Cout, p.taps);
 }
 
 long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW) {

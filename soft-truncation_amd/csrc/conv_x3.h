@@ -273,8 +273,8 @@ struct RowsLoader {
 };
 
 // ---- the kernel: out tile 128 x 128, 4 waves of 64 x 64, chunks of 32 k ---------------------------------------
-// Grid: tiles (XCD-remapped);  with taps_z > 0 (wgrad) one flat dimension of taps x tiles x splits, tap fastest so
-// that the nine blocks reading the same dy / x panels are neighbours on one XCD's L2.
+// Grid (XCD-remapped): one flat dimension of taps_z x tiles x K-splits blocks, z fastest.  taps_z = 9 for the 3x3
+// weight gradient (the nine blocks reading the same dy / x panels are neighbours on one XCD's L2), 1 otherwise.
 template <class AL, class BL, class EP, bool HAND>
 __global__ __launch_bounds__(256) void gemm_kernel(ConvP p, Src q, int M, int Nn, int tiles_m, int tiles_n,
                                                    int nchunks_total, int chunks_per_split, int taps_z) {
@@ -285,16 +285,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(ConvP p, Src q, int M, int Nn
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int ntiles = tiles_m * tiles_n;
-  int tile, zb = 0, zs = 0;
-  if (taps_z > 0) {
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
-    zb = id % taps_z;
-    const int rest = id / taps_z;
-    tile = rest % ntiles;
-    zs = rest / ntiles;
-  } else {
-    tile = xcd_remap(blockIdx.x, ntiles);
-  }
+  // one flat grid dimension of z-batches (taps) x tiles x K splits, z fastest
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int zb = id % taps_z;
+  const int rest = id / taps_z;
+  const int tile = rest % ntiles;
+  const int zs = rest / ntiles;
   const int tm = tile % tiles_m, tn = tile / tiles_m;
   const int m0 = tm * 128, n0 = tn * 128;
   const int c_begin = zs * chunks_per_split;

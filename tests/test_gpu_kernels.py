@@ -275,6 +275,8 @@ CONV_CASES = [
   (48, 256, 0, 16, 16, 256, 1, 1, 0, 16, 16, 1, False, True, True),     # split kernel: NIN (w[Cin][Cout]) + residual
   (48, 128, 128, 16, 16, 256, 1, 1, 0, 16, 16, 0, False, False, False), # split kernel: 1x1 shortcut on a concat
   (96, 128, 0, 16, 16, 160, 1, 1, 0, 16, 16, 1, True, False, False),    # split kernel: NIN, ragged Cout
+  (40, 64, 64, 8, 8, 200, 3, 1, 1, 8, 8, 0, True, True, True),          # split kernel, K split into slabs: concat, ragged
+  (100, 256, 0, 4, 4, 256, 3, 1, 1, 4, 4, 0, True, True, False),        # K-split slabs on 4x4 maps
 ]
 
 
