@@ -73,12 +73,15 @@ int stk_fused_bias_act_f32(const float* x, const float* b, const float* ref, flo
  * hipGraph draw a fresh mask on every replay (the by-value seed is frozen at capture time).
  * mean/rstd [N*G] are written by fwd and read by bwd.
  * bwd: dx = dx_beta*dx + grad wrt x (split into dx1/dx2 like the input), dgamma/dbeta are
- * accumulated (+=).  ws: >= 2*N*C floats of scratch.
+ * accumulated (+=).
+ * ws: stk_gn_ws_bytes(N, C, HW, G) bytes of scratch (>= 2*N*C floats).  fwd uses it only for groups too large for
+ * one workgroup (it may be NULL otherwise; with NULL such groups take the one-workgroup-per-group kernel).
  * ------------------------------------------------------------------------------------------ */
 int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2,
                    const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                    int N, int HW, int G, float eps, int act, float drop_p,
-                   unsigned long long seed, const unsigned long long* seed_dev, void* stream);
+                   unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream);
+long stk_gn_ws_bytes(int N, int C, int HW, int G);
 int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, int C2,
                    const float* gamma, const float* beta, const float* mean, const float* rstd,
                    float* dx1, float dx1_beta, float* dx2, float dx2_beta,

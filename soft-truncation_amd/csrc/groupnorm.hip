@@ -321,6 +321,173 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
   }
 }
 
+// ---- large groups: one (sample, group) split over many workgroups -------------------------------------------
+// A 256x256 map at batch 4 has only N*G = 128 groups of 1 MB each: one workgroup per group leaves half the chip
+// idle and streams each group serially (measured 689 us for a 134 MB backward).  Here a workgroup owns one CHUNK
+// (GN_CHUNK consecutive elements of one channel); a first kernel writes per-chunk partial sums, the second one
+// folds the partials of its group in a fixed order and streams its chunk.  Partials: part[((n*C + c)*Sc + k)*2 + {0,1}].
+constexpr int GN_CHUNK = 4096;       // floats: 4 float4 per thread
+
+__device__ __forceinline__ const float* gn_chan(const GnArgs& a, int n, int c) {
+  return c < a.C1 ? a.x1 + ((long)n * a.C1 + c) * a.HW : a.x2 + ((long)n * a.C2 + (c - a.C1)) * a.HW;
+}
+
+// forward statistics: shifted sums (shift = first element of the group) of one chunk
+__global__ __launch_bounds__(256) void gn_split_stats_kernel(GnArgs a, float* __restrict__ part, int Sc) {
+  __shared__ float red[16];
+  const int k = blockIdx.x % Sc, nc = blockIdx.x / Sc;
+  const int C = a.C1 + a.C2, n = nc / C, c = nc - n * C, g = c / a.cpg;
+  const float shift = gn_chan(a, n, g * a.cpg)[0];
+  const float4* p4 = reinterpret_cast<const float4*>(gn_chan(a, n, c) + (long)k * GN_CHUNK);
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < GN_CHUNK / 1024; ++i) {
+    const float4 v = p4[threadIdx.x + 256 * i];
+    const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+    s[0] += (d0 + d1) + (d2 + d3);
+    s[1] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  block_sum<2>(s, red);
+  if (threadIdx.x == 0) { part[(long)blockIdx.x * 2] = s[0]; part[(long)blockIdx.x * 2 + 1] = s[1]; }
+}
+
+__global__ __launch_bounds__(256) void gn_split_fwd_kernel(GnArgs a, const float* __restrict__ part, int Sc,
+                                                           float* __restrict__ y, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out, float eps) {
+  __shared__ float red[16];
+  const int k = blockIdx.x % Sc, nc = blockIdx.x / Sc;
+  const int C = a.C1 + a.C2, n = nc / C, c = nc - n * C, g = c / a.cpg;
+  const float shift = gn_chan(a, n, g * a.cpg)[0];
+  // fold the cpg * Sc partials of the group (fixed order inside block_sum)
+  float s[2] = {0.f, 0.f};
+  const long pbase = ((long)n * C + g * a.cpg) * Sc;
+  for (int i = threadIdx.x; i < a.cpg * Sc; i += 256) { s[0] += part[(pbase + i) * 2]; s[1] += part[(pbase + i) * 2 + 1]; }
+  block_sum<2>(s, red);
+  const float inv_l = 1.f / ((float)a.cpg * (float)a.HW);
+  const float md = s[0] * inv_l;
+  const float var = fmaxf(s[1] * inv_l - md * md, 0.f);
+  const float mean = shift + md, rstd = 1.f / sqrtf(var + eps);
+  if (threadIdx.x == 0 && k == 0 && c == g * a.cpg) { mean_out[n * a.G + g] = mean; rstd_out[n * a.G + g] = rstd; }
+  unsigned long long seed = a.seed;
+  if (a.drop_p > 0.f && a.seed_dev) seed += *a.seed_dev;
+  const float ga = a.gamma[c], be = a.beta[c];
+  const long coff = (long)k * GN_CHUNK;
+  const float4* p4 = reinterpret_cast<const float4*>(gn_chan(a, n, c) + coff);
+  float4* o4 = reinterpret_cast<float4*>(y + ((long)n * C + c) * a.HW + coff);
+  const unsigned long long flat0 = ((unsigned long long)n * C + c) * a.HW + coff;
+#pragma unroll
+  for (int i = 0; i < GN_CHUNK / 1024; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const float4 v = p4[e];
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float u = ga * ((r[j] - mean) * rstd) + be;
+      float t = a.act ? silu_f(u) : u;
+      if (a.drop_p > 0.f) t = (stk_uniform(seed, flat0 + (unsigned long long)(e * 4 + j)) >= a.drop_p) ? t * a.keep_scale : 0.f;
+      r[j] = t;
+    }
+    o4[e] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+// backward partials of one chunk: sum du, sum du * xhat
+__global__ __launch_bounds__(256) void gn_split_bwd_part_kernel(GnArgs a, const float* __restrict__ dy,
+                                                                const float* __restrict__ mean_in,
+                                                                const float* __restrict__ rstd_in,
+                                                                float* __restrict__ part, int Sc) {
+  __shared__ float red[16];
+  const int k = blockIdx.x % Sc, nc = blockIdx.x / Sc;
+  const int C = a.C1 + a.C2, n = nc / C, c = nc - n * C, g = c / a.cpg;
+  const float mean = mean_in[n * a.G + g], rstd = rstd_in[n * a.G + g];
+  unsigned long long seed = a.seed;
+  if (a.drop_p > 0.f && a.seed_dev) seed += *a.seed_dev;
+  const float ga = a.gamma[c], be = a.beta[c];
+  const long coff = (long)k * GN_CHUNK;
+  const float4* x4 = reinterpret_cast<const float4*>(gn_chan(a, n, c) + coff);
+  const float4* d4 = reinterpret_cast<const float4*>(dy + ((long)n * C + c) * a.HW + coff);
+  const unsigned long long flat0 = ((unsigned long long)n * C + c) * a.HW + coff;
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < GN_CHUNK / 1024; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const float4 xv = x4[e], dv = d4[e];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float xh;
+      const float du = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, flat0 + (unsigned long long)(e * 4 + j), xh);
+      s[0] += du;
+      s[1] += du * xh;
+    }
+  }
+  block_sum<2>(s, red);
+  if (threadIdx.x == 0) { part[(long)blockIdx.x * 2] = s[0]; part[(long)blockIdx.x * 2 + 1] = s[1]; }
+}
+
+__global__ __launch_bounds__(256) void gn_split_bwd_kernel(GnArgs a, const float* __restrict__ dy,
+                                                           const float* __restrict__ mean_in,
+                                                           const float* __restrict__ rstd_in, const float* __restrict__ part,
+                                                           int Sc, float* __restrict__ dx1, float beta1,
+                                                           float* __restrict__ dx2, float beta2, float* __restrict__ ws) {
+  __shared__ float red[16];
+  const int k = blockIdx.x % Sc, nc = blockIdx.x / Sc;
+  const int C = a.C1 + a.C2, n = nc / C, c = nc - n * C, g = c / a.cpg;
+  const float mean = mean_in[n * a.G + g], rstd = rstd_in[n * a.G + g];
+  // group sums of du*gamma and du*gamma*xhat from the partials (fixed order), and this channel's own sums
+  float s[2] = {0.f, 0.f};
+  const long pbase = ((long)n * C + g * a.cpg) * Sc;
+  for (int i = threadIdx.x; i < a.cpg * Sc; i += 256) {
+    const float gc = a.gamma[g * a.cpg + i / Sc];
+    s[0] += gc * part[(pbase + i) * 2];
+    s[1] += gc * part[(pbase + i) * 2 + 1];
+  }
+  block_sum<2>(s, red);
+  const float inv_l = 1.f / ((float)a.cpg * (float)a.HW);
+  const float m1 = s[0] * inv_l, m2 = s[1] * inv_l;
+  if (k == 0 && threadIdx.x == 0) {            // per-(sample, channel) sums for the parameter gradients
+    float t0 = 0.f, t1 = 0.f;
+    const long cb = ((long)n * C + c) * Sc;
+    for (int q = 0; q < Sc; ++q) { t0 += part[(cb + q) * 2]; t1 += part[(cb + q) * 2 + 1]; }
+    ws[((long)n * C + c) * 2] = t0;
+    ws[((long)n * C + c) * 2 + 1] = t1;
+  }
+  float* op; float ob;
+  if (c < a.C1) { op = dx1 ? dx1 + ((long)n * a.C1 + c) * a.HW : nullptr; ob = beta1; }
+  else { op = dx2 ? dx2 + ((long)n * a.C2 + (c - a.C1)) * a.HW : nullptr; ob = beta2; }
+  if (!op) return;
+  unsigned long long seed = a.seed;
+  if (a.drop_p > 0.f && a.seed_dev) seed += *a.seed_dev;
+  const float ga = a.gamma[c], be = a.beta[c];
+  const long coff = (long)k * GN_CHUNK;
+  const float4* x4 = reinterpret_cast<const float4*>(gn_chan(a, n, c) + coff);
+  const float4* d4 = reinterpret_cast<const float4*>(dy + ((long)n * C + c) * a.HW + coff);
+  float4* o4 = reinterpret_cast<float4*>(op + coff);
+  const unsigned long long flat0 = ((unsigned long long)n * C + c) * a.HW + coff;
+#pragma unroll
+  for (int i = 0; i < GN_CHUNK / 1024; ++i) {
+    const int e = threadIdx.x + 256 * i;
+    const float4 xv = x4[e], dv = d4[e];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float xh;
+      const float du = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, flat0 + (unsigned long long)(e * 4 + j), xh);
+      r[j] = rstd * (du * ga - m1 - xh * m2);
+    }
+    if (ob != 0.f) {
+      const float4 old = o4[e];
+      r[0] += ob * old.x; r[1] += ob * old.y; r[2] += ob * old.z; r[3] += ob * old.w;
+    }
+    o4[e] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+// Split path preconditions: groups too large for the register-resident kernels, channels made of whole chunks,
+// 16-byte aligned tensors.
+inline bool gn_split_ok(int HW, int cpg) { return (long)cpg * HW > 16384 && HW % GN_CHUNK == 0; }
+
 // dgamma[c] += sum_n ws[n,c,1];  dbeta[c] += sum_n ws[n,c,0].  32 channels per block, 8-way split over n.
 __global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int N, int C) {
@@ -352,7 +519,7 @@ extern "C" {
 
 int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
                    float* mean, float* rstd, int N, int HW, int G, float eps, int act, float drop_p,
-                   unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
+                   unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream) {
   const int C = C1 + C2;
   if (!x1 || !gamma || !beta || !y || !mean || !rstd || N <= 0 || HW <= 0 || G <= 0 || C1 <= 0 || C2 < 0 || C % G ||
       (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f)
@@ -362,6 +529,15 @@ int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float
   a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p);
   a.seed = seed; a.seed_dev = seed_dev;
   const bool vec = (HW & 3) == 0 && stk_aligned16(x1) && stk_aligned16(y) && (!x2 || stk_aligned16(x2));
+  if (ws && vec && gn_split_ok(HW, a.cpg)) {
+    const int Sc = HW / GN_CHUNK;
+    const dim3 grid((unsigned)((long)N * C * Sc));
+    hipLaunchKernelGGL(gn_split_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, ws, Sc);
+    STK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_split_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, ws, Sc, y, mean, rstd, eps);
+    STK_CHECK_LAUNCH();
+    return STK_OK;
+  }
   if (vec)
     hipLaunchKernelGGL((gn_fwd_kernel<4>), dim3(N * G), dim3(256), 0, (hipStream_t)stream, a, y, mean, rstd, eps);
   else
@@ -388,7 +564,17 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
   const bool flat = (1 << hw_log2) == HW && HW >= 16 && L <= 16384 && a.cpg <= 512 && stk_aligned16(x1) &&
                     stk_aligned16(dy) && (!x2 || stk_aligned16(x2)) && (!dx1 || stk_aligned16(dx1)) &&
                     (!dx2 || stk_aligned16(dx2));
-  if (flat) {
+  const bool al16 = stk_aligned16(x1) && stk_aligned16(dy) && (!x2 || stk_aligned16(x2)) && (!dx1 || stk_aligned16(dx1)) &&
+                    (!dx2 || stk_aligned16(dx2));
+  if (al16 && gn_split_ok(HW, a.cpg)) {
+    const int Sc = HW / GN_CHUNK;
+    float* part = ws + 2L * N * C;                       // after the [N][C][2] channel sums
+    const dim3 grid((unsigned)((long)N * C * Sc));
+    hipLaunchKernelGGL(gn_split_bwd_part_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, dy, mean, rstd, part, Sc);
+    STK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_split_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, dy, mean, rstd, part, Sc, dx1,
+                       dx1_beta, dx2, dx2_beta, ws);
+  } else if (flat) {
     const int L4 = (int)(L >> 2);
     static const int tgt = getenv("STK_GN_IPT") ? atoi(getenv("STK_GN_IPT")) : 4;
     int T = 64;
@@ -413,6 +599,13 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
     STK_CHECK_LAUNCH();
   }
   return STK_OK;
+}
+
+long stk_gn_ws_bytes(int N, int C, int HW, int G) {
+  if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) return 0;
+  long f = 2L * N * C;                                   // backward: per-(sample, channel) sums
+  if (gn_split_ok(HW, C / G)) f += 2L * N * C * (HW / GN_CHUNK);     // per-chunk partials (forward and backward)
+  return f * 4;
 }
 
 }  // extern "C"

@@ -132,7 +132,7 @@ class GroupNormAct(Op):
     rt.lib.gn_fwd_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
                       rt.v(self.y), rt.v(self.mean), rt.v(self.rstd), self.N, self.HW, self.G, self.eps,
                       self.act, self._p(rt), (rt.seed + 0x9E3779B1 * self.op_id) & 0xFFFFFFFFFFFFFFFF,
-                      rt.seed_dev, rt.stream)
+                      rt.seed_dev, rt.ws, rt.stream)
 
   def backward(self, rt):
     rt.lib.gn_bwd_f32(rt.g(self.y), rt.v(self.x1), self.C1, rt.v(self.x2), self.C2,
@@ -143,7 +143,7 @@ class GroupNormAct(Op):
                       (rt.seed + 0x9E3779B1 * self.op_id) & 0xFFFFFFFFFFFFFFFF, rt.seed_dev, rt.stream)
 
   def ws_bytes(self, lib):
-    return 4 * 2 * self.N * (self.C1 + self.C2)
+    return max(int(lib.gn_ws_bytes(self.N, self.C1 + self.C2, self.HW, self.G)), 4 * 2 * self.N * (self.C1 + self.C2))
 
 
 class Conv(Op):

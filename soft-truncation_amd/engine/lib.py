@@ -29,7 +29,8 @@ SIGNATURES = {
   'stk_upfirdn2d_f32': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, S],
   'stk_upfirdn2d_acc_f32': [P, P, P, F, I, I, I, I, I, I, I, I, I, I, I, I, I, I, S],
   'stk_fused_bias_act_f32': [P, P, P, P, L, I, I, I, I, F, F, S],
-  'stk_gn_fwd_f32': [P, I, P, I, P, P, P, P, P, I, I, I, F, I, F, U64, P, S],
+  'stk_gn_fwd_f32': [P, I, P, I, P, P, P, P, P, I, I, I, F, I, F, U64, P, P, S],
+  'stk_gn_ws_bytes': [I, I, I, I],
   'stk_gn_bwd_f32': [P, P, I, P, I, P, P, P, P, P, F, P, F, P, P, P, I, I, I, I, F, U64, P, S],
   'stk_conv2d_variant': [I, I, I, I, I, I, I, I, I, I, I, I, I, I],
   'stk_conv2d_fwd_ws_bytes': [I, I, I, I, I, I, I, I, I, I],
@@ -60,7 +61,7 @@ SIGNATURES = {
   'stk_dropout_mask_f32': [P, L, F, U64, S],
 }
 _RESTYPE = {'stk_strerror': c_char_p, 'stk_backend': c_char_p, 'stk_conv2d_wgrad_ws_bytes': c_long,
-            'stk_conv2d_fwd_ws_bytes': c_long, 'stk_conv2d_dgrad_ws_bytes': c_long}
+            'stk_conv2d_fwd_ws_bytes': c_long, 'stk_conv2d_dgrad_ws_bytes': c_long, 'stk_gn_ws_bytes': c_long}
 _NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant'}
 
 

@@ -217,6 +217,8 @@ GN_CASES = [
   (1, 256, 256, 16, 32, 1, 0.0),
   (2, 12, 0, 5, 3, 1, 0.0),          # HW = 25: scalar path
   (1, 128, 0, 64, 32, 1, 0.0),
+  (2, 64, 0, 128, 32, 1, 0.1),       # 32 K-element groups: split over workgroups (HW = 4 chunks)
+  (1, 32, 32, 64, 8, 1, 0.0),        # split path, concat input, 8 channels per group
 ]
 
 
@@ -236,10 +238,10 @@ def test_groupnorm(ref_lib, hip_lib, case):
     y, mean, rstd = to(torch.zeros(N, C, H, H)), to(torch.zeros(N * G)), to(torch.zeros(N * G))
     sdev = torch.tensor([17], dtype=torch.int64, device=dev)
     a1, a2, ga, be = to(x1), to(x2), to(gamma), to(beta)
-    call(lib, 'gn_fwd_f32', a1, C1, a2, C2, ga, be, y, mean, rstd, N, HW, G, 1e-6, act, p, seed, sdev)
+    ws = to(torch.zeros(max(int(lib.gn_ws_bytes(N, C, HW, G)) // 4, 2 * N * C)))
+    call(lib, 'gn_fwd_f32', a1, C1, a2, C2, ga, be, y, mean, rstd, N, HW, G, 1e-6, act, p, seed, sdev, ws)
     dx1, dx2 = to(d1.clone()), to(d2.clone()) if C2 else None
     dg, db = to(torch.ones(C)), to(torch.ones(C))
-    ws = to(torch.zeros(2 * N * C))
     call(lib, 'gn_bwd_f32', to(dy), a1, C1, a2, C2, ga, be, mean, rstd, dx1, 0.0, dx2, 1.0, dg, db, ws, N, HW, G, act,
          p, seed, sdev)
     o = {'y': y, 'mean': mean, 'rstd': rstd, 'dx1': dx1, 'dgamma': dg, 'dbeta': db}

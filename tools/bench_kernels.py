@@ -89,19 +89,19 @@ def main():
       rec('conv.wgrad', shape, timeit(lambda: call(lib, 'conv2d_wgrad_f32', x1, C1, x2, C2, dy, dw, 0, 1.0, ws, ws.numel() * 4, *dims), args.reps), flops)
 
   if not args.only or 'gn' in args.only:
-    for C, H in [(128, 32), (256, 16), (256, 8), (384, 32), (512, 16)]:
+    for C, H, Nb in [(128, 32, N), (256, 16, N), (256, 8, N), (384, 32, N), (512, 16, N), (128, 256, 4), (256, 128, 4)]:
       G = 32
-      x = torch.randn(N, C, H, H, device=d)
+      x = torch.randn(Nb, C, H, H, device=d)
       g, b = torch.ones(C, device=d), torch.zeros(C, device=d)
       y = torch.empty_like(x)
-      mean, rstd = torch.empty(N * G, device=d), torch.empty(N * G, device=d)
+      mean, rstd = torch.empty(Nb * G, device=d), torch.empty(Nb * G, device=d)
       dy, dx = torch.randn_like(x), torch.empty_like(x)
       dg, db = torch.zeros(C, device=d), torch.zeros(C, device=d)
-      ws = torch.empty(2 * N * C, device=d)
+      ws = torch.empty(int(lib.gn_ws_bytes(Nb, C, H * H, G)) // 4 + 64, device=d)
       nb = x.numel() * 4
-      shape = f'C{C} @{H}x{H} b{N}'
-      rec('gn_silu.fwd', shape, timeit(lambda: call(lib, 'gn_fwd_f32', x, C, None, 0, g, b, y, mean, rstd, N, H * H, G, 1e-6, 1, 0.1, 1, None), args.reps), nbytes=2 * nb)
-      rec('gn_silu.bwd', shape, timeit(lambda: call(lib, 'gn_bwd_f32', dy, x, C, None, 0, g, b, mean, rstd, dx, 0.0, None, 0.0, dg, db, ws, N, H * H, G, 1, 0.1, 1, None), args.reps), nbytes=3 * nb)
+      shape = f'C{C} @{H}x{H} b{Nb}'
+      rec('gn_silu.fwd', shape, timeit(lambda: call(lib, 'gn_fwd_f32', x, C, None, 0, g, b, y, mean, rstd, Nb, H * H, G, 1e-6, 1, 0.1, 1, None, ws), args.reps), nbytes=2 * nb)
+      rec('gn_silu.bwd', shape, timeit(lambda: call(lib, 'gn_bwd_f32', dy, x, C, None, 0, g, b, mean, rstd, dx, 0.0, None, 0.0, dg, db, ws, Nb, H * H, G, 1, 0.1, 1, None), args.reps), nbytes=3 * nb)
 
   if not args.only or 'misc' in args.only:
     n = N * 256 * 16 * 16
