@@ -869,7 +869,7 @@ inline X3WgradPlan x3_wgrad_plan(int C1, int C2, int N, int Cout, int H, int W, 
   if (K * cmax * 4 >= 0x7fffffffL || (C2 > 0 && C1 % 32)) return q;    // 32-bit buffer offsets; a wave's rows share a tensor
   const bool pow2 = (W & (W - 1)) == 0 && ((H * W) & (H * W - 1)) == 0;
   const bool geom = (KH == 3 && KW == 3 && pad == 1) || (KH == 1 && KW == 1 && pad == 0);
-  if (!geom || stride != 1 || OH != H || OW != W || !pow2 || W < 8 || H * W < 32 || Cin < 64 || Cout < 64 ||
+  if (!geom || stride != 1 || OH != H || OW != W || !pow2 || W < 4 || H * W < 16 || Cin < 64 || Cout < 64 ||
       K > 0x7fffffffL || K % 32)
     return q;
   const int taps = KH * KW;
@@ -1074,12 +1074,13 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
     const int tm = stk_cdiv(Cout, 128), tn = stk_cdiv(p.Cin, 128);
     const int nch = (int)((long)N * p.HW / 32);
     const dim3 grid((unsigned)(p.taps * tm * tn * xq.splits));
-    if (C2 > 0)
-      hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false>, x3::RowsLoader<true, true>, EpWgrad, false>), grid, dim3(256),
-                         0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, p.taps);
-    else
-      hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false>, x3::RowsLoader<true, false>, EpWgrad, false>), grid, dim3(256),
-                         0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, p.taps);
+#define STK_X3_WGRAD(DUAL, SEG)                                                                                      \
+  hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false, SEG>, x3::RowsLoader<true, DUAL, SEG>, EpWgrad, false>), \
+                     grid, dim3(256), 0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, p.taps)
+    if (W >= 16) { if (C2 > 0) STK_X3_WGRAD(true, 16); else STK_X3_WGRAD(false, 16); }
+    else if (W == 8) { if (C2 > 0) STK_X3_WGRAD(true, 8); else STK_X3_WGRAD(false, 8); }
+    else { if (C2 > 0) STK_X3_WGRAD(true, 4); else STK_X3_WGRAD(false, 4); }
+#undef STK_X3_WGRAD
     STK_CHECK_LAUNCH();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid(xq.slab)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
                        xq.slab, alpha, w_layout, Cout, p.Cin, p.taps);

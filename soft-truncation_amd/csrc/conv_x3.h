@@ -190,10 +190,12 @@ struct ActLoader {
 
 // wgrad operands: rows = channels, k = pixels (contiguous in NCHW).  Thread (row = tid>>1, half = tid&1) holds the
 // 16 consecutive pixels k0 + 16*half .. +15 of its channel, shifted by the tap for the x operand.  Requires W a
-// power of two >= 8 and H*W a power of two >= 32, so a 16-pixel run is one row segment (W >= 16) or two rows (W = 8);
-// with a concat input the first source must hold a multiple of 32 channels (a wave's 32 rows share one tensor).
-template <bool SHIFT, bool DUAL>
+// power of two >= 4 and H*W a power of two >= 16; SEG = min(W, 16): a 16-pixel run is 16 / SEG whole row segments.
+// With a concat input the first source must hold a multiple of 32 channels (a wave's 32 rows share one tensor).
+template <bool SHIFT, bool DUAL, int SEG>
 struct RowsLoader {
+  static_assert(SEG == 16 || SEG == 8 || SEG == 4, "row segment of a 16-pixel run");
+  static constexpr int NSEG = 16 / SEG;
   __amdgpu_buffer_rsrc_t rs;
   int rowoff;             // element offset of this thread's channel plane inside image 0 of its tensor
   int bstride;            // elements between images in this thread's tensor
@@ -219,7 +221,7 @@ struct RowsLoader {
   }
   // slice 14 computes the next run's mask and offsets, slices 15..19 issue its loads (all 16 registers were
   // consumed by the conversion slices 0..7); the mask in use by those slices is replaced at slice 14.
-  unsigned o0, o1, o8, o9;
+  unsigned os[NSEG], og[NSEG];      // byte offsets of the first element / of elements 1.. of each row segment
   __device__ __forceinline__ void ld(int g, const ConvP& p, const Src&, int c) {
     if (g == 14) {
       const int k = c * KC + half * 16;              // first pixel of the run (global pixel index)
@@ -229,44 +231,45 @@ struct RowsLoader {
       unsigned m = 0;
       if (!SHIFT) {
         m = 0xffffu;
-      } else if (p.W >= 16) {                        // one row segment
+      } else if (SEG == 16) {                        // one row segment of a row of >= 16 pixels
         const bool yok = (unsigned)(y + dy) < (unsigned)p.H;
         m = yok ? 0xffffu : 0u;
         if (dx < 0 && x0 == 0) m &= ~1u;
         if (dx > 0 && x0 + 16 == p.W) m &= ~0x8000u;
-      } else {                                       // W == 8: two full rows
-        const bool y0 = (unsigned)(y + dy) < (unsigned)p.H, y1 = (unsigned)(y + 1 + dy) < (unsigned)p.H;
-        m = (y0 ? 0x00ffu : 0u) | (y1 ? 0xff00u : 0u);
-        if (dx < 0) m &= ~0x0101u;
-        if (dx > 0) m &= ~0x8080u;
+      } else {                                       // NSEG whole rows of SEG pixels
+#pragma unroll
+        for (int sgi = 0; sgi < NSEG; ++sgi)
+          if ((unsigned)(y + sgi + dy) < (unsigned)p.H) m |= ((1u << SEG) - 1u) << (sgi * SEG);
+        constexpr unsigned FIRST = SEG == 8 ? 0x0101u : 0x1111u;
+        if (dx < 0) m &= ~FIRST;
+        if (dx > 0) m &= ~(FIRST << (SEG - 1));
       }
       okm = kin ? m : 0u;
       // The run is contiguous in memory, but its element offsets may be negative where they are masked: column -1
-      // of the first row of the tensor (element 0; element 8 when W = 8), or the whole first half when W = 8 and
-      // the row above the image is addressed.  A negative voffset plus an immediate is NOT wrapped back into the
-      // buffer by the range check, so the run is read as four pieces -- [0], [1..7], [8], [9..15] -- each from its
+      // of the first row of the tensor (the first element of a segment), or whole leading segments when the row
+      // above the image is addressed.  A negative voffset plus an immediate is NOT wrapped back into the buffer by
+      // the range check, so each segment is read as two pieces -- its first element and the rest -- each from its
       // own offset clamped at 0 (a clamped piece is entirely masked), immediates only inside a piece.  The offsets
       // are made opaque because hipcc otherwise rewrites max(o + 1, 0) * 4 + imm as max(o, -1) * 4 + (imm + 4),
       // i.e. back into the negative-base form.  A run that ends past the tensor reads 0 there (range check).
       const int o = (kin ? b * bstride + rowoff + hw : 0) + dy * p.W + dx;
-      o0 = (unsigned)(max(o, 0) * 4); o1 = (unsigned)(max(o + 1, 0) * 4);
-      o8 = (unsigned)(max(o + 8, 0) * 4); o9 = (unsigned)(max(o + 9, 0) * 4);
-      asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o8), "+v"(o9));
+#pragma unroll
+      for (int sgi = 0; sgi < NSEG; ++sgi) {
+        os[sgi] = (unsigned)(max(o + sgi * SEG, 0) * 4);
+        og[sgi] = (unsigned)(max(o + sgi * SEG + 1, 0) * 4);
+        asm volatile("" : "+v"(os[sgi]), "+v"(og[sgi]));
+      }
     } else if (g == 15) {
-      r[0] = bload(rs, o0, 0);
-      r[8] = bload(rs, o8, 0);
-    } else if (g == 16) {
 #pragma unroll
-      for (int j = 1; j < 5; ++j) r[j] = bload(rs, o1 + (unsigned)(j - 1) * 4u, 0);
-    } else if (g == 17) {
+      for (int sgi = 0; sgi < NSEG; ++sgi) r[sgi * SEG] = bload(rs, os[sgi], 0);
+    } else if (g >= 16 && g < 20) {
+      // the 16 - NSEG remaining elements in four slices: quarter q of every segment's tail
+      const int q = g - 16;
 #pragma unroll
-      for (int j = 5; j < 8; ++j) r[j] = bload(rs, o1 + (unsigned)(j - 1) * 4u, 0);
-    } else if (g == 18) {
-#pragma unroll
-      for (int j = 9; j < 13; ++j) r[j] = bload(rs, o9 + (unsigned)(j - 9) * 4u, 0);
-    } else if (g == 19) {
-#pragma unroll
-      for (int j = 13; j < 16; ++j) r[j] = bload(rs, o9 + (unsigned)(j - 9) * 4u, 0);
+      for (int j = 0; j < 16; ++j) {
+        const int sgi = j / SEG, e = j % SEG;                     // element e >= 1 of segment sgi
+        if (e >= 1 && ((e - 1) * 4) / (SEG - 1) == q) r[j] = bload(rs, og[sgi] + (unsigned)(e - 1) * 4u, 0);
+      }
     }
   }
   __device__ __forceinline__ void st(int g, unsigned char* t) { sp.st(g, r, okm, t, row, half * 16); }
