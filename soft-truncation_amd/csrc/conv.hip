@@ -859,10 +859,10 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
 // Weight gradient on the split kernel: 3x3 / stride 1 / pad 1 or 1x1 / stride 1, power-of-two maps of >= 8 columns and
 // >= 32 pixels, enough channels to fill 128-wide tiles.  One GEMM per tap, K (= pixels) split so that <= 512
 // workgroups run.
-struct X3WgradPlan { int ok; int splits; int chunks_per_split; long slab; };
+struct X3WgradPlan { int ok; int splits; int chunks_per_split; long slab; int rows3; };
 inline X3WgradPlan x3_wgrad_plan(int C1, int C2, int N, int Cout, int H, int W, int OH, int OW, int KH, int KW, int stride,
                                  int pad) {
-  X3WgradPlan q = {0, 0, 0, 0};
+  X3WgradPlan q = {0, 0, 0, 0, 0};
   const int Cin = C1 + C2;
   const long K = (long)N * H * W;
   const int cmax = Cout > C1 ? (Cout > C2 ? Cout : C2) : (C1 > C2 ? C1 : C2);
@@ -873,7 +873,10 @@ inline X3WgradPlan x3_wgrad_plan(int C1, int C2, int N, int Cout, int H, int W, 
       K > 0x7fffffffL || K % 32)
     return q;
   const int taps = KH * KW;
-  const long tiles = (long)taps * stk_cdiv(Cout, 128) * stk_cdiv(Cin, 128);
+  // 3x3 on maps of >= 8 columns: three taps (one kernel row) per workgroup on 128 x 64 tiles (wgrad3_kernel)
+  q.rows3 = (taps == 9 && W >= 8 && (C2 == 0 || C1 % 16 == 0)) ? 1 : 0;
+  const long tiles = q.rows3 ? 3L * stk_cdiv(Cout, 128) * stk_cdiv(Cin, 64)
+                             : (long)taps * stk_cdiv(Cout, 128) * stk_cdiv(Cin, 128);
   // a 1x1 layer with few tiles needs so many K splits that writing / re-reading the partial slabs eats the gain
   // (measured: 256->256 even, 128->256 slower than the f32-input kernel)
   if (taps == 1 && tiles < 6) return q;
@@ -1073,6 +1076,17 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
     x3::Src q = {};
     const int tm = stk_cdiv(Cout, 128), tn = stk_cdiv(p.Cin, 128);
     const int nch = (int)((long)N * p.HW / 32);
+    if (xq.rows3) {
+      const int tn64 = stk_cdiv(p.Cin, 64);
+      const dim3 grid3((unsigned)(3 * tm * tn64 * xq.splits));
+      if (C2 > 0) hipLaunchKernelGGL((x3::wgrad3_kernel<true>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split);
+      else hipLaunchKernelGGL((x3::wgrad3_kernel<false>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split);
+      STK_CHECK_LAUNCH();
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid(xq.slab)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
+                         xq.slab, alpha, w_layout, Cout, p.Cin, p.taps);
+      STK_CHECK_LAUNCH();
+      return STK_OK;
+    }
     const dim3 grid((unsigned)(p.taps * tm * tn * xq.splits));
 #define STK_X3_WGRAD(DUAL, SEG)                                                                                      \
   hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false, SEG>, x3::RowsLoader<true, DUAL, SEG>, EpWgrad, false>), \

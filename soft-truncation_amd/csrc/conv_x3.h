@@ -403,6 +403,189 @@ __global__ __launch_bounds__(256) void gemm_kernel(ConvP p, Src q, int M, int Nn
   }
 }
 
+// ---- 3x3 weight gradient, three taps per workgroup ---------------------------------------------------------------
+// The per-tap GEMM above re-reads and re-splits dy nine times and x nine times.  Here a workgroup owns one kernel ROW
+// (kh) of a 128(co) x 64(ci) block of dw: the three taps kw = 0, 1, 2 read the same x pixels shifted by one, so a
+// thread loads its 8-pixel run plus one pixel on each side ONCE, splits those 10 values once and writes the three
+// shifted windows to LDS; the dy tile is staged once for all three taps.  Per chunk and thread: 26 loads and
+// ~170 VALU for 72 MFMAs per wave (per-tap kernel: 32 loads, ~210 VALU for 48).
+//   A tile  [3 planes][128 co][32 px]            as in gemm_kernel (RowsLoader, unshifted)
+//   B tiles [3 taps][3 planes][64 ci][32 px]     thread (row = tid >> 2, quarter = tid & 3) owns pixels 8q .. 8q + 7
+// Waves: 2 (co halves of 64 rows = 2 MFMA tiles) x 2 (ci halves of 32 = 1 MFMA tile); accumulators acc[2][3 taps].
+// Requires W a power of two >= 8 (an 8-pixel run stays inside one image row), H*W a power of two >= 32.
+constexpr int W3_BPLANE = 64 * PITCH;            // one plane of one tap of the x operand
+constexpr int W3_BTAP = 3 * W3_BPLANE;
+constexpr int W3_LDS = OPER + 3 * W3_BTAP;       // 30720 + 46080 = 76800 bytes -> two workgroups per CU
+
+template <bool DUAL>
+struct Rows3Loader {
+  __amdgpu_buffer_rsrc_t rs;
+  int rowoff, bstride, row, quarter, dy; bool rowok;
+  unsigned okm;            // bit e + 1: element e (-1 .. 8) of the current run is valid
+  float r[10];             // elements -1 .. 8
+  float h[3][10];          // their three bf16 parts (upper halves of these fp32 values)
+  unsigned om, o0, o8;
+  __device__ __forceinline__ void init(const ConvP& p, int n0, int tid, int kh) {
+    row = tid >> 2; quarter = tid & 3; dy = kh - 1; okm = 0;
+    const int ch = n0 + row;
+    rowok = ch < p.Cin;
+    const int c = rowok ? ch : 0;
+    const bool first = !DUAL || __builtin_amdgcn_readfirstlane(n0 + (tid >> 6) * 16) < p.C1;   // wave-uniform
+    rs = first ? make_rsrc(p.x1, (long)p.N * p.C1 * p.HW * 4) : make_rsrc(p.x2, (long)p.N * p.C2 * p.HW * 4);
+    rowoff = (first ? c : (c >= p.C1 ? c - p.C1 : 0)) * p.HW;
+    bstride = (first ? p.C1 : p.C2) * p.HW;
+  }
+  // slices 0..4 split two elements each, 5..13 pack + write one (tap, plane) window each
+  __device__ __forceinline__ void st(int g, unsigned char* t) {
+    if (g < 5) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = 2 * g + u;
+        const float v = igemm::keep_if(r[e], okm, e);
+        const float r1 = v - hi_part(v);
+        h[0][e] = v; h[1][e] = r1; h[2][e] = r1 - hi_part(r1);
+      }
+    } else if (g < 14) {
+      const int tap = (g - 5) / 3, s = (g - 5) % 3;          // window of tap kw: elements kw - 1 .. kw + 6 -> h[kw .. kw + 7]
+      unsigned char* d = t + tap * W3_BTAP + s * W3_BPLANE + row * PITCH + quarter * 16;
+      *reinterpret_cast<u32x4*>(d) = u32x4{pack_hi(h[s][tap], h[s][tap + 1]), pack_hi(h[s][tap + 2], h[s][tap + 3]),
+                                           pack_hi(h[s][tap + 4], h[s][tap + 5]), pack_hi(h[s][tap + 6], h[s][tap + 7])};
+    }
+  }
+  // slice 14: mask and offsets of the next run; 15: the two halo elements; 16, 17: the eight pixels of the run
+  __device__ __forceinline__ void ld(int g, const ConvP& p, int c) {
+    if (g == 14) {
+      const int k = c * KC + quarter * 8;
+      const bool kin = rowok && k < p.N * p.HW;
+      const int b = k >> p.ohw_shift, hw = k & (p.HW - 1);
+      const int y = hw >> p.ow_shift, x0 = hw & (p.W - 1);
+      unsigned m = (unsigned)(y + dy) < (unsigned)p.H ? 0x3ffu : 0u;
+      if (x0 == 0) m &= ~1u;                       // column -1
+      if (x0 + 8 == p.W) m &= ~0x200u;             // column W
+      okm = kin ? m : 0u;
+      // offsets clamped at 0 and opaque, pieces [-1], [0..7], [8]: see RowsLoader
+      const int o = (kin ? b * bstride + rowoff + hw : 0) + dy * p.W;
+      om = (unsigned)(max(o - 1, 0) * 4); o0 = (unsigned)(max(o, 0) * 4); o8 = (unsigned)(max(o + 8, 0) * 4);
+      asm volatile("" : "+v"(om), "+v"(o0), "+v"(o8));
+    } else if (g == 15) {
+      r[0] = bload(rs, om, 0);
+      r[9] = bload(rs, o8, 0);
+    } else if (g == 16 || g == 17) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[1 + (g - 16) * 4 + j] = bload(rs, o0 + (unsigned)((g - 16) * 4 + j) * 4u, 0);
+    }
+  }
+};
+
+template <bool DUAL>
+__global__ __launch_bounds__(256) void wgrad3_kernel(ConvP p, int tiles_m, int tiles_n, int nchunks_total,
+                                                     int chunks_per_split) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[W3_LDS];
+  unsigned char* As = lds;
+  unsigned char* Bs = lds + OPER;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int ntiles = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);       // kernel row fastest: the three blocks share dy / x panels
+  const int kh = id % 3;
+  const int rest = id / 3;
+  const int tile = rest % ntiles;
+  const int zs = rest / ntiles;
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int m0 = tm * 128, n0 = tn * 64;
+  const int c_begin = zs * chunks_per_split;
+  const int c_last = min(nchunks_total, c_begin + chunks_per_split) - 1;
+
+  Src q = {};
+  RowsLoader<false, false, 16> al;
+  Rows3Loader<DUAL> bl;
+  al.init(p, q, m0, tid, 4);
+  bl.init(p, n0, tid, kh);
+
+  floatx16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.f;
+
+  const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 32;
+  const int fk = lane >> 5, fc = lane & 31;
+  const unsigned char* a_rd = As + (wm0 + fc) * PITCH + fk * 16;
+  const unsigned char* b_rd = Bs + (wn0 + fc) * PITCH + fk * 16;
+
+#define STK_W3_FRAGS(KK)                                                                                   \
+  _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+      a[i][s] = *reinterpret_cast<const bf16x8*>(a_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);             \
+    _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                            \
+      b[t][s] = *reinterpret_cast<const bf16x8*>(b_rd + t * W3_BTAP + s * W3_BPLANE + (KK) * 32);            \
+  }
+  constexpr int SA[6] = {2, 1, 0, 1, 0, 0}, SB[6] = {0, 1, 2, 0, 1, 0};
+#define STK_W3_MFMAS                                                                                       \
+  _Pragma("unroll") for (int pr = 0; pr < 6; ++pr) _Pragma("unroll") for (int i = 0; i < 2; ++i)              \
+    _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                            \
+      acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][SA[pr]], b[t][SB[pr]], acc[i][t], 0, 0, 0);
+
+#pragma unroll
+  for (int g = 0; g < 24; ++g) { al.ld(g, p, q, c_begin); bl.ld(g, p, c_begin); }
+  {
+    const int c1 = min(c_begin + 1, c_last);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) { al.st(g, As); bl.st(g, Bs); }
+#pragma unroll
+    for (int g = 0; g < 24; ++g) { al.ld(g, p, q, c1); bl.ld(g, p, c1); }
+  }
+  bf16x8 a[2][3], b[3][3];
+  for (int c = c_begin; c < c_last; ++c) {
+    __syncthreads();                                   // chunk c is in LDS
+    STK_W3_FRAGS(0)
+    STK_W3_MFMAS
+    STK_W3_FRAGS(1)
+    __syncthreads();                                   // nobody reads LDS any more
+    const int c2 = min(c + 2, c_last);
+    STK_W3_MFMAS
+#pragma unroll
+    for (int g = 0; g < 24; ++g) al.st(g, As);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) bl.st(g, Bs);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) al.ld(g, p, q, c2);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) bl.ld(g, p, c2);
+#pragma unroll
+    for (int g = 0; g < 36; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);     // VALU
+      if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+    }
+  }
+  __syncthreads();
+  STK_W3_FRAGS(0)
+  STK_W3_MFMAS
+  STK_W3_FRAGS(1)
+  STK_W3_MFMAS
+#undef STK_W3_MFMAS
+#undef STK_W3_FRAGS
+
+  // partial slab of split zs as [tap][Cout][Cin] (lanes = ci, contiguous); splitk_reduce_kernel re-lays it out
+  float* slab = p.part + (long)zs * p.part_stride;
+  const int n = n0 + wn0 + fc;
+  if (n < p.Cin) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm0 + i * 32 + 4 * fk + igemm::strip_row(e);
+          if (m < p.Cout) slab[((long)(kh * 3 + t) * p.Cout + m) * p.Cin + n] = acc[i][t][e];
+        }
+  }
+}
+
 inline int pad128(int v) { return (v + 127) / 128 * 128; }
 // bytes of prepared weights for an M x Kc layer
 inline long wp_bytes(int M, int Kc, int taps) { return 3L * taps * pad128(M) * Kc * 2; }
