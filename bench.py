@@ -68,6 +68,10 @@ def kernel_peak(kind):
 TRAIN_FLOPS_PER_IMG = {'cifar10_ddpmpp_nll_st': 65.072e9, 'imagenet32_ddpmpp_st': 65.072e9,
                        'celeba_uncsnpp_st': 252.128e9, 'celebahq_uncsnpp_st': 1598.169e9}
 
+# forward activation traffic A_f of the fused model; a training step moves ~3 A_f per image
+TRAIN_HBM_BYTES_PER_IMG = {'cifar10_ddpmpp_nll_st': 3 * 126.2e6, 'imagenet32_ddpmpp_st': 3 * 126.2e6,
+                           'celeba_uncsnpp_st': 3 * 459.2e6, 'celebahq_uncsnpp_st': 3 * 3796.5e6}
+
 WORKLOADS = {
   # name -> (config factory name, per-GPU batch, description)
   'cifar10': ('cifar10_ddpmpp_nll_st', 128, 'DDPM++ (VP) CIFAR-10 32x32, configs/vp/CIFAR10/ddpmpp_nll_st.py (BASELINE configs[1])'),
@@ -89,6 +93,7 @@ def parse():
   ap.add_argument('--prof-steps', type=int, default=3)
   ap.add_argument('--cpu-batch', type=int, default=8)
   ap.add_argument('--cpu-steps', type=int, default=5)
+  ap.add_argument('--sampler-steps', type=int, default=6, help='PC-sampler iterations timed after the training steps (0 = skip)')
   return ap.parse_args()
 
 
@@ -119,6 +124,28 @@ def cpu_baseline(st, cfg_name, batch, steps):
           'sample': f'{cfg_name} full-size model, batch {batch}, median of {steps} training steps after 1 warm-up '
                     f'(oracle/ref_torch.RefNet + torch.optim.Adam + EMA, PyTorch CPU fp32)',
           'sec_per_step': med}
+
+
+def sampler_rate(st, cfg, sde, score_model, batch, steps, device):
+  """Score evaluations per second of the config's own sampler: `steps` iterations of
+  sampling.get_sampling_fn(...) on a batch of `batch` images (the reverse-time grid is shortened to `steps`
+  points; every iteration runs the same corrector + predictor network evaluations as the full-length run)."""
+  import copy
+  sde_s = copy.copy(sde)
+  sde_s.N = steps
+  shape = (batch, cfg.data.num_channels, cfg.data.image_size, cfg.data.image_size)
+  inverse_scaler = st.datasets.get_data_inverse_scaler(cfg)
+  fn = st.sampling.get_sampling_fn(cfg, sde_s, shape, inverse_scaler, 1e-3 if cfg.training.sde == 'vpsde' else 1e-5)
+  fn(score_model)                                   # warm-up (builds the inference program, captures its graph)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  _, nfe = fn(score_model)
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  evals = nfe + 1                                   # + the denoising evaluation at t = eps
+  return {'score_evals_per_s': evals / dt, 'image_evals_per_s': evals * batch / dt, 'batch': batch, 'iterations': steps,
+          'network_evals': evals, 'method': cfg.sampling.method, 'predictor': cfg.sampling.predictor,
+          'corrector': cfg.sampling.corrector, 'ms_per_eval': 1e3 * dt / evals}
 
 
 def main():
@@ -222,6 +249,17 @@ def main():
         out['kernels'] = {k: {'tflops': round(v['tflops'], 2), 'frac_of_peak': round(v['tflops'] / kernel_peak(k), 3),
                               'avg_us': round(v['avg_us'], 1), 'launches': v['count'],
                               'total_ms_per_step': round(v['total_ms'] / max(args.prof_steps, 1), 3)} for k, v in summ.items()}
+    hbm_bytes = TRAIN_HBM_BYTES_PER_IMG.get(cfg_name)
+    if hbm_bytes is not None:
+      gbs = (hbm_bytes * per_gpu_batch + 16.0 * 4 * score_model.module.engine().flat.data.numel()) * (args.steps / elapsed) / 1e9
+      out['step_roofline'].update({'hbm_algorithmic_GBps': gbs, 'frac_hbm': gbs / 8000.0,
+                                   'hbm_note': 'SURVEY.md 8(d) fused-traffic model: 3 x A_f bytes per image + 16 x 4 B per '
+                                               'parameter per step, against 8 TB/s'})
+    if args.sampler_steps > 0:
+      try:
+        out['sampler'] = sampler_rate(st, cfg, sde, score_model, per_gpu_batch, args.sampler_steps, device)
+      except Exception as e:                         # the reference's RVE sampling raises: report, do not fail
+        out['sampler'] = {'error': repr(e)[:200]}
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(st, cfg_name, args.cpu_batch, args.cpu_steps)
     print(json.dumps(out), flush=True)

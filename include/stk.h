@@ -158,7 +158,9 @@ int stk_softmax_bwd_f32(const float* y, const float* dy, float* dx, long rows, i
 /* y = x*sigmoid(x);  dx = beta*dx + dy * sig(x)*(1 + x*(1-sig(x))) */
 int stk_silu_fwd_f32(const float* x, float* y, long n, void* stream);
 int stk_silu_bwd_f32(const float* x, const float* dy, float* dx, float beta, long n, void* stream);
-/* out = alpha*a + beta*b   (b may be NULL -> treated as 0; out may alias a or b) */
+/* out = alpha*a + beta*b   (b may be NULL -> treated as 0; out may alias a or b).
+ * Every `beta` of this header follows the same rule: beta == 0 means the accumulated operand is NOT READ (it may be
+ * uninitialised memory), never multiplied by zero. */
 int stk_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out, long n, void* stream);
 /* out = (a + b) * (1.f/div)  -- the skip_rescale combine (x + h)/sqrt(2), models/layerspp.py:104,287 */
 int stk_add_div_f32(const float* a, const float* b, float div, float* out, long n, void* stream);

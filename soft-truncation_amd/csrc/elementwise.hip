@@ -76,7 +76,7 @@ struct Axpby {
   const float* a; float alpha; const float* b; float beta; float* out;
   template <int V> __device__ void run(long i) const {
     auto x = Vec<V>::load(a, i);
-    if (b) {
+    if (b && beta != 0.f) {          // beta == 0: b is not read (it may be uninitialised memory; 0 * NaN = NaN)
       auto y = Vec<V>::load(b, i);
 #pragma unroll
       for (int j = 0; j < V; ++j) x.v[j] = alpha * x.v[j] + beta * y.v[j];

@@ -24,6 +24,17 @@ import warnings
 import torch
 
 from . import lib as stk_lib
+
+# STK_POISON=1 (debugging aid): fill every arena with NaN when it is allocated, so that an op reading memory that no
+# op has written shows up as NaN in the output instead of depending on what the allocator hands back.
+_POISON = os.environ.get('STK_POISON', '0') == '1'
+
+
+def _arena(n, device):
+  t = torch.empty(max(n, 1), dtype=torch.float32, device=device)
+  if _POISON:
+    t.fill_(float('nan'))
+  return t
 from .flat import FlatParams
 from .graph import Graph, Runtime
 
@@ -34,7 +45,7 @@ class Context:
 
   def __init__(self, prog):
     self.prog = prog
-    self.act = torch.empty(max(prog.graph.act_size, 1), dtype=torch.float32, device=prog.device)
+    self.act = _arena(prog.graph.act_size, prog.device)
     self.gact = None
     self.rt = None
     self.released = False
@@ -53,7 +64,7 @@ class Program:
     for off, arr in graph.const_chunks:
       const[off:off + arr.size] = torch.from_numpy(arr)
     self.const = const.to(device)
-    self.ws = torch.empty(graph.ws_bytes // 4, dtype=torch.float32, device=device)
+    self.ws = _arena(graph.ws_bytes // 4, device)
     self.free = []
 
   def acquire(self):
@@ -199,7 +210,7 @@ class Executor:
       if c.seed_t is None:
         c.seed_t = torch.zeros(1, dtype=torch.int64, device=flat.device)
       if c.gact is None and torch.is_grad_enabled():
-        c.gact = torch.empty(max(g.gact_size, 1), dtype=torch.float32, device=prog.device)
+        c.gact = _arena(g.gact_size, prog.device)
       c.seed_t.fill_(seed)
       done = self._replay(c, 'fwd', training)
       if done:
@@ -217,7 +228,7 @@ class Executor:
     prog, g, rt = c.prog, c.prog.graph, c.rt
     flat = self.flat
     if c.gact is None:
-      c.gact = torch.empty(max(g.gact_size, 1), dtype=torch.float32, device=prog.device)
+      c.gact = _arena(g.gact_size, prog.device)
     o = g.output
     c.gact[o.goff:o.goff + o.numel].view(o.shape).copy_(gout)
     done = False

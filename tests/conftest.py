@@ -2,6 +2,11 @@ import os
 import subprocess
 import sys
 
+import os
+
+# every engine arena starts as NaN in the tests: an op that reads memory nobody wrote fails loudly (engine/executor.py)
+os.environ.setdefault('STK_POISON', '1')
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

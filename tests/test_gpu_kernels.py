@@ -123,6 +123,8 @@ def test_elementwise(ref_lib, hip_lib, n):
     z = to(torch.zeros(n)); call(lib, 'axpby_f32', to(a), 1.5, to(b), -0.25, z, n); o['axpby'] = z
     z2 = to(torch.zeros(n)); call(lib, 'axpby_f32', to(a), 0.7, None, 0.0, z2, n); o['ax'] = z2
     z3 = to(b.clone()); call(lib, 'axpby_f32', to(a), 0.7, z3, 1.0, z3, n); o['axpby_alias'] = z3
+    # beta == 0: the accumulated operand must not be read (0 * NaN would poison the result)
+    z4 = to(torch.full((n,), float('nan'))); call(lib, 'axpby_f32', to(a), 0.7, z4, 0.0, z4, n); o['axpby_beta0'] = z4
     w = to(torch.zeros(n)); call(lib, 'add_div_f32', to(a), to(b), float(np.float32(np.sqrt(2.))), w, n); o['add_div'] = w
     w1 = to(torch.zeros(n)); call(lib, 'add_div_f32', to(a), to(b), 1.0, w1, n); o['add'] = w1
     v = to(torch.zeros(n)); call(lib, 'affine_f32', to(a), 2.0, -1.0, v, n); o['affine'] = v
