@@ -208,6 +208,11 @@ int stk_adam_f32(float* p, float* g, float* m, float* v, long n,
                  float bc1, float bc2, const float* sumsq, float max_norm, void* stream);
 int stk_ema_f32(float* shadow, const float* p, long n, float one_minus_decay, void* stream);
 
+/* Sample post-processing, replaces `np.clip(samples.permute(0,2,3,1).cpu().numpy() * 255., 0, 255).astype(np.uint8)`
+ * (sampling_lib.py:43): out[n, hw, c] = uint8(clip(255 * x[n, c, hw], 0, 255)), float NCHW -> uint8 NHWC on the device,
+ * so that 1/4 of the bytes cross PCIe. */
+int stk_samples_to_uint8(const float* x, unsigned char* out, int N, int C, long HW, void* stream);
+
 /* Counter-based RNG shared by both libraries so dropout masks are reproducible across them:
  * u(seed, i) in [0,1) from a 64-bit mix of (seed, i); keep iff u >= p.
  * stk_dropout_mask_f32 materialises mask[i] = keep ? 1/(1-p) : 0 (debug / oracle use). */

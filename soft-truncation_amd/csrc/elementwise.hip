@@ -324,6 +324,30 @@ int stk_perturb_f32(const float* x, const float* z, const float* a, const float*
   return launch_ew((long)N * inner, v, Perturb{x, z, a, s, out, inner}, S(stream));
 }
 
+// Sample post-processing (sampling_lib.py:43-44): out[n, hw, c] = uint8(clip(255 * x[n, c, hw], 0, 255)), NCHW -> NHWC.
+// One thread per pixel: C strided reads (coalesced across the lanes of a wave), C contiguous bytes written.
+__global__ __launch_bounds__(256) void to_uint8_nhwc_kernel(const float* __restrict__ x, unsigned char* __restrict__ out,
+                                                            long npix, int C, long HW) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += stride) {
+    const long n = i / HW, hw = i - n * HW;
+    const float* p = x + n * C * HW + hw;
+    unsigned char* o = out + i * C;
+    for (int c = 0; c < C; ++c) {
+      const float v = fminf(fmaxf(p[(long)c * HW] * 255.f, 0.f), 255.f);
+      o[c] = (unsigned char)v;                 // truncation, like numpy's astype(uint8) on a clipped float
+    }
+  }
+}
+
+int stk_samples_to_uint8(const float* x, unsigned char* out, int N, int C, long HW, void* stream) {
+  if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return STK_EINVAL;
+  const long npix = (long)N * HW;
+  hipLaunchKernelGGL(to_uint8_nhwc_kernel, dim3(stk_ew_grid(npix)), dim3(256), 0, S(stream), x, out, npix, C, HW);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+
 int stk_dropout_mask_f32(float* mask, long n, float p, unsigned long long seed, void* stream) {
   if (!mask || n < 0 || p < 0.f || p >= 1.f) return STK_EINVAL;
   return launch_ew(n, stk_aligned16(mask), DropMask{mask, p, 1.f / (1.f - p), seed}, S(stream));

@@ -2,8 +2,6 @@ import os
 import subprocess
 import sys
 
-import os
-
 # every engine arena starts as NaN in the tests: an op that reads memory nobody wrote fails loudly (engine/executor.py)
 os.environ.setdefault('STK_POISON', '1')
 

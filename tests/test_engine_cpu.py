@@ -66,3 +66,20 @@ def test_device_rk45_matches_scipy():
                                 rtol=rtol, atol=atol)
     assert nfev == sol.nfev
     assert np.abs(sol.y[:, -1] - y.numpy()).max() < 1e-11
+
+
+def test_sample_postprocessing_on_checker(st, ref_lib, tmp_path):
+  """sampling_lib: uint8 NHWC conversion == the reference's numpy expression (sampling_lib.py:43), grid layout ==
+  torchvision.make_grid(nrow, padding=2) restated, npz round trip."""
+  import numpy as np
+  import torch
+  g = torch.Generator().manual_seed(3)
+  x = torch.rand(10, 3, 8, 8, generator=g) * 1.2 - 0.1            # some values outside [0, 1]
+  got = st.sampling_lib.samples_to_uint8(x, backend=ref_lib)
+  want = np.clip(x.permute(0, 2, 3, 1).numpy() * 255., 0, 255).astype(np.uint8)
+  assert got.dtype == np.uint8 and got.shape == (10, 8, 8, 3)
+  assert np.array_equal(got, want)
+  grid = st.sampling_lib.make_grid_uint8(want, nrow=3, padding=2)
+  assert grid.shape == (4 * 10 + 2, 3 * 10 + 2, 3)
+  assert np.array_equal(grid[2:10, 2:10], want[0]) and np.array_equal(grid[12:20, 22:30], want[5])
+  assert not grid[:2].any() and not grid[:, :2].any() and not grid[32:40, 12:].any()   # padding and the empty cells

@@ -456,3 +456,27 @@ def test_optimizer_kernels(ref_lib, hip_lib, n):
     return o
 
   compare(both(ref_lib, hip_lib, fn), 2e-5, 'optimizer')
+
+
+# ---------------------------------------------------------------------------------------------------
+# sample post-processing (sampling_lib.py:36-57)
+# ---------------------------------------------------------------------------------------------------
+def test_samples_to_uint8_and_get_samples(st, ref_lib, hip_lib, tmp_path):
+  x = rnd(37, 3, 32, 32, seed=5) * 0.4 + 0.5
+  want = np.clip(x.permute(0, 2, 3, 1).numpy() * 255., 0, 255).astype(np.uint8)
+  assert np.array_equal(st.sampling_lib.samples_to_uint8(x, backend=ref_lib), want)
+  assert np.array_equal(st.sampling_lib.samples_to_uint8(x.to(dev_of(hip_lib))), want)       # bit-exact on the device
+
+  cfg = st.configs.get_config('cifar10_ddpmpp_nll_st')
+  calls = []
+
+  def sampling_fn(model):
+    calls.append(1)
+    return x[:16].to(dev_of(hip_lib)), 7
+
+  out = st.sampling_lib.get_samples(cfg, None, None, sampling_fn, step=3, r=0, sample_dir=str(tmp_path))
+  assert np.array_equal(out, want[:16])
+  d = st.sampling_lib.get_dir_name(cfg, str(tmp_path), 3)
+  assert np.array_equal(np.load(d + '/samples_0.npz')['samples'], want[:16])
+  again = st.sampling_lib.get_samples(cfg, None, None, sampling_fn, step=3, r=0, sample_dir=str(tmp_path))
+  assert len(calls) == 1 and np.array_equal(again, out)          # second call reads the file, as the reference does
