@@ -213,6 +213,12 @@ int stk_ema_f32(float* shadow, const float* p, long n, float one_minus_decay, vo
  * so that 1/4 of the bytes cross PCIe. */
 int stk_samples_to_uint8(const float* x, unsigned char* out, int N, int C, long HW, void* stream);
 
+/* Input-pipeline tail on the device (datasets.py:313-324, run_lib.py:72-75): uint8 NHWC images -> float NCHW batch.
+ *   v = u8 * (1/255);  flip != 0: image n is mirrored left-right iff stk_uniform(seed ^ 0x5DEECE66D, n) < 0.5;
+ *   dequant != 0: v = (255 v + stk_uniform(seed, output element index)) / 256;  centered != 0: v = 2 v - 1. */
+int stk_preprocess_u8(const unsigned char* img, float* out, int N, int C, int H, int W, int flip, int dequant,
+                      int centered, unsigned long long seed, void* stream);
+
 /* Counter-based RNG shared by both libraries so dropout masks are reproducible across them:
  * u(seed, i) in [0,1) from a 64-bit mix of (seed, i); keep iff u >= p.
  * stk_dropout_mask_f32 materialises mask[i] = keep ? 1/(1-p) : 0 (debug / oracle use). */

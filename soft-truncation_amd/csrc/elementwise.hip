@@ -348,6 +348,38 @@ int stk_samples_to_uint8(const float* x, unsigned char* out, int N, int C, long 
   return STK_OK;
 }
 
+// Input pipeline tail on the device (datasets.py:313-324 + run_lib.py:72-75): uint8 NHWC image -> float NCHW batch,
+//   v = u8 / 255 (tf.image.convert_image_dtype);  per-image random horizontal flip;  uniform dequantisation
+//   v = (255 v + u) / 256, u ~ U[0,1);  scaler 2v - 1 when the data is centred.
+// One thread per output pixel; the draws are pure functions of (seed, image index) / (seed, output element index).
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
+                                                            int N, int C, int H, int W, int flip, int dequant,
+                                                            int centered, unsigned long long seed) {
+  const long HW = (long)H * W, npix = (long)N * HW, stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += stride) {
+    const long n = i / HW, hw = i - n * HW;
+    const int y = (int)(hw / W), x = (int)(hw - (long)y * W);
+    const bool f = flip && stk_uniform(seed ^ 0x5DEECE66DULL, (unsigned long long)n) < 0.5f;
+    const unsigned char* p = img + ((n * H + y) * W + (f ? W - 1 - x : x)) * C;
+    for (int c = 0; c < C; ++c) {
+      const long o = (n * C + c) * HW + hw;
+      float v = (float)p[c] * (1.f / 255.f);
+      if (dequant) v = (255.f * v + stk_uniform(seed, (unsigned long long)o)) * (1.f / 256.f);
+      if (centered) v = v * 2.f - 1.f;
+      out[o] = v;
+    }
+  }
+}
+
+int stk_preprocess_u8(const unsigned char* img, float* out, int N, int C, int H, int W, int flip, int dequant,
+                      int centered, unsigned long long seed, void* stream) {
+  if (!img || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return STK_EINVAL;
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(stk_ew_grid((long)N * H * W)), dim3(256), 0, S(stream), img, out, N, C, H,
+                     W, flip, dequant, centered, seed);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+
 int stk_dropout_mask_f32(float* mask, long n, float p, unsigned long long seed, void* stream) {
   if (!mask || n < 0 || p < 0.f || p >= 1.f) return STK_EINVAL;
   return launch_ew(n, stk_aligned16(mask), DropMask{mask, p, 1.f / (1.f - p), seed}, S(stream));

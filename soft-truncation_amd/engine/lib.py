@@ -60,6 +60,7 @@ SIGNATURES = {
   'stk_ema_f32': [P, P, L, F, S],
   'stk_dropout_mask_f32': [P, L, F, U64, S],
   'stk_samples_to_uint8': [P, P, I, I, L, S],
+  'stk_preprocess_u8': [P, P, I, I, I, I, I, I, I, U64, S],
 }
 _RESTYPE = {'stk_strerror': c_char_p, 'stk_backend': c_char_p, 'stk_conv2d_wgrad_ws_bytes': c_long,
             'stk_conv2d_fwd_ws_bytes': c_long, 'stk_conv2d_dgrad_ws_bytes': c_long, 'stk_gn_ws_bytes': c_long}

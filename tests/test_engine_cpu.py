@@ -83,3 +83,26 @@ def test_sample_postprocessing_on_checker(st, ref_lib, tmp_path):
   assert grid.shape == (4 * 10 + 2, 3 * 10 + 2, 3)
   assert np.array_equal(grid[2:10, 2:10], want[0]) and np.array_equal(grid[12:20, 22:30], want[5])
   assert not grid[:2].any() and not grid[:, :2].any() and not grid[32:40, 12:].any()   # padding and the empty cells
+
+
+def test_device_batch_on_checker(st, ref_lib):
+  """datasets.device_batch == convert_image_dtype + flip + (255 x + u) / 256 + scaler (datasets.py:313-324,
+  run_lib.py:72-75): exact without the random parts; with them, every image is the original or its mirror and the
+  dequantisation noise is U[0,1) per element."""
+  import numpy as np
+  import torch
+  g = torch.Generator().manual_seed(11)
+  img = torch.randint(0, 256, (64, 8, 8, 3), generator=g, dtype=torch.uint8)
+  cfg = st.configs.get_config('cifar10_ddpmpp_nll_st')          # centred, random_flip, no dequantisation
+  plain = img.permute(0, 3, 1, 2).float() * (1.0 / 255.0)
+  out = st.datasets.device_batch(cfg, img, seed=5, evaluation=True, backend=ref_lib)
+  assert torch.equal(out, plain * 2. - 1.)
+  out = st.datasets.device_batch(cfg, img, seed=5, backend=ref_lib)
+  same = (out == plain * 2. - 1.).flatten(1).all(1)
+  mirrored = (out == (plain * 2. - 1.).flip(3)).flatten(1).all(1)
+  assert bool((same | mirrored).all()) and 10 < int(mirrored.sum()) < 54          # about half of the images flip
+  cfg.data.dequantization, cfg.data.random_flip, cfg.data.centered = 'uniform', False, False
+  out = st.datasets.device_batch(cfg, img, seed=9, backend=ref_lib)
+  u = out * 256. - 255. * plain
+  assert float(u.min()) > -1e-4 and float(u.max()) < 1. + 1e-4 and abs(float(u.mean()) - 0.5) < 0.02
+  assert not torch.equal(out, st.datasets.device_batch(cfg, img, seed=10, backend=ref_lib))

@@ -480,3 +480,16 @@ def test_samples_to_uint8_and_get_samples(st, ref_lib, hip_lib, tmp_path):
   assert np.array_equal(np.load(d + '/samples_0.npz')['samples'], want[:16])
   again = st.sampling_lib.get_samples(cfg, None, None, sampling_fn, step=3, r=0, sample_dir=str(tmp_path))
   assert len(calls) == 1 and np.array_equal(again, out)          # second call reads the file, as the reference does
+
+
+def test_preprocess_u8(st, ref_lib, hip_lib):
+  """Device input-pipeline tail: bit-identical to the checker (shared counter RNG), all four flag combinations."""
+  g = torch.Generator().manual_seed(2)
+  img = torch.randint(0, 256, (33, 16, 12, 3), generator=g, dtype=torch.uint8)
+  cfg = st.configs.get_config('cifar10_ddpmpp_nll_st')
+  for dequant, flip, centered in ((False, False, True), (True, True, False), (True, False, True), (False, True, False)):
+    cfg.data.dequantization = 'uniform' if dequant else 'none'
+    cfg.data.random_flip, cfg.data.centered = flip, centered
+    a = st.datasets.device_batch(cfg, img, seed=1234, backend=ref_lib)
+    b = st.datasets.device_batch(cfg, img.to(dev_of(hip_lib)), seed=1234)
+    assert torch.equal(a, b.cpu())
