@@ -96,6 +96,7 @@ def load():
     ns.ema = importlib.import_module('models.ema')
     ns.losses = importlib.import_module('losses')
     ns.sampling = importlib.import_module('sampling')
+    ns.likelihood = importlib.import_module('likelihood')
     ns.config_module = lambda dotted: importlib.import_module(dotted)
     ns.modules = {k: v for k, v in sys.modules.items()
                   if k.split('.')[0] in saved and v is not None}

@@ -17,14 +17,16 @@ from . import op
 from .models import utils as _mutils  # noqa: F401
 from .models import ema, layers, layerspp, ncsnpp, up_or_down_sampling  # noqa: F401
 from . import models
-from . import losses, sampling, sampling_lib, utils
+from . import likelihood, losses, sampling, sampling_lib, utils
 
-__all__ = ['configs', 'datasets', 'sde_lib', 'op', 'models', 'losses', 'sampling', 'sampling_lib', 'utils', 'install']
+__all__ = ['configs', 'datasets', 'sde_lib', 'op', 'models', 'likelihood', 'losses', 'sampling', 'sampling_lib', 'utils',
+           'install']
 
 # name the reference's modules import under -> our module
 _REFERENCE_NAMES = {
   'sde_lib': sde_lib,
   'losses': losses,
+  'likelihood': likelihood,
   'sampling': sampling,
   'utils': utils,
   'op': op,

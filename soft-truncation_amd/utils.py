@@ -5,7 +5,7 @@
 ``ema.shadow_params`` as a list of tensors -- so checkpoints are interchangeable.
 ``load_model`` and ``get_loss_fns`` reproduce what ``run_lib.train`` calls before its loop
 (run_lib.py:51-66).  The TensorFlow file API of the reference (``tf.io.gfile``) is replaced by
-``os``; likelihood evaluators are outside the hot path and are not provided.
+``os``.
 """
 import logging
 import os
@@ -13,7 +13,7 @@ import os
 import numpy as np
 import torch
 
-from . import losses, sampling
+from . import likelihood, losses, sampling
 from .models import utils as mutils
 from .models.ema import ExponentialMovingAverage
 
@@ -62,12 +62,13 @@ def load_model(config, workdir, print_=True, sde=None):
 
 
 def get_loss_fns(config, sde, inverse_scaler, train=True):
-  """(train_step_fn, nll_fn, nelbo_fn, sampling_fn) as in utils.py:75-82; the two likelihood
-  evaluators belong to likelihood.py (outside this path) and are returned as None."""
+  """(train_step_fn, nll_fn, nelbo_fn, sampling_fn) as in utils.py:75-82."""
   optimize_fn = losses.optimization_manager(config)
   train_step_fn = losses.get_step_fn(config, sde, train=train, optimize_fn=optimize_fn)
   sampling_shape = (config.sampling.batch_size, config.data.num_channels,
                     config.data.image_size, config.data.image_size)
   sampling_fn = sampling.get_sampling_fn(config, sde, sampling_shape, inverse_scaler,
                                          config.sampling.truncation_time)
-  return train_step_fn, None, None, sampling_fn
+  nll_fn = likelihood.get_likelihood_fn(config, sde, inverse_scaler)
+  nelbo_fn = likelihood.get_elbo_fn(config, sde, inverse_scaler=inverse_scaler)
+  return train_step_fn, nll_fn, nelbo_fn, sampling_fn

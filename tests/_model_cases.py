@@ -217,3 +217,68 @@ def golden_forward_backward(st, lib, family):
   model = st.models.utils.DataParallel(net)
   s = st.models.utils.get_score_fn(cfg, sde, model, train=False, continuous=True)(x, torch.from_numpy(g['t']).to(dev))
   assert rel_err(s, torch.from_numpy(g['score'])) <= TOL
+
+
+def golden_likelihood(st, model, cfg, family, tol, nfe_exact=True):
+  """likelihood.py (residual term, ST-NELBO, ODE NLL) on `model` against the reference's own outputs
+  (tests/golden/likelihood_{family}.npz, generated by tools/make_golden.py; noise injected)."""
+  import os
+  from _model_util import patched_rng
+  g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', f'likelihood_{family}.npz')))
+  dev = next(model.parameters()).device
+  sde = st.sde_lib.get_sde(cfg, None)
+  cfg.eval.probability_flow, cfg.eval.lambda_ = True, 0.0
+  data = torch.from_numpy(g['data']).to(dev)
+  inv = st.datasets.get_data_inverse_scaler(cfg)
+  model.eval()
+  score_fn = st.models.utils.get_score_fn(cfg, sde, model, train=False, continuous=True)
+
+  def close(a, ref, what):
+    a = a.detach().cpu().double().numpy()
+    assert np.abs(a - ref).max() <= tol * max(np.abs(ref).max(), 1.0), (what, a, ref)
+
+  for deq in ('none', 'lossless'):
+    cfg.data.dequantization = deq
+    for var in ('ddpm', 'scoreflow'):
+      with patched_rng(21), torch.no_grad():
+        r = st.likelihood.get_likelihood_residual_fn(cfg, sde, score_fn, variance=var)(data, 1e-3)
+      close(r, g[f'residual.{deq}.{var}'], f'residual {deq} {var}')
+  cfg.data.dequantization = 'none'
+  np.random.seed(3)
+  with patched_rng(31):
+    nelbo, resid = st.likelihood.get_elbo_fn(cfg, sde, inverse_scaler=inv)(model, data, eps=1e-3)
+  close(nelbo, g['nelbo'], 'nelbo')
+  close(resid, g['nelbo.residual'], 'nelbo residual')
+  with patched_rng(41):
+    bpd, z, nfe = st.likelihood.get_likelihood_fn(cfg, sde, inv)(model, data, eps=1e-3)
+  if nfe == int(g['nll.nfe']):
+    close(bpd, g['nll.bpd'], 'nll bpd')
+    close(z, g['nll.z'], 'nll latent')
+  else:
+    # An adaptive solver amplifies rounding-level differences of the network into a different step sequence when an
+    # error estimate lands next to the acceptance threshold; the two solutions then agree to the solver tolerance
+    # (rtol = atol = 1e-5, the reference's defaults), not to the arithmetic tolerance.
+    assert not nfe_exact, (nfe, int(g['nll.nfe']))
+    assert abs(nfe - int(g['nll.nfe'])) <= 0.1 * int(g['nll.nfe'])
+    b, zz = bpd.detach().cpu().double().numpy(), z.detach().cpu().double().numpy()
+    assert np.abs(b - g['nll.bpd']).max() <= 1e-3 * np.abs(g['nll.bpd']).max(), ('nll bpd', b, g['nll.bpd'])
+    assert np.abs(zz - g['nll.z']).max() <= 1e-2 * np.abs(g['nll.z']).max(), 'nll latent'
+
+
+def golden_likelihood_product(st, lib, family):
+  """The HIP engine (or the checker) through likelihood.py against the reference's likelihood fixtures: needs the
+  network's input gradient (Hutchinson divergence, NELBO Jacobian-vector product) from the hand-written backward."""
+  import os
+  g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', f'model_{family}.npz')))
+  base = {'vp': st.configs.cifar10_ddpmpp_nll_st, 've': st.configs.celebahq_uncsnpp_st}[family]()
+  cfg = st.configs.tiny(base, nf=8, ch_mult=(1, 1, 2) if family == 've' else (1, 2), num_res_blocks=1,
+                        image_size=8, attn_resolutions=(4,), dropout=0.0)
+  dev = torch.device('cuda:0') if lib.is_device else torch.device('cpu')
+  cfg.device = dev
+  net = st.models.ncsnpp.NCSNpp(cfg, None)
+  net.load_state_dict({k[3 + len('module.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('sd.')})
+  net.set_backend(lib)
+  model = st.models.utils.DataParallel(net.to(dev).eval())
+  # fp32 kernels vs the reference's CPU arithmetic: the adaptive solver may take a different number of steps only if
+  # an error estimate lands within rounding of the acceptance threshold; the fixture's tolerance keeps it identical
+  golden_likelihood(st, model, cfg, family, tol=TOL, nfe_exact=False)

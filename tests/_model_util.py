@@ -71,18 +71,23 @@ class _Draws:
   def randn_like(self, x, **kw):
     return torch.empty(x.shape).normal_(generator=self.g).to(x.device)
 
+  def randint_like(self, x, low=0, high=None, **kw):
+    if high is None:
+      low, high = 0, low
+    return torch.randint(low, high, tuple(x.shape), generator=self.g).to(device=x.device, dtype=x.dtype)
+
 
 @contextlib.contextmanager
 def patched_rng(seed):
   """Serve torch.rand / randn / randn_like from one CPU stream (CPU and GPU generators differ, so
   parity tests inject the noise explicitly -- SURVEY.md 8(c))."""
   d = _Draws(seed)
-  saved = (torch.rand, torch.randn, torch.randn_like)
-  torch.rand, torch.randn, torch.randn_like = d.rand, d.randn, d.randn_like
+  saved = (torch.rand, torch.randn, torch.randn_like, torch.randint_like)
+  torch.rand, torch.randn, torch.randn_like, torch.randint_like = d.rand, d.randn, d.randn_like, d.randint_like
   try:
     yield
   finally:
-    torch.rand, torch.randn, torch.randn_like = saved
+    torch.rand, torch.randn, torch.randn_like, torch.randint_like = saved
 
 
 def make_state(st, cfg, model):

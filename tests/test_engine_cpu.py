@@ -106,3 +106,10 @@ def test_device_batch_on_checker(st, ref_lib):
   u = out * 256. - 255. * plain
   assert float(u.min()) > -1e-4 and float(u.max()) < 1. + 1e-4 and abs(float(u.mean()) - 0.5) < 0.02
   assert not torch.equal(out, st.datasets.device_batch(cfg, img, seed=10, backend=ref_lib))
+
+
+@pytest.mark.parametrize('family', ['vp'])       # 've' (900 network evaluations on the plain-C checker) runs on the GPU only
+def test_likelihood_engine_on_checker(st, ref_lib, family):
+  """likelihood.py through the planned-graph engine (checker backend): exercises the engine's input-gradient path
+  under torch.autograd.grad against the reference's fixtures."""
+  cases.golden_likelihood_product(st, ref_lib, family)

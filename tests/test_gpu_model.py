@@ -53,6 +53,11 @@ def test_golden_fixtures(st, hip_lib, family):
   cases.golden_forward_backward(st, hip_lib, family)
 
 
+@pytest.mark.parametrize('family', ['vp', 've'])
+def test_golden_likelihood(st, hip_lib, family):
+  cases.golden_likelihood_product(st, hip_lib, family)
+
+
 def test_product_fails_loudly_without_gpu_tensors(st, hip_lib):
   """The HIP backend refuses CPU tensors instead of falling back."""
   import torch

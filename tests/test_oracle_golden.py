@@ -213,3 +213,13 @@ def test_state_dict_layout_matches_reference(st):
     assert got == [(k, tuple(s)) for k, s in want]
     spec = ref_torch.build_spec(cfg)
     assert len(spec) == len(model.module.all_modules)
+
+
+@pytest.mark.parametrize('family', ['vp', 've'])
+def test_likelihood_matches_reference(st, family):
+  """likelihood.py (host arithmetic around score_fn, device-resident RK45) on the oracle network == the reference's
+  likelihood.py on the reference network: residual terms, soft-truncation NELBO, ODE NLL incl. the solver's nfev."""
+  import _model_cases as cases
+  g = load(f'model_{family}.npz')
+  cfg, sd, ref = _ref_model(st, family, g)
+  cases.golden_likelihood(st, ref, cfg, family, tol=2e-5)

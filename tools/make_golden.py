@@ -112,7 +112,8 @@ def op_fixture(ns):
   np.savez_compressed(os.path.join(OUT, 'ops.npz'), **out)
 
 
-def model_fixture(ns, family):
+def build_model(ns, family):
+  """The tiny reference model of a family with its fixture weights (same draws every time)."""
   dotted, kw = FAMILIES[family]
   cfg = tiny(refimport.get_config(dotted), **kw)
   torch.manual_seed(0)
@@ -123,6 +124,44 @@ def model_fixture(ns, family):
     for p in model.parameters():
       if p.requires_grad:
         p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+  return cfg, sde, model, g
+
+
+def likelihood_fixture(ns, family):
+  """Outputs of the reference's likelihood.py (residual term, ST-NELBO, ODE NLL) on the fixture model of
+  model_{family}.npz, noise injected; both residual variants (dequantization 'lossless' and otherwise)."""
+  cfg, sde, model, _ = build_model(ns, family)
+  model.eval()
+  # default_lsun_configs.py (the 've' family) defines neither eval.probability_flow nor eval.lambda_, so the reference's
+  # own NLL raises AttributeError there; the fixture sets the values the other two default configs use
+  cfg.eval.probability_flow, cfg.eval.lambda_ = True, 0.0
+  lik = ns.likelihood
+  H = cfg.data.image_size
+  gen = torch.Generator().manual_seed(77)
+  data = torch.rand(3, 3, H, H, generator=gen)
+  data = data * 2. - 1. if cfg.data.centered else data
+  inv = (lambda v: (v + 1.) / 2.) if cfg.data.centered else (lambda v: v)
+  out = {'data': npy(data)}
+  score_fn = ns.mutils.get_score_fn(cfg, sde, model, train=False, continuous=True)
+  for deq in ('none', 'lossless'):
+    cfg.data.dequantization = deq
+    for var in ('ddpm', 'scoreflow'):
+      with patched_rng(21), torch.no_grad():
+        out[f'residual.{deq}.{var}'] = npy(lik.get_likelihood_residual_fn(cfg, sde, score_fn, variance=var)(data, 1e-3))
+  cfg.data.dequantization = 'none'
+  np.random.seed(3)
+  with patched_rng(31):
+    nelbo, resid = lik.get_elbo_fn(cfg, sde, inverse_scaler=inv)(model, data, eps=1e-3)
+  out['nelbo'], out['nelbo.residual'] = npy(nelbo.detach()), npy(resid.detach())
+  with patched_rng(41):
+    bpd, z, nfe = lik.get_likelihood_fn(cfg, sde, inv)(model, data, eps=1e-3)     # rtol = atol = 1e-5, the reference's defaults
+  out['nll.bpd'], out['nll.z'], out['nll.nfe'] = npy(bpd), npy(z), np.asarray(nfe)
+  np.savez_compressed(os.path.join(OUT, f'likelihood_{family}.npz'), **out)
+  print(family, 'likelihood: nfe', nfe, 'bpd', bpd.tolist())
+
+
+def model_fixture(ns, family):
+  cfg, sde, model, g = build_model(ns, family)
   out = {}
   for k, v in model.state_dict().items():
     out['sd.' + k] = npy(v)
@@ -192,6 +231,8 @@ def main():
   op_fixture(ns)
   for fam in FAMILIES:
     model_fixture(ns, fam)
+  for fam in ('vp', 've'):
+    likelihood_fixture(ns, fam)
   for f in sorted(os.listdir(OUT)):
     print(f, os.path.getsize(os.path.join(OUT, f)))
 
