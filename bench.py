@@ -41,9 +41,9 @@ PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 # rocprofv3 symbol of the kernel behind a profiler label (for the committed PMC summary, see traffic_of)
 KERNEL_SYMBOL = {
-  'conv3x3.wgrad.x3': 'gemm_kernel<RowsLoader<false, false>, RowsLoader<true, false>, EpWgrad, false>',
-  'conv3x3.fwd.x3': 'gemm_kernel<WpLoader, ActLoader<false>, EpFwd, true>',
-  'conv3x3.dgrad.x3': 'gemm_kernel<WpLoader, ActLoader<false>, EpDgrad, true>',
+  'conv3x3.wgrad.x3': 'wgrad3_kernel<false>',
+  'conv3x3.fwd.x3': 'gemm_kernel<WpLoader, ActLoader<false, 9>, EpFwd, true>',
+  'conv3x3.dgrad.x3': 'gemm_kernel<WpLoader, ActLoader<false, 9>, EpDgrad, true>',
 }
 
 

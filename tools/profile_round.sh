@@ -12,5 +12,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o r -- $BENCH 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o r -- $BENCH --prof-steps 0 --no-kernel-timer > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o r -- $BENCH --prof-steps 0 --no-kernel-timer > /dev/null 2> $OUT/pmc_mfma.err
 python tools/profile_summary.py $OUT > $OUT/summary.txt 2>&1
+# the raw traces are large (gpurun merges at most 64 MiB back): keep the per-kernel stats and the summaries only
+rm -f $OUT/stats/*kernel_trace.csv $OUT/pmc_*/*counter_collection.csv
 tail -5 $OUT/summary.txt
 ls $OUT $OUT/stats | head -30
