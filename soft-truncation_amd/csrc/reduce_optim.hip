@@ -67,6 +67,26 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ d
     out[(long)n * out_stride + c] = alpha * s;
   }
 }
+// Long rows (large maps at small batch: 512 rows of 65536 floats at 256x256, batch 4): one 256-thread workgroup per
+// row -- with one wave per row only 128 workgroups exist and each wave streams 256 KB serially.
+__global__ __launch_bounds__(256) void rowsum_block_kernel(const float* __restrict__ dy, float* __restrict__ out, int N,
+                                                           int C, int HW, int out_stride, float alpha) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  const float4* p4 = reinterpret_cast<const float4*>(dy + row * HW);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+    const float4 v = p4[i];
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n = (int)(row / C), c = (int)(row - (long)n * C);
+    out[(long)n * out_stride + c] = alpha * ((red[0] + red[1]) + (red[2] + red[3]));
+  }
+}
 // dbias[c] += sum_n src[n*stride + c].  32 channels per 256-thread block: thread (c = t%32, part = t/32)
 // sums every 8th row (32 consecutive floats per row segment -> coalesced), LDS folds the 8 parts.
 __global__ __launch_bounds__(256) void colsum_acc_kernel(const float* __restrict__ src, float* __restrict__ dbias, int N,
@@ -223,8 +243,12 @@ int stk_bias_grad_f32(const float* dy, int N, int C, int HW, float alpha, float*
   if (!dy || N <= 0 || C <= 0 || HW <= 0 || (!dtemb && !ws) || (!dtemb && !dbias)) return STK_EINVAL;
   float* rows = dtemb ? dtemb : ws;
   const int stride = dtemb ? temb_stride : C;
-  hipLaunchKernelGGL(rowsum_kernel, dim3(stk_cdiv((long)N * C, 4)), dim3(256), 0, S(stream), dy, rows, N, C, HW, stride,
-                     alpha);
+  if (HW >= 4096 && (HW & 3) == 0 && stk_aligned16(dy))
+    hipLaunchKernelGGL(rowsum_block_kernel, dim3((unsigned)((long)N * C)), dim3(256), 0, S(stream), dy, rows, N, C, HW,
+                       stride, alpha);
+  else
+    hipLaunchKernelGGL(rowsum_kernel, dim3(stk_cdiv((long)N * C, 4)), dim3(256), 0, S(stream), dy, rows, N, C, HW, stride,
+                       alpha);
   STK_CHECK_LAUNCH();
   if (dbias) {
     hipLaunchKernelGGL(colsum_acc_kernel, dim3(stk_cdiv(C, 32)), dim3(256), 0, S(stream), rows, dbias, N, C, stride);

@@ -493,3 +493,21 @@ def test_preprocess_u8(st, ref_lib, hip_lib):
     a = st.datasets.device_batch(cfg, img, seed=1234, backend=ref_lib)
     b = st.datasets.device_batch(cfg, img.to(dev_of(hip_lib)), seed=1234)
     assert torch.equal(a, b.cpu())
+
+
+def test_bias_grad_long_rows(ref_lib, hip_lib):
+  """64x64 maps: rows of 4096 floats take the one-workgroup-per-row kernel."""
+  N, C, HW, TS = 3, 10, 4096, 16
+  dy = rnd(N, C, 64, 64, seed=3)
+  db0 = rnd(C, seed=4)
+
+  def fn(lib, to):
+    d = to(dy)
+    ws = to(torch.zeros(N * C))
+    dt = to(torch.zeros(N, TS)); db = to(db0.clone())
+    call(lib, 'bias_grad_f32', d, N, C, HW, 0.5, dt.data_ptr() + 4 * 4, TS, db, ws)
+    db2 = to(db0.clone())
+    call(lib, 'bias_grad_f32', d, N, C, HW, 1.0, None, 0, db2, ws)
+    return {'dtemb': dt, 'dbias': db, 'dbias_only': db2}
+
+  compare(both(ref_lib, hip_lib, fn), 1e-5, 'bias_grad')
