@@ -255,7 +255,7 @@ def main():
       out['step_roofline'].update({'hbm_algorithmic_GBps': gbs, 'frac_hbm': gbs / 8000.0,
                                    'hbm_note': 'SURVEY.md 8(d) fused-traffic model: 3 x A_f bytes per image + 16 x 4 B per '
                                                'parameter per step, against 8 TB/s'})
-    if args.sampler_steps > 0:
+    if world == 1 and args.sampler_steps > 0:        # like the CPU baseline: only in the single-GPU run
       try:
         out['sampler'] = sampler_rate(st, cfg, sde, score_model, per_gpu_batch, args.sampler_steps, device)
       except Exception as e:                         # the reference's RVE sampling raises: report, do not fail
