@@ -11,6 +11,7 @@ import numpy as np
 import torch
 from scipy import integrate
 
+from . import _decoder
 from .engine import rk45
 from .models import utils as mutils
 
@@ -42,63 +43,22 @@ def get_div_fn(fn):
 
 
 def get_likelihood_residual_fn(config, sde, score_fn, variance='ddpm'):
-  """Reconstruction term at the truncation time (likelihood.py:210-313): ``fn(batch, eps=None) -> [B]`` nats."""
-
-  def approx_standard_normal_cdf(x):
-    return 0.5 * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * (x ** 3))))
-
-  def discretized_gaussian_log_likelihood(x, means, log_scales):
-    # data is integers [0, 255] rescaled to [-1, 1]
-    assert x.shape == means.shape
-    centered = x - means
-    inv_std = torch.exp(-log_scales)
-    cdf_plus = approx_standard_normal_cdf(inv_std * (centered + 1. / 255.))
-    cdf_min = approx_standard_normal_cdf(inv_std * (centered - 1. / 255.))
-    floor = torch.tensor(1e-12, device=cdf_plus.device)
-    log_cdf_plus = torch.log(torch.max(cdf_plus, floor))
-    log_one_minus_cdf_min = torch.log(torch.max(1. - cdf_min, floor))
-    log_delta = torch.log(torch.max(cdf_plus - cdf_min, floor))
-    out = torch.where(x < -0.999, log_cdf_plus, torch.where(x > 0.999, log_one_minus_cdf_min, log_delta))
-    assert out.shape == x.shape
-    return out
-
-  def posterior(batch, eps):
-    """x_eps ~ p(x_eps | x), the score there and the Gaussian q(x | x_eps) built from it (mean, per-sample std)."""
-    if eps is None:
-      eps = sde.eps
-    eps_vec = torch.ones((batch.shape[0]), device=batch.device) * eps
-    mean, std = sde.marginal_prob(batch, eps_vec)
-    z = torch.randn_like(batch)
-    perturbed = mean + _bcast(std) * z
-    score = score_fn(perturbed, eps_vec)
-    alpha, beta = sde.marginal_prob(torch.ones_like(batch), eps_vec)
-    q_mean = perturbed / alpha + _bcast(beta) ** 2 * score / alpha
-    if variance == 'ddpm':
-      q_std = beta
-    elif variance == 'scoreflow':
-      q_std = beta / torch.mean(alpha, axis=(1, 2, 3))
-    return std, q_mean, q_std
-
-  def entropy(n_dim, std):
-    return n_dim / 2. * (np.log(2 * np.pi) + 2 * torch.log(std) + 1.)
+  """Reconstruction term at the truncation time (likelihood.py:210-313): ``fn(batch, eps=None) -> [B]`` nats,
+  decoder negative log-likelihood minus the entropy of the perturbation kernel (`_decoder.py`)."""
 
   def residual_lossless(batch, eps=None):
-    std, q_mean, q_std = posterior(batch, eps)
+    std, q_mean, q_std = _decoder.posterior_at(sde, score_fn, batch, sde.eps if eps is None else eps, variance)
     if not config.data.centered:
-      batch = 2. * batch - 1.
-      q_mean = 2. * q_mean - 1.
-      q_std = 2. * q_std
-    decoder_nll = -discretized_gaussian_log_likelihood(batch, means=q_mean, log_scales=_bcast(torch.log(q_std)))
-    residual = decoder_nll.sum(axis=(1, 2, 3)) - entropy(np.prod(batch.shape[1:]), std)
+      batch, q_mean, q_std = 2. * batch - 1., 2. * q_mean - 1., 2. * q_std
+    nll = -_decoder.discretized_gaussian_log_likelihood(batch, means=q_mean, log_scales=_bcast(torch.log(q_std)))
+    residual = nll.sum(axis=(1, 2, 3)) - _decoder.entropy_of_perturbation(np.prod(batch.shape[1:]), std)
     assert residual.shape == torch.Size([batch.shape[0]])
     return residual
 
   def residual_gaussian(batch, eps=None):
-    std, q_mean, q_std = posterior(batch, eps)
-    n_dim = np.prod(batch.shape[1:])
-    p_entropy = entropy(n_dim, std)
-    q_recon = n_dim / 2. * (np.log(2 * np.pi) + 2 * torch.log(q_std)) \
-        + 0.5 / (q_std ** 2) * torch.square(batch - q_mean).sum(axis=(1, 2, 3))
+    std, q_mean, q_std = _decoder.posterior_at(sde, score_fn, batch, sde.eps if eps is None else eps, variance)
+    p_entropy = _decoder.entropy_of_perturbation(np.prod(batch.shape[1:]), std)
+    q_recon = _decoder.gaussian_reconstruction(batch, q_mean, q_std)
     assert q_recon.shape == p_entropy.shape == torch.Size([batch.shape[0]])
     return q_recon - p_entropy
 

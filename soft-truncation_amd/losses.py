@@ -19,6 +19,7 @@ import numpy as np
 import torch
 import torch.optim as optim
 
+from . import _decoder
 from .engine import ddp
 from .engine.flat import flat_of
 from .engine.optim import FusedAdam
@@ -26,24 +27,32 @@ from .models import utils as mutils
 from .sde_lib import VESDE, VPSDE
 
 
+def _wide(v):
+  return v[:, None, None, None]
+
+
+def _per_sample_reducer(config):
+  """mean over CHW when ``training.reduce_mean`` else half the sum (losses.py:77)."""
+  if config.training.reduce_mean:
+    return torch.mean
+  return lambda *args, **kwargs: 0.5 * torch.sum(*args, **kwargs)
+
+
+# optimizer name -> (second Adam beta, decoupled weight decay); losses.py:31-39
+_OPTIMIZERS = {'Adam': (0.999, False), 'AdamW': (0.99, True)}
+
+
 def get_optimizer(config, params):
-  """Adam / AdamW per ``config.optim`` (losses.py:29-41).  Flat-backed parameters (the score
-  network) get the fused HIP optimizer; other parameter lists get torch's."""
-  params = list(params)
-  o = config.optim
-  fused = flat_of(params) is not None
-  if o.optimizer == 'Adam':
-    if fused:
-      return FusedAdam(params, lr=o.lr, betas=(o.beta1, 0.999), eps=o.eps, weight_decay=o.weight_decay,
-                       amsgrad=o.amsgrad)
-    return optim.Adam(params, lr=o.lr, betas=(o.beta1, 0.999), eps=o.eps, weight_decay=o.weight_decay,
-                      amsgrad=o.amsgrad)
-  if o.optimizer == 'AdamW':
-    if fused:
-      return FusedAdam(params, lr=o.lr, betas=(o.beta1, 0.99), eps=o.eps, weight_decay=o.weight_decay,
-                       adamw=True)
-    return optim.AdamW(params, lr=o.lr, betas=(o.beta1, 0.99), eps=o.eps, weight_decay=o.weight_decay)
-  raise NotImplementedError(f'Optimizer {o.optimizer} not supported yet!')
+  """Adam / AdamW per ``config.optim`` (losses.py:29-41).  Flat-backed parameters (the score network) get the fused
+  HIP optimizer; other parameter lists get torch's."""
+  params, o = list(params), config.optim
+  if o.optimizer not in _OPTIMIZERS:
+    raise NotImplementedError(f'Optimizer {o.optimizer} not supported yet!')
+  beta2, decoupled = _OPTIMIZERS[o.optimizer]
+  common = dict(lr=o.lr, betas=(o.beta1, beta2), eps=o.eps, weight_decay=o.weight_decay)
+  if flat_of(params) is not None:
+    return FusedAdam(params, adamw=True, **common) if decoupled else FusedAdam(params, amsgrad=o.amsgrad, **common)
+  return optim.AdamW(params, **common) if decoupled else optim.Adam(params, amsgrad=o.amsgrad, **common)
 
 
 def optimization_manager(config):
@@ -51,14 +60,16 @@ def optimization_manager(config):
 
   def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup,
                   grad_clip=config.optim.grad_clip):
-    params = list(params)
+    params = list(params)                       # a generator would be exhausted by the first consumer below
+    fused = hasattr(optimizer, 'clip_grad_norm')
     if warmup > 0:
-      for g in optimizer.param_groups:
-        g['lr'] = lr * np.minimum(step / warmup, 1.0)
-    ddp.sync_gradients(optimizer, None if hasattr(optimizer, 'clip_grad_norm') else params)
+      warm_lr = lr * np.minimum(step / warmup, 1.0)
+      for group in optimizer.param_groups:
+        group['lr'] = warm_lr
+    ddp.sync_gradients(optimizer, None if fused else params)
     if grad_clip >= 0:
-      if hasattr(optimizer, 'clip_grad_norm'):
-        optimizer.clip_grad_norm(grad_clip)
+      if fused:
+        optimizer.clip_grad_norm(grad_clip)      # norm stays on the device, folded into the Adam launch
       else:
         torch.nn.utils.clip_grad_norm_(params, max_norm=grad_clip)
     optimizer.step()
@@ -67,76 +78,44 @@ def optimization_manager(config):
 
 
 def get_sde_loss_fn(config, sde, train, variance='scoreflow'):
-  """Soft-truncation weighted denoising score matching for a continuous SDE (losses.py:61-168)."""
-  reduce_op = torch.mean if config.training.reduce_mean else lambda *args, **kwargs: 0.5 * torch.sum(*args, **kwargs)
+  """Soft-truncation weighted denoising score matching for a continuous SDE (losses.py:61-168):
+  ``loss_fn(model, batch, importance_sampling, t_min=None) -> [B]``."""
+  tr = config.training
+  reduce_op = _per_sample_reducer(config)
 
-  def approx_standard_normal_cdf(x):
-    return 0.5 * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * (x ** 3))))
+  def score_matching(batch, t, Z, z, std, score):
+    if tr.importance_sampling or not tr.likelihood_weighting:
+      sq = torch.square(score * _wide(std) + z)
+      return 0.5 * Z * reduce_op(sq.reshape(sq.shape[0], -1), dim=-1)
+    g2 = sde.sde(torch.zeros_like(batch), t)[1] ** 2
+    sq = torch.square(score + z / _wide(std))
+    return 0.5 * Z * reduce_op(sq.reshape(sq.shape[0], -1), dim=-1) * g2
 
-  def discretized_gaussian_log_likelihood(x, means, log_scales):
-    assert x.shape == means.shape
-    centered_x = x - means
-    inv_stdv = torch.exp(-log_scales)
-    cdf_plus = approx_standard_normal_cdf(inv_stdv * (centered_x + 1. / 255.))
-    cdf_min = approx_standard_normal_cdf(inv_stdv * (centered_x - 1. / 255.))
-    floor = torch.tensor(1e-12, device=cdf_plus.device)
-    log_cdf_plus = torch.log(torch.max(cdf_plus, floor))
-    log_one_minus_cdf_min = torch.log(torch.max(1. - cdf_min, floor))
-    cdf_delta = cdf_plus - cdf_min
-    log_probs = torch.where(x < -0.999, log_cdf_plus,
-                            torch.where(x > 0.999, log_one_minus_cdf_min,
-                                        torch.log(torch.max(cdf_delta, floor))))
-    assert log_probs.shape == x.shape
-    return log_probs
+  def reconstruction(score_fn, batch, t_min, losses):
+    """Decoder term at the truncation time (losses.py:134-164; off in every BASELINE config)."""
+    std, q_mean, q_std = _decoder.posterior_at(sde, score_fn, batch, t_min, variance)
+    if config.data.dequantization == 'lossless':
+      nll = -_decoder.discretized_gaussian_log_likelihood(batch, means=q_mean, log_scales=_wide(torch.log(q_std)))
+      term = nll.sum(axis=(1, 2, 3))
+    else:
+      p_entropy = _decoder.entropy_of_perturbation(np.prod(batch.shape[1:]), std)
+      q_recon = _decoder.gaussian_reconstruction(batch, q_mean, q_std)
+      assert q_recon.shape == p_entropy.shape == torch.Size([batch.shape[0]])
+      term = q_recon - p_entropy
+      assert losses.shape == term.shape
+    return term / np.prod(list(batch.shape[1:])) if tr.reduce_mean else term
 
   def loss_fn(model, batch, importance_sampling, t_min=None):
-    """Per-sample losses [B] for one (micro-)batch (losses.py:101-166)."""
     if t_min is None:
       t_min = sde.get_t_min(config)
-    t, Z = sde.get_diffusion_time(config, batch.shape[0], batch.device, t_min,
-                                  importance_sampling=importance_sampling)
-    score_fn = mutils.get_score_fn(config, sde, model, train=train, continuous=config.training.continuous)
+    t, Z = sde.get_diffusion_time(config, batch.shape[0], batch.device, t_min, importance_sampling=importance_sampling)
+    score_fn = mutils.get_score_fn(config, sde, model, train=train, continuous=tr.continuous)
     z = torch.randn_like(batch)
     mean, std = sde.marginal_prob(batch, t)
-    perturbed_data = mean + std[:, None, None, None] * z
-    score = score_fn(perturbed_data, t)
-
-    if config.training.importance_sampling or not config.training.likelihood_weighting:
-      losses = torch.square(score * std[:, None, None, None] + z)
-      losses = 0.5 * Z * reduce_op(losses.reshape(losses.shape[0], -1), dim=-1)
-    else:
-      g2 = sde.sde(torch.zeros_like(batch), t)[1] ** 2
-      losses = torch.square(score + z / std[:, None, None, None])
-      losses = 0.5 * Z * reduce_op(losses.reshape(losses.shape[0], -1), dim=-1) * g2
-
-    if config.training.reconstruction_loss:
-      eps_vec = torch.ones((batch.shape[0]), device=batch.device) * t_min
-      mean, std = sde.marginal_prob(batch, eps_vec)
-      z = torch.randn_like(batch)
-      perturbed_data = mean + std[:, None, None, None] * z
-      score = score_fn(perturbed_data, eps_vec)
-      alpha, beta = sde.marginal_prob(torch.ones_like(batch), eps_vec)
-      q_mean = perturbed_data / alpha + beta[:, None, None, None] ** 2 * score / alpha
-      if variance == 'ddpm':
-        q_std = beta
-      elif variance == 'scoreflow':
-        q_std = beta / torch.mean(alpha, axis=(1, 2, 3))
-      if config.data.dequantization == 'lossless':
-        decoder_nll = -discretized_gaussian_log_likelihood(
-          batch, means=q_mean, log_scales=torch.log(q_std)[:, None, None, None])
-        reconstruction_loss = decoder_nll.sum(axis=(1, 2, 3))
-      else:
-        n_dim = np.prod(batch.shape[1:])
-        p_entropy = n_dim / 2. * (np.log(2 * np.pi) + 2 * torch.log(std) + 1.)
-        q_recon = n_dim / 2. * (np.log(2 * np.pi) + 2 * torch.log(q_std)) \
-                  + 0.5 / (q_std ** 2) * torch.square(batch - q_mean).sum(axis=(1, 2, 3))
-        assert q_recon.shape == p_entropy.shape == torch.Size([batch.shape[0]])
-        reconstruction_loss = q_recon - p_entropy
-        assert losses.shape == reconstruction_loss.shape
-      if config.training.reduce_mean:
-        reconstruction_loss = reconstruction_loss / np.prod(list(batch.shape[1:]))
-      losses = losses + reconstruction_loss
-
+    score = score_fn(mean + _wide(std) * z, t)
+    losses = score_matching(batch, t, Z, z, std, score)
+    if tr.reconstruction_loss:
+      losses = losses + reconstruction(score_fn, batch, t_min, losses)
     return losses
 
   return loss_fn
@@ -145,20 +124,17 @@ def get_sde_loss_fn(config, sde, train, variance='scoreflow'):
 def get_smld_loss_fn(config, vesde, train):
   """Legacy discrete SMLD objective (losses.py:171-192); unreachable with continuous configs."""
   assert isinstance(vesde, VESDE), "SMLD training only works for VESDEs."
-  smld_sigma_array = torch.flip(vesde.discrete_sigmas, dims=(0,))
-  reduce_op = torch.mean if config.training.reduce_mean else lambda *args, **kwargs: 0.5 * torch.sum(*args, **kwargs)
+  descending = torch.flip(vesde.discrete_sigmas, dims=(0,))
+  reduce_op = _per_sample_reducer(config)
 
   def loss_fn(model, batch):
     model_fn = mutils.get_model_fn(model, train=train)
     labels = torch.randint(0, vesde.N, (batch.shape[0],), device=batch.device)
-    sigmas = smld_sigma_array.to(batch.device)[labels]
-    noise = torch.randn_like(batch) * sigmas[:, None, None, None]
-    perturbed_data = noise + batch
-    score = model_fn(perturbed_data, labels)
-    target = -noise / (sigmas ** 2)[:, None, None, None]
-    losses = torch.square(score - target)
-    losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1) * sigmas ** 2
-    return torch.mean(losses)
+    sigmas = descending.to(batch.device)[labels]
+    noise = torch.randn_like(batch) * _wide(sigmas)
+    score = model_fn(noise + batch, labels)
+    sq = torch.square(score - (-noise / _wide(sigmas ** 2)))
+    return torch.mean(reduce_op(sq.reshape(sq.shape[0], -1), dim=-1) * sigmas ** 2)
 
   return loss_fn
 
@@ -166,92 +142,78 @@ def get_smld_loss_fn(config, vesde, train):
 def get_ddpm_loss_fn(config, vpsde, train):
   """Legacy discrete DDPM objective (losses.py:195-215); unreachable with continuous configs."""
   assert isinstance(vpsde, VPSDE), "DDPM training only works for VPSDEs."
-  reduce_op = torch.mean if config.training.reduce_mean else lambda *args, **kwargs: 0.5 * torch.sum(*args, **kwargs)
+  reduce_op = _per_sample_reducer(config)
 
   def loss_fn(model, batch):
     model_fn = mutils.get_model_fn(model, train=train)
     labels = torch.randint(0, vpsde.N, (batch.shape[0],), device=batch.device)
-    sqrt_alphas_cumprod = vpsde.sqrt_alphas_cumprod.to(batch.device)
-    sqrt_1m_alphas_cumprod = vpsde.sqrt_1m_alphas_cumprod.to(batch.device)
+    keep = vpsde.sqrt_alphas_cumprod.to(batch.device)
+    blur = vpsde.sqrt_1m_alphas_cumprod.to(batch.device)
     noise = torch.randn_like(batch)
-    perturbed_data = sqrt_alphas_cumprod[labels, None, None, None] * batch + \
-                     sqrt_1m_alphas_cumprod[labels, None, None, None] * noise
-    score = model_fn(perturbed_data, labels)
-    losses = torch.square(score - noise)
-    losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1)
-    return torch.mean(losses)
+    noisy = keep[labels, None, None, None] * batch + blur[labels, None, None, None] * noise
+    sq = torch.square(model_fn(noisy, labels) - noise)
+    return torch.mean(reduce_op(sq.reshape(sq.shape[0], -1), dim=-1))
 
   return loss_fn
 
 
-def get_step_fn(config, sde, train, optimize_fn=None):
-  """One training step: ``step_fn(state, batch) -> losses[B]`` on the CPU (losses.py:218-325).
-
-  ``state`` = {'model', 'optimizer', 'ema', 'step'}; mutated in place exactly like the reference:
-  zero_grad, one host draw of t_min shared by the micro-batches, per-micro-batch
-  loss/backward, optimize_fn, ``step += 1``, EMA update.
-  """
+def _pick_loss_fn(config, sde, train):
   if config.training.continuous:
-    loss_fn = get_sde_loss_fn(config, sde, train)
-  else:
-    assert not config.training.likelihood_weighting, \
-      "Likelihood weighting is not supported for original SMLD/DDPM training."
-    if isinstance(sde, VESDE):
-      loss_fn = get_smld_loss_fn(config, sde, train)
-    elif isinstance(sde, VPSDE):
-      loss_fn = get_ddpm_loss_fn(config, sde, train)
-    else:
-      raise ValueError(f"Discrete training for {sde.__class__.__name__} is not recommended.")
+    return get_sde_loss_fn(config, sde, train)
+  assert not config.training.likelihood_weighting, \
+    "Likelihood weighting is not supported for original SMLD/DDPM training."
+  if isinstance(sde, VESDE):
+    return get_smld_loss_fn(config, sde, train)
+  if isinstance(sde, VPSDE):
+    return get_ddpm_loss_fn(config, sde, train)
+  raise ValueError(f"Discrete training for {sde.__class__.__name__} is not recommended.")
 
-  def _finish(state, model, optimizer):
-    optimize_fn(optimizer, model.parameters(), step=state['step'])
-    state['step'] += 1
-    state['ema'].update(model.parameters())
+
+def get_step_fn(config, sde, train, optimize_fn=None):
+  """One training step: ``step_fn(state, batch) -> losses`` on the CPU (losses.py:218-325).
+
+  ``state`` = {'model', 'optimizer', 'ema', 'step'}, mutated in place exactly like the reference: zero_grad, one host
+  draw of t_min shared by the micro-batches, per-micro-batch loss + backward of its mean, ``optimize_fn``,
+  ``step += 1``, EMA update.  With ``training.mixed`` each micro-batch is split in halves -- importance-sampled and
+  uniform-time -- combined as L_is + w L_ddpm (optionally balanced by mean(L_is / L_ddpm)), and the function returns
+  B/2 losses (losses.py:295-320)."""
+  loss_fn = _pick_loss_fn(config, sde, train)
+  tr = config.training
+  mixed = bool(tr.mixed)
+
+  def plain_losses(model, chunk, t_min):
+    return loss_fn(model, chunk, importance_sampling=tr.importance_sampling, t_min=t_min)
+
+  def mixed_losses(model, chunk, t_min):
+    half = chunk.shape[0] // 2
+    l_is = loss_fn(model, chunk[:half], importance_sampling=True, t_min=t_min)
+    l_ddpm = loss_fn(model, chunk[half:], importance_sampling=False, t_min=t_min)
+    weight = tr.ddpm_weight
+    if tr.balanced:
+      weight = weight * torch.mean(l_is / l_ddpm).detach().item()
+    return l_is + weight * l_ddpm
+
+  micro_losses = mixed_losses if mixed else plain_losses
 
   def step_fn(state, batch):
-    model = state['model']
-    optimizer = state['optimizer']
+    model, optimizer = state['model'], state['optimizer']
     if train:
       optimizer.zero_grad()
-      batch_size = batch.shape[0]
-      nmb = config.optim.num_micro_batch
-      per = batch_size // nmb
-      losses_ = torch.zeros(batch_size)
+      n, parts = batch.shape[0], config.optim.num_micro_batch
+      per = n // parts
+      out_per = per // 2 if mixed else per
+      losses_ = torch.zeros(n // 2 if mixed else n)
       t_min = sde.get_t_min(config)
-      for k in range(nmb):
-        losses = loss_fn(model, batch[per * k: per * (k + 1)],
-                         importance_sampling=config.training.importance_sampling, t_min=t_min)
+      for k in range(parts):
+        losses = micro_losses(model, batch[per * k: per * (k + 1)], t_min)
         torch.mean(losses).backward(retain_graph=True)
-        losses_[per * k: per * (k + 1)] = losses.cpu().detach()
-      _finish(state, model, optimizer)
+        losses_[out_per * k: out_per * (k + 1)] = losses.cpu().detach()
+      optimize_fn(optimizer, model.parameters(), step=state['step'])
+      state['step'] += 1
+      state['ema'].update(model.parameters())
     return losses_
 
-  def step_fn_mixed(state, batch):
-    """Half of each micro-batch importance-sampled, half uniform-time (losses.py:295-320)."""
-    model = state['model']
-    optimizer = state['optimizer']
-    if train:
-      optimizer.zero_grad()
-      batch_size = batch.shape[0]
-      nmb = config.optim.num_micro_batch
-      per = batch_size // nmb
-      half = batch_size // (2 * nmb)
-      losses_ = torch.zeros(batch_size // 2)
-      t_min = sde.get_t_min(config)
-      for k in range(nmb):
-        losses_is = loss_fn(model, batch[per * k: per * k + half], importance_sampling=True, t_min=t_min)
-        losses_ddpm = loss_fn(model, batch[per * k + half: per * (k + 1)], importance_sampling=False, t_min=t_min)
-        if config.training.balanced:
-          losses = losses_is + config.training.ddpm_weight * \
-                   torch.mean(losses_is / losses_ddpm).detach().item() * losses_ddpm
-        else:
-          losses = losses_is + config.training.ddpm_weight * losses_ddpm
-        torch.mean(losses).backward(retain_graph=True)
-        losses_[per // 2 * k: per // 2 * (k + 1)] = losses.cpu().detach()
-      _finish(state, model, optimizer)
-    return losses_
-
-  return step_fn_mixed if config.training.mixed else step_fn
+  return step_fn
 
 
 def get_div_fn(fn):
@@ -259,8 +221,8 @@ def get_div_fn(fn):
 
   def div_fn(x, t, eps):
     with torch.enable_grad():
-      fn_eps = torch.sum(fn(x, t) * eps)
-      grad_fn_eps = torch.autograd.grad(fn_eps, x)[0]
-    return torch.sum(grad_fn_eps * eps, dim=tuple(range(1, len(x.shape))))
+      projected = torch.sum(fn(x, t) * eps)
+      grad = torch.autograd.grad(projected, x)[0]
+    return torch.sum(grad * eps, dim=tuple(range(1, len(x.shape))))
 
   return div_fn
