@@ -23,14 +23,14 @@ _MODELS = {}
 def register_model(cls=None, *, name=None):
   """Decorator registering a model class under ``name`` (default: the class name)."""
 
-  def _register(cls):
-    local_name = cls.__name__ if name is None else name
-    if local_name in _MODELS:
-      raise ValueError(f'Already registered model with name: {local_name}')
-    _MODELS[local_name] = cls
-    return cls
+  def add(model_cls):
+    key = name if name is not None else model_cls.__name__
+    if key in _MODELS:
+      raise ValueError(f'Already registered model with name: {key}')
+    _MODELS[key] = model_cls
+    return model_cls
 
-  return _register if cls is None else _register(cls)
+  return add if cls is None else add(cls)
 
 
 def get_model(name):
@@ -44,23 +44,15 @@ def get_sigmas(config):
 
 
 def get_ddpm_params(config):
-  """DDPM beta/alpha tables (models/utils.py:65-86)."""
-  num_diffusion_timesteps = 1000
-  beta_start = config.model.beta_min / config.model.num_scales
-  beta_end = config.model.beta_max / config.model.num_scales
-  betas = np.linspace(beta_start, beta_end, num_diffusion_timesteps, dtype=np.float64)
+  """DDPM beta/alpha tables over 1000 steps (models/utils.py:65-86)."""
+  steps, m = 1000, config.model
+  lo, hi = m.beta_min / m.num_scales, m.beta_max / m.num_scales
+  betas = np.linspace(lo, hi, steps, dtype=np.float64)
   alphas = 1. - betas
-  alphas_cumprod = np.cumprod(alphas, axis=0)
-  return {
-    'betas': betas,
-    'alphas': alphas,
-    'alphas_cumprod': alphas_cumprod,
-    'sqrt_alphas_cumprod': np.sqrt(alphas_cumprod),
-    'sqrt_1m_alphas_cumprod': np.sqrt(1. - alphas_cumprod),
-    'beta_min': beta_start * (num_diffusion_timesteps - 1),
-    'beta_max': beta_end * (num_diffusion_timesteps - 1),
-    'num_diffusion_timesteps': num_diffusion_timesteps,
-  }
+  cum = np.cumprod(alphas, axis=0)
+  return dict(betas=betas, alphas=alphas, alphas_cumprod=cum, sqrt_alphas_cumprod=np.sqrt(cum),
+              sqrt_1m_alphas_cumprod=np.sqrt(1. - cum), beta_min=lo * (steps - 1), beta_max=hi * (steps - 1),
+              num_diffusion_timesteps=steps)
 
 
 class DataParallel(torch.nn.Module):
@@ -91,61 +83,67 @@ def create_model(config, sde):
 
 
 def get_model_fn(model, train=False):
-  """Callable running the model in train or eval mode (models/utils.py:97-126)."""
+  """Callable running the model in train or eval mode, re-asserted on every call (models/utils.py:97-126)."""
 
   def model_fn(x, labels):
-    if not train:
-      model.eval()
-    else:
-      model.train()
+    model.train() if train else model.eval()
     return model(x, labels)
 
   return model_fn
+
+
+def _vp_time_labels(config, sde, t):
+  """Conditioning of a continuously-trained VP network: 999 t, or the unbounded parametrisation that rescales the
+  antiderivative of g^2/sigma^2 onto [0, 999] (models/utils.py:149-154)."""
+  tr = config.training
+  if not tr.unbounded_parametrization:
+    return t * 999
+  sc = tr.stabilizing_constant
+  a0 = sde.antiderivative(1e-5, stabilizing_constant=sc)
+  return (sde.antiderivative(t, stabilizing_constant=sc) - a0) / (sde.antiderivative(sde.T, stabilizing_constant=sc) - a0) * 999.
+
+
+def _vp_score_fn(config, sde, model_fn, continuous):
+  sub = isinstance(sde, sde_lib.subVPSDE)
+
+  def score_fn(x, t, logsnr_model=None, logsnr=None):
+    if continuous or sub:
+      labels = _vp_time_labels(config, sde, t)
+      std = sde.marginal_prob(torch.zeros_like(x), t)[1]
+      out = model_fn(x, labels)
+    else:                                           # discrete DDPM ladder
+      labels = t * (sde.N - 1)
+      out = model_fn(x, labels)
+      std = sde.sqrt_1m_alphas_cumprod.to(labels.device)[labels.long()]
+    return - out / std[:, None, None, None] if config.training.ddpm_score else out
+
+  return score_fn
+
+
+def _ve_score_fn(sde, model_fn, continuous):
+  def score_fn(x, t):
+    if continuous:
+      labels = sde.marginal_prob(torch.zeros_like(x), t)[1]          # sigma(t)
+    else:
+      labels = sde.T - t
+      labels *= sde.N - 1
+      labels = torch.round(labels).long()
+    return model_fn(x, labels)
+
+  return score_fn
 
 
 def get_score_fn(config, sde, model, train=False, continuous=False):
   """Turn the raw network into a score function s(x, t) (models/utils.py:128-190).
 
   VP / subVP: labels = 999 t (continuous), score = -net/std when ``training.ddpm_score``;
-  VE / RVE:   labels = sigma(t) (continuous), the network output is already the score.
-  """
+  VE / RVE:   labels = sigma(t) (continuous), the network output is already the score."""
   model_fn = get_model_fn(model, train=train)
-
   if isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE)):
-    def score_fn(x, t, logsnr_model=None, logsnr=None):
-      if continuous or isinstance(sde, sde_lib.subVPSDE):
-        if config.training.unbounded_parametrization:
-          sc = config.training.stabilizing_constant
-          a0 = sde.antiderivative(1e-5, stabilizing_constant=sc)
-          labels = (sde.antiderivative(t, stabilizing_constant=sc) - a0) / \
-                   (sde.antiderivative(sde.T, stabilizing_constant=sc) - a0) * 999.
-        else:
-          labels = t * 999
-        std = sde.marginal_prob(torch.zeros_like(x), t)[1]
-        score = model_fn(x, labels)
-      else:
-        labels = t * (sde.N - 1)
-        score = model_fn(x, labels)
-        std = sde.sqrt_1m_alphas_cumprod.to(labels.device)[labels.long()]
-
-      if config.training.ddpm_score:
-        score = - score / std[:, None, None, None]
-      return score
-
-  elif isinstance(sde, (sde_lib.VESDE, sde_lib.reciprocal_VESDE)):
-    def score_fn(x, t):
-      if continuous:
-        labels = sde.marginal_prob(torch.zeros_like(x), t)[1]
-      else:
-        labels = sde.T - t
-        labels *= sde.N - 1
-        labels = torch.round(labels).long()
-      return model_fn(x, labels)
-
-  else:
-    raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
-
-  return score_fn
+    return _vp_score_fn(config, sde, model_fn, continuous)
+  if isinstance(sde, (sde_lib.VESDE, sde_lib.reciprocal_VESDE)):
+    return _ve_score_fn(sde, model_fn, continuous)
+  raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
 
 
 def to_flattened_numpy(x):

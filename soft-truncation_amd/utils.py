@@ -18,28 +18,28 @@ from .models import utils as mutils
 from .models.ema import ExponentialMovingAverage
 
 
+_STATEFUL = ('optimizer', 'model', 'ema')          # entries of `state` with a state_dict; 'step' is a plain int
+
+
 def restore_checkpoint(config, ckpt_dir, state, device):
+  """Load {'optimizer', 'model', 'ema', 'step'} into `state` in place; a missing file leaves it as it is
+  (utils.py:13-25)."""
   if not os.path.exists(ckpt_dir):
     os.makedirs(os.path.dirname(ckpt_dir), exist_ok=True)
     logging.warning(f"No checkpoint found at {ckpt_dir}. Returned the same state as input")
     return state
   logging.info(ckpt_dir + ' loaded ...')
-  loaded_state = torch.load(ckpt_dir, map_location=device, weights_only=False)
-  state['optimizer'].load_state_dict(loaded_state['optimizer'])
-  state['model'].load_state_dict(loaded_state['model'], strict=False)
-  state['ema'].load_state_dict(loaded_state['ema'])
-  state['step'] = loaded_state['step']
+  loaded = torch.load(ckpt_dir, map_location=device, weights_only=False)
+  for key in _STATEFUL:
+    kwargs = dict(strict=False) if key == 'model' else {}
+    state[key].load_state_dict(loaded[key], **kwargs)
+  state['step'] = loaded['step']
   return state
 
 
 def save_checkpoint(config, ckpt_dir, state):
-  saved_state = {
-    'optimizer': state['optimizer'].state_dict(),
-    'model': state['model'].state_dict(),
-    'ema': state['ema'].state_dict(),
-    'step': state['step'],
-  }
-  torch.save(saved_state, ckpt_dir)
+  """utils.py:28-36."""
+  torch.save({**{key: state[key].state_dict() for key in _STATEFUL}, 'step': state['step']}, ckpt_dir)
 
 
 def load_model(config, workdir, print_=True, sde=None):
@@ -49,10 +49,9 @@ def load_model(config, workdir, print_=True, sde=None):
   ema = ExponentialMovingAverage(score_model.parameters(), decay=config.model.ema_rate)
   state = dict(optimizer=optimizer, model=score_model, ema=ema, step=0)
   if print_:
-    model_params = sum(np.prod(p.size()) for p in score_model.parameters() if p.requires_grad)
-    total_num_params = sum(np.prod(p.size()) for p in score_model.parameters())
-    logging.info(f"model parameters: {model_params}")
-    logging.info(f"total number of parameters: {total_num_params}")
+    sizes = [(np.prod(p.size()), p.requires_grad) for p in score_model.parameters()]
+    logging.info(f"model parameters: {sum(n for n, trainable in sizes if trainable)}")
+    logging.info(f"total number of parameters: {sum(n for n, _ in sizes)}")
   checkpoint_dir = os.path.join(workdir, "checkpoints")
   checkpoint_meta_dir = os.path.join(workdir, "checkpoints-meta", "checkpoint.pth")
   os.makedirs(checkpoint_dir, exist_ok=True)
