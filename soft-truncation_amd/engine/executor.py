@@ -174,7 +174,9 @@ class Executor:
       torch.cuda.synchronize()
       g = torch.cuda.CUDAGraph()
       try:
-        with torch.cuda.graph(g):
+        # thread_local: calls made by OTHER threads while this one captures (e.g. the RCCL watchdog of a
+        # multi-GPU run polling its events) must not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
           rt = self._runtime(c, training, 0, c.seed_t.data_ptr())   # stream = the capture stream
           if direction == 'fwd':
             for op in ops:
