@@ -2,6 +2,7 @@
 RefNet on the host, through the reference's own interfaces (models.utils, losses.get_step_fn,
 sampling.get_sampling_fn)."""
 import pytest
+import torch
 
 import _model_cases as cases
 
@@ -56,6 +57,41 @@ def test_golden_fixtures(st, hip_lib, family):
 @pytest.mark.parametrize('family', ['vp', 've'])
 def test_golden_likelihood(st, hip_lib, family):
   cases.golden_likelihood_product(st, hip_lib, family)
+
+
+def test_train_steps_with_rccl_process_group(st, hip_lib, monkeypatch):
+  """The multi-GPU code path on the one GPU a test box has: an RCCL ("nccl") process group of one rank, the
+  gradient exchange forced on (bucketed async all-reduce of the flat gradient buffer + averaging by world size 1),
+  hipGraph capture and replay while the communicator's watchdog thread is alive.  Results must still match the
+  oracle, i.e. the exchange is the identity and nothing in it disturbs the captured launch sequences."""
+  import socket
+  import torch.distributed as dist
+  from importlib import import_module
+  ddp = import_module('soft-truncation_amd.engine.ddp')
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                          device_id=torch.device('cuda:0'))
+  try:
+    calls = []
+    real = dist.all_reduce
+
+    def counting_all_reduce(*a, **k):
+      calls.append(1)
+      return real(*a, **k)
+
+    real_sync = ddp.sync_gradients
+
+    def sync_device_side_only(optimizer, params=None, **kw):      # the oracle's CPU replica has nothing to exchange
+      if hasattr(optimizer, 'clip_grad_norm'):
+        real_sync(optimizer, params, **kw)
+
+    monkeypatch.setattr(ddp, 'is_distributed', lambda: True)
+    monkeypatch.setattr(ddp, 'sync_gradients', sync_device_side_only)
+    monkeypatch.setattr(dist, 'all_reduce', counting_all_reduce)
+    cases.train_steps(st, hip_lib, 'vp', steps=4)
+    assert len(calls) >= 4                      # one bucket per step for the tiny model
+  finally:
+    dist.destroy_process_group()
 
 
 def test_product_fails_loudly_without_gpu_tensors(st, hip_lib):
