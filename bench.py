@@ -148,6 +148,32 @@ def sampler_rate(st, cfg, sde, score_model, batch, steps, device):
           'corrector': cfg.sampling.corrector, 'ms_per_eval': 1e3 * dt / evals}
 
 
+def arithmetic_check(device):
+  """Accuracy of the two convolution paths on one layer of the workload's shape (128 -> 128, 3x3, 32x32, batch 24),
+  each against float64: the bf16 three-way-split kernel (ws given) and the f32-input MFMA kernel (ws = NULL).
+  Reported so that the `dtype: f32` claim of this line can be checked from the line itself."""
+  from importlib import import_module
+  lib = import_module('soft-truncation_amd.engine.lib').load()
+  g = torch.Generator().manual_seed(0)
+  N, C, H = 24, 128, 32
+  x = torch.randn(N, C, H, H, generator=g).to(device)
+  w = (torch.randn(C, C, 3, 3, generator=g) / 34.).to(device)
+  ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+  shape = (C, 0, N, H, H, C, 3, 3, 1, 1)
+  nbytes = int(lib.conv2d_fwd_ws_bytes(*shape))
+  ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=device)
+  stream = torch.cuda.current_stream(device).cuda_stream
+  out = {}
+  for name, wsp, wsb in (('x3_bf16_split', ws.data_ptr(), nbytes), ('f32_input_mfma', None, 0)):
+    y = torch.empty(N, C, H, H, dtype=torch.float32, device=device)
+    lib.conv2d_fwd_f32(x.data_ptr(), C, None, 0, w.data_ptr(), 0, None, None, 0, None, 1.0, y.data_ptr(), N, H, H, C, H, H,
+                       3, 3, 1, 1, wsp, wsb, stream)
+    torch.cuda.synchronize()
+    out[name + '_max_err_over_max_abs'] = float((y.double() - ref).abs().max() / ref.abs().max())
+  out['x3_path_selected'] = nbytes > 0
+  return out
+
+
 def main():
   args = parse()
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -257,6 +283,8 @@ def main():
       out['step_roofline'].update({'hbm_algorithmic_GBps': gbs, 'frac_hbm': gbs / 8000.0,
                                    'hbm_note': 'SURVEY.md 8(d) fused-traffic model: 3 x A_f bytes per image + 16 x 4 B per '
                                                'parameter per step, against 8 TB/s'})
+    if world == 1:
+      out['arithmetic_check'] = arithmetic_check(device)
     if world == 1 and args.sampler_steps > 0:        # like the CPU baseline: only in the single-GPU run
       try:
         out['sampler'] = sampler_rate(st, cfg, sde, score_model, per_gpu_batch, args.sampler_steps, device)
