@@ -110,7 +110,7 @@ long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int 
                              int stride, int pad);
 /* Which kernel family a call with full scratch takes (for profiling labels): dir 0 fwd, 1 dgrad, 2 wgrad;
  * returns 0 / 1 = f32-input MFMA with 64 / 128 tiles, 2 = bf16 three-way split, 3 = f32-input all-taps wgrad,
- * < 0 = unsupported shape. */
+ * 4 = streaming kernel for a <= 4 channel side (stem, head, 3-channel pyramids), < 0 = unsupported shape. */
 int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, int OH, int OW,
                        int KH, int KW, int stride, int pad, int w_layout);
 long stk_conv2d_dgrad_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW,

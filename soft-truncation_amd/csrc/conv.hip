@@ -529,6 +529,7 @@ __global__ __launch_bounds__(256) void slab_dgrad_kernel(ConvP p, int splits, in
 }
 
 #include "conv_x3.h"
+#include "conv_thin.h"
 
 // dw (in the weight's own layout) += alpha * sum over splits of slab[tap][co][ci]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
@@ -957,6 +958,24 @@ int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const f
   const long Ng = (long)N * p.OHW;
   const bool big = use_big_tile(Cout, Ng, 1);
   hipStream_t s = (hipStream_t)stream;
+  if (thin::geometry_ok(p) && Ng <= 0x7fffffffL) {          // a 3-channel side: streaming kernels (conv_thin.h)
+    const unsigned nblk = (unsigned)stk_cdiv(Ng, 256L);
+    if (C2 == 0 && p.Cin <= 4) {
+      thin::Args a = {x1, w, (long)p.Cin * p.taps, (long)p.taps, 0, p.Cin, Cout, p.taps, 0};
+      const dim3 grid(nblk, (unsigned)stk_cdiv(Cout, thin::OB));
+      if (p.taps == 9) hipLaunchKernelGGL((thin::thin_in_kernel<9>), grid, dim3(256), 0, s, p, a);
+      else hipLaunchKernelGGL((thin::thin_in_kernel<1>), grid, dim3(256), 0, s, p, a);
+      STK_CHECK_LAUNCH();
+      return STK_OK;
+    }
+    if (Cout <= 4) {
+      const unsigned nblk64 = (unsigned)stk_cdiv(Ng, 64L);
+      if (p.taps == 9) hipLaunchKernelGGL((thin::thin_out_kernel<9>), dim3(nblk64), dim3(256), 0, s, p, Cout);
+      else hipLaunchKernelGGL((thin::thin_out_kernel<1>), dim3(nblk64), dim3(256), 0, s, p, Cout);
+      STK_CHECK_LAUNCH();
+      return STK_OK;
+    }
+  }
   const X3Plan xr = x3_plan(p, p.Cin, C1, C2, Cout, Ng);
   if (ws && xr.ok && ws_bytes >= x3_ws_bytes(xr, Cout, p.Cin, p.taps))
     return launch_x3<EpFwd>(p, xr, x1, C1, x2, C2, Cout, Ng, 0, ws, s);
@@ -997,6 +1016,14 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
   const long Ng = (long)N * p.HW;
   const bool big = use_big_tile(Cin, Ng, 1);
   hipStream_t s = (hipStream_t)stream;
+  if (thin::geometry_ok(p) && Cout <= 4 && Ng <= 0x7fffffffL) {     // data gradient of a thin-output layer
+    thin::Args a = {dy, w, (long)p.taps, (long)Cin * p.taps, 1, Cout, Cin, p.taps, 1};
+    const dim3 grid((unsigned)stk_cdiv(Ng, 256L), (unsigned)stk_cdiv(Cin, thin::OB));
+    if (p.taps == 9) hipLaunchKernelGGL((thin::thin_in_kernel<9>), grid, dim3(256), 0, s, p, a);
+    else hipLaunchKernelGGL((thin::thin_in_kernel<1>), grid, dim3(256), 0, s, p, a);
+    STK_CHECK_LAUNCH();
+    return STK_OK;
+  }
   const X3Plan xr = x3_plan(p, Cout, Cout, 0, Cin, Ng);
   if (ws && xr.ok && ws_bytes >= x3_ws_bytes(xr, Cin, Cout, p.taps))
     return launch_x3<EpDgrad>(p, xr, dy, Cout, nullptr, 0, Cin, Ng, 1, ws, s);
@@ -1023,13 +1050,16 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, OH, OW, KH, KW, stride, pad)) return -1;
   const int Cin = C1 + C2;
+  p.w_layout = w_layout;
   if (dir == 0) {
     const long Ng = (long)N * p.OHW;
+    if (thin::geometry_ok(p) && ((C2 == 0 && Cin <= 4) || Cout <= 4)) return 4;
     if (x3_plan(p, Cin, C1, C2, Cout, Ng).ok) return 2;
     return use_big_tile(Cout, Ng, 1) && !(p.taps == 1 && w_layout == 0 && (Cin % 8)) ? 1 : 0;
   }
   if (dir == 1) {
     const long Ng = (long)N * p.HW;
+    if (thin::geometry_ok(p) && Cout <= 4) return 4;
     if (x3_plan(p, Cout, Cout, 0, Cin, Ng).ok) return 2;
     return use_big_tile(Cin, Ng, 1) && !(p.taps == 1 && w_layout == 1 && (Cout % 8)) ? 1 : 0;
   }

@@ -170,7 +170,7 @@ class Conv(Op):
     # algorithmic FLOPs of one launch (1 MAC = 2 FLOP); identical for fwd, dgrad and wgrad
     self.flops = 2.0 * N * OH * OW * Cout * (C1 + C2) * KH * KW
 
-  _VARIANT = {0: 't64', 1: 't128', 2: 'x3', 3: 't128'}
+  _VARIANT = {0: 't64', 1: 't128', 2: 'x3', 3: 't128', 4: 'thin'}
 
   def _kind(self, lib, direction):
     """Kernel label for the profiler: direction, taps and the kernel family csrc/conv.hip picks for this shape

@@ -279,6 +279,9 @@ CONV_CASES = [
   (48, 256, 0, 16, 16, 256, 1, 1, 0, 16, 16, 1, False, True, True),     # split kernel: NIN (w[Cin][Cout]) + residual
   (48, 128, 128, 16, 16, 256, 1, 1, 0, 16, 16, 0, False, False, False), # split kernel: 1x1 shortcut on a concat
   (96, 128, 0, 16, 16, 160, 1, 1, 0, 16, 16, 1, True, False, False),    # split kernel: NIN, ragged Cout
+  (3, 3, 0, 16, 16, 40, 1, 1, 0, 16, 16, 0, False, True, False),        # thin input, 1x1 (input_skip Combine)
+  (2, 64, 32, 8, 8, 3, 3, 1, 1, 8, 8, 0, False, True, True),            # thin output on a concat input (output_skip)
+  (2, 160, 0, 12, 20, 2, 3, 1, 1, 12, 20, 0, True, False, False),       # thin output, > 128 input channels, ragged map
   (40, 64, 64, 8, 8, 200, 3, 1, 1, 8, 8, 0, True, True, True),          # split kernel, K split into slabs: concat, ragged
   (100, 256, 0, 4, 4, 256, 3, 1, 1, 4, 4, 0, True, True, False),        # K-split slabs on 4x4 maps
 ]
