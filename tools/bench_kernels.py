@@ -63,6 +63,8 @@ def main():
   ]
   if not args.only or 'conv' in args.only:
     for C1, C2, H, Cout, K in conv_shapes:
+      if 'k1' in args.only and K != 1:
+        continue
       Cin = C1 + C2
       x1 = torch.randn(N, C1, H, H, device=d)
       x2 = torch.randn(N, C2, H, H, device=d) if C2 else None
