@@ -532,23 +532,40 @@ __global__ __launch_bounds__(256) void slab_dgrad_kernel(ConvP p, int splits, in
 #include "conv_thin.h"
 
 // dw (in the weight's own layout) += alpha * sum over splits of slab[tap][co][ci]
+// Threads walk the SLAB order four elements at a time, so the `splits` reads per element are 16-byte and coalesced
+// and only the single read-modify-write of dw is scattered (stride `taps` floats).  Indexing by the dw order instead
+// made every slab read a 9-way scatter and the kernel 2-3x slower than the partial sums' HBM time.
+// Summation order over the splits is fixed (z ascending): results do not depend on the launch geometry.
+__device__ __forceinline__ long splitk_dst(long j, int layout, long CC, int Cout, int Cin, int taps) {
+  if (layout == 0) {             // j = tap*Cout*Cin + (co*Cin + ci)  ->  (co*Cin + ci)*taps + tap
+    const int tap = (int)(j / CC);
+    return (j - (long)tap * CC) * taps + tap;
+  }
+  const int co = (int)(j / Cin), ci = (int)(j - (long)co * Cin);      // NIN: j = co*Cin + ci  ->  ci*Cout + co
+  return (long)ci * Cout + co;
+}
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                             long n, int splits, long stride, float alpha, int layout,
                                                             int Cout, int Cin, int taps) {
   const long gstride = (long)gridDim.x * 256;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += gstride) {
-    long src;
-    if (layout == 0) {           // i = (co*Cin + ci)*taps + tap
-      const int tap = (int)(i % taps);
-      const long mc = i / taps;  // co*Cin + ci
-      src = (long)tap * Cout * Cin + mc;
-    } else {                     // NIN: i = ci*Cout + co
-      const int co = (int)(i % Cout), ci = (int)(i / Cout);
-      src = (long)co * Cin + ci;
+  const long CC = (long)Cout * Cin;
+  const long n4 = ((n | stride) & 3) == 0 ? n / 4 : 0;                // float4 path needs 16-byte aligned slabs
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n4; v += gstride) {
+    const float4* src = reinterpret_cast<const float4*>(part) + v;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int z = 0; z < splits; ++z) {
+      const float4 t = src[(long)z * (stride / 4)];
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
     }
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += part[(long)z * stride + src];
-    dw[i] += alpha * s;
+    const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dw[splitk_dst(4 * v + e, layout, CC, Cout, Cin, taps)] += alpha * a4[e];
+  }
+  for (long j = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; j < n; j += gstride) {
+    float sum = 0.f;
+    for (int z = 0; z < splits; ++z) sum += part[(long)z * stride + j];
+    dw[splitk_dst(j, layout, CC, Cout, Cin, taps)] += alpha * sum;
   }
 }
 
@@ -1045,7 +1062,7 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
 }
 
 /* which kernel family a call with full scratch takes: 0/1 = f32-input MFMA with 64/128 tiles, 2 = bf16 three-way
- * split, 3 = f32-input all-taps weight gradient.  dir: 0 fwd, 1 dgrad, 2 wgrad. */
+ * split, 3 = f32-input all-taps weight gradient, 4 = thin-side streaming kernels.  dir: 0 fwd, 1 dgrad, 2 wgrad. */
 int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW,
                        int stride, int pad, int w_layout) {
   ConvP p = {};
@@ -1064,6 +1081,7 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
     if (x3_plan(p, Cout, Cout, 0, Cin, Ng).ok) return 2;
     return use_big_tile(Cin, Ng, 1) && !(p.taps == 1 && w_layout == 1 && (Cout % 8)) ? 1 : 0;
   }
+  if (thin::geometry_ok(p) && ((C2 == 0 && Cin <= 4) || Cout <= 4)) return 4;
   if (x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad).ok) return 2;
   const bool can9 = stride == 1 && pad == 1 && C2 == 0 && OH == H && OW == W && w_layout == 0;
   const WgradPlan q = wgrad_plan(Cin, N, Cout, OH, OW, KH, KW, can9);
@@ -1087,7 +1105,9 @@ long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, 
   const WgradPlan b = wgrad_plan(C1 + C2, N, Cout, OH, OW, KH, KW, false);
   const X3WgradPlan x = x3_wgrad_plan(C1, C2, N, Cout, OH, OW, OH, OW, KH, KW, 1, KH == 3 ? 1 : 0);
   const long na = (long)a.splits * a.slab, nb = (long)b.splits * b.slab, nx = x.ok ? (long)x.splits * x.slab : 0;
-  const long m = na > nb ? na : nb;
+  long m = na > nb ? na : nb;
+  if (C2 == 0 && C1 <= 4) { const long t = (long)thin::wgrad_slabs(N, (long)OH * OW, Cout) * Cout * C1 * KH * KW; m = t > m ? t : m; }
+  if (Cout <= 4) { const long t = (long)thin::wgrad_slabs(N, (long)OH * OW, C1 + C2) * Cout * (C1 + C2) * KH * KW; m = t > m ? t : m; }
   return (m > nx ? m : nx) * 4 + 256;
 }
 
@@ -1101,6 +1121,28 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
   int rc = fill_common(p, N, H, W, C1, C2, Cout, OH, OW, KH, KW, stride, pad);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  p.w_layout = w_layout;
+  if (thin::geometry_ok(p) && ((C2 == 0 && p.Cin <= 4) || Cout <= 4)) {      // a 3-channel side (conv_thin.h)
+    const bool stem = C2 == 0 && p.Cin <= 4;
+    thin::WArgs a = {};
+    if (stem) { a.thin = x1; a.b1 = dy; a.b2 = dy; a.B1 = Cout; a.B2 = 0; a.CT = p.Cin; a.head = 0; }
+    else { a.thin = dy; a.b1 = x1; a.b2 = C2 > 0 ? x2 : x1; a.B1 = C1; a.B2 = C2; a.CT = Cout; a.head = 1; }
+    const int BC = a.B1 + a.B2, S = thin::wgrad_slabs(N, p.HW, BC);
+    a.pxb = (int)((p.HW + 255) / 256); a.items = N * a.pxb; a.part = ws; a.slab = (long)Cout * p.Cin * p.taps;
+    if (ws_bytes < (long)S * a.slab * 4) return STK_EINVAL;
+    const dim3 grid((unsigned)S, (unsigned)stk_cdiv(BC, 4));
+    if (p.taps == 9) {
+      if (a.CT == 3) hipLaunchKernelGGL((thin::thin_wgrad_kernel<9, 3>), grid, dim3(256), 0, s, p, a);
+      else hipLaunchKernelGGL((thin::thin_wgrad_kernel<9, 4>), grid, dim3(256), 0, s, p, a);
+    } else {
+      hipLaunchKernelGGL((thin::thin_wgrad_kernel<1, 4>), grid, dim3(256), 0, s, p, a);
+    }
+    STK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((a.slab + 3) / 4)), dim3(256), 0, s, ws, dw, a.slab, S, a.slab,
+                       alpha, 0, Cout, p.Cin, p.taps);
+    STK_CHECK_LAUNCH();
+    return STK_OK;
+  }
   const X3WgradPlan xq = x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad);
   if (xq.ok && ws_bytes >= (long)xq.splits * xq.slab * 4) {
     p.x1 = x1; p.x2 = C2 > 0 ? x2 : x1; p.dy = dy; p.w_layout = w_layout; p.part = ws; p.part_stride = xq.slab;
@@ -1113,7 +1155,7 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
       if (C2 > 0) hipLaunchKernelGGL((x3::wgrad3_kernel<true>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split);
       else hipLaunchKernelGGL((x3::wgrad3_kernel<false>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split);
       STK_CHECK_LAUNCH();
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid(xq.slab)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((xq.slab + 3) / 4)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
                          xq.slab, alpha, w_layout, Cout, p.Cin, p.taps);
       STK_CHECK_LAUNCH();
       return STK_OK;
@@ -1127,7 +1169,7 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
     else { if (C2 > 0) STK_X3_WGRAD(true, 4); else STK_X3_WGRAD(false, 4); }
 #undef STK_X3_WGRAD
     STK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid(xq.slab)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((xq.slab + 3) / 4)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
                        xq.slab, alpha, w_layout, Cout, p.Cin, p.taps);
     STK_CHECK_LAUNCH();
     return STK_OK;
@@ -1156,7 +1198,7 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
     else rc = launch<CS, ConvP, AWgrad<CS>, BWgrad<CS, false>, EpWgrad>(p, Cout, p.Cin, K, q.k_per_split, q.splits, p.taps, s, true);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid(q.slab)), dim3(256), 0, s, ws, dw, q.slab, q.splits,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((q.slab + 3) / 4)), dim3(256), 0, s, ws, dw, q.slab, q.splits,
                      q.slab, alpha, w_layout, Cout, p.Cin, p.taps);
   STK_CHECK_LAUNCH();
   return STK_OK;

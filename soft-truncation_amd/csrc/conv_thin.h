@@ -16,6 +16,8 @@
 //                     one thread per pixel, CO accumulators, weights broadcast from LDS in blocks of 128 channels;
 //                     the nine shifted reads of a channel plane overlap between neighbouring lanes and hit L1.
 //
+//   thin_wgrad_kernel  the weight gradient of either kind (below).
+//
 // Both are HBM-bound on the big tensor (4 bytes per element, once).  Epilogues are the same arithmetic as EpFwd /
 // EpDgrad.  3x3 / stride 1 / pad 1 and 1x1 / stride 1 / pad 0 only, [Cout,Cin,kh,kw] weights.
 #pragma once
@@ -161,6 +163,92 @@ __global__ __launch_bounds__(256) void thin_out_kernel(ConvP p, int CO) {
   if (p.res) v += p.res[idx];
   if (p.use_div) v *= p.inv_div;
   p.y[idx] = v;
+}
+
+// Weight gradient of a layer with a thin side:  dw[big channel, thin channel, tap] = sum over (n, pixel) of
+// big[n, bc, q] * thin[n, tc, q + off(tap)].  For the stem / Combine layers big = dy and thin = x (tap as is); for the
+// thin-OUTPUT layers big = x (a concat of two tensors at most), thin = dy and q + off(t) pairs with the weight tap
+// taps-1-t.  A workgroup owns four big channels and walks 256-pixel items of the flattened (image, pixel block) list
+// with stride gridDim.x; a thread keeps 4 x (CT*taps) sums in registers, fed by one patch of the thin tensor (L1/L2
+// hits) and four coalesced reads of the big tensor -- which is read exactly once overall.  The 256 per-thread sums
+// of a workgroup meet in LDS (per wave, conflict-free pitch 65, then across the four waves in a fixed order) and go
+// to slab blockIdx.x in the [tap][co][ci] layout of splitk_reduce_kernel.
+struct WArgs {
+  const float* thin; const float* b1; const float* b2;
+  int B1, B2;          // channels of the big tensor's two sources (B2 = 0: one source)
+  int CT;              // thin channels
+  int head;            // 0: thin = x (dw[bc][tc][tap]);  1: thin = dy (dw[tc][bc][taps-1-tap])
+  int items, pxb;      // items = N * pxb, pxb = ceil(HW / 256)
+  float* part; long slab;
+};
+
+template <int TAPS, int CTT>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(ConvP p, WArgs a) {
+  constexpr int KK = CTT * TAPS;
+  __shared__ float red[4][KK * 65];
+  __shared__ float wsum[4][4 * KK];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int BC = a.B1 + a.B2, bc0 = blockIdx.y * 4;
+  float acc[4][KK];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < KK; ++k) acc[j][k] = 0.f;
+  for (int it = blockIdx.x; it < a.items; it += gridDim.x) {
+    const int n = it / a.pxb, hw = (it - n * a.pxb) * 256 + tid;
+    const bool live = hw < p.HW;
+    const int y = hw / p.W, x = hw - y * p.W;
+    const unsigned mask = live ? tap_mask(y, x, p.H, p.W, TAPS) : 0u;
+    const float* tb = a.thin + (long)n * a.CT * p.HW + (live ? hw : 0);
+    float pv[KK];
+#pragma unroll
+    for (int c = 0; c < CTT; ++c)
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const bool ok = c < a.CT && ((mask >> t) & 1u);
+        const int off = TAPS == 9 ? (t / 3 - 1) * p.W + (t % 3 - 1) : 0;
+        const float v = tb[ok ? (long)c * p.HW + off : 0];
+        pv[c * TAPS + t] = ok ? v : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int bc = bc0 + j;
+      if (bc < BC) {                                                  // uniform
+        const float* bp = bc < a.B1 ? a.b1 + ((long)n * a.B1 + bc) * p.HW : a.b2 + ((long)n * a.B2 + (bc - a.B1)) * p.HW;
+        const float v = live ? bp[hw] : 0.f;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) acc[j][k] += v * pv[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int k = 0; k < KK; ++k) red[wv][k * 65 + lane] = acc[j][k];
+    __syncthreads();
+    if (lane < KK) {
+      float sum = 0.f;
+      for (int i = 0; i < 64; ++i) sum += red[wv][lane * 65 + i];
+      wsum[wv][j * KK + lane] = sum;
+    }
+    __syncthreads();
+  }
+  if (tid < 4 * KK) {
+    const int j = tid / KK, k = tid - j * KK, c = k / TAPS, t = k - c * TAPS, bc = bc0 + j;
+    if (bc < BC && c < a.CT) {
+      const float total = ((wsum[0][tid] + wsum[1][tid]) + wsum[2][tid]) + wsum[3][tid];
+      const long idx = a.head ? ((long)(TAPS - 1 - t) * a.CT + c) * BC + bc : ((long)t * BC + bc) * a.CT + c;
+      a.part[(long)blockIdx.x * a.slab + idx] = total;
+    }
+  }
+}
+
+// number of slabs (= gridDim.x) of thin_wgrad_kernel: ~1024 workgroups over the chip, never more than the work items
+inline int wgrad_slabs(int N, long HW, int BC) {
+  const long items = (long)N * ((HW + 255) / 256);
+  long s = 1024 / ((BC + 3) / 4);
+  if (s < 1) s = 1;
+  return (int)(s < items ? s : items);
 }
 
 inline bool geometry_ok(const ConvP& p) {
