@@ -105,6 +105,14 @@ def main():
       rec('gn_silu.fwd', shape, timeit(lambda: call(lib, 'gn_fwd_f32', x, C, None, 0, g, b, y, mean, rstd, Nb, H * H, G, 1e-6, 1, 0.1, 1, None, ws), args.reps), nbytes=2 * nb)
       rec('gn_silu.bwd', shape, timeit(lambda: call(lib, 'gn_bwd_f32', dy, x, C, None, 0, g, b, mean, rstd, dx, 0.0, None, 0.0, dg, db, ws, Nb, H * H, G, 1, 0.1, 1, None), args.reps), nbytes=3 * nb)
 
+  if not args.only or 'bias' in args.only:
+    for C, H in [(128, 32), (256, 16), (256, 8), (256, 4)]:
+      dy = torch.randn(N, C, H, H, device=d)
+      db, dt, ws = torch.zeros(C, device=d), torch.zeros(N, C, device=d), torch.empty(N * C + 64, device=d)
+      shape = f'C{C} @{H}x{H} b{N}'
+      rec('bias_grad', shape, timeit(lambda: call(lib, 'bias_grad_f32', dy, N, C, H * H, 1.0, None, 0, db, ws), args.reps), nbytes=dy.numel() * 4)
+      rec('bias_grad+temb', shape, timeit(lambda: call(lib, 'bias_grad_f32', dy, N, C, H * H, 1.0, dt, C, db, ws), args.reps), nbytes=dy.numel() * 4)
+
   if not args.only or 'misc' in args.only:
     n = N * 256 * 16 * 16
     a, b2, o = torch.randn(n, device=d), torch.randn(n, device=d), torch.empty(n, device=d)
