@@ -823,7 +823,9 @@ inline X3Plan x3_plan(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
   if (tiles >= 192) { r.ok = 1; return r; }
   long splits = 512 / tiles;
   if (splits > nch / 6) splits = nch / 6;            // >= 6 chunks per workgroup, or the prologue dominates
-  if (tiles < 16 || splits < 2) return r;
+  // few tiles: the 3x3 layers still pay (4 tiles of a 256-channel 8x8 map at batch 4: 94 us on 16 workgroups of the
+  // f32-input kernel); a 1x1 layer has too few chunks to split
+  if ((tiles < 16 && p.taps != 9) || splits < 2) return r;
   r.chunks_per_split = (int)((nch + splits - 1) / splits);
   r.splits = (nch + r.chunks_per_split - 1) / r.chunks_per_split;
   r.slab = (long)M * Ng;

@@ -284,6 +284,8 @@ CONV_CASES = [
   (2, 160, 0, 12, 20, 2, 3, 1, 1, 12, 20, 0, True, False, False),       # thin output, > 128 input channels, ragged map
   (40, 64, 64, 8, 8, 200, 3, 1, 1, 8, 8, 0, True, True, True),          # split kernel, K split into slabs: concat, ragged
   (100, 256, 0, 4, 4, 256, 3, 1, 1, 4, 4, 0, True, True, False),        # K-split slabs on 4x4 maps
+  (4, 256, 0, 4, 4, 256, 3, 1, 1, 4, 4, 0, True, False, True),          # K-split, one half-empty pixel tile (batch 4)
+  (4, 128, 128, 8, 8, 256, 3, 1, 1, 8, 8, 0, False, True, False),       # K-split, 4 tiles, concat input (batch 4)
 ]
 
 
