@@ -88,6 +88,7 @@ def parse():
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--workload', default='cifar10', choices=sorted(WORKLOADS))
   ap.add_argument('--batch', type=int, default=0, help='per-GPU batch override')
+  ap.add_argument('--fir', action='store_true', help='same net with model.fir=True (FIR resampling through upfirdn2d); SURVEY 8(d)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-kernel-timer', action='store_true')
   ap.add_argument('--prof-steps', type=int, default=3)
@@ -97,11 +98,13 @@ def parse():
   return ap.parse_args()
 
 
-def cpu_baseline(st, cfg_name, batch, steps):
+def cpu_baseline(st, cfg_name, batch, steps, fir=False):
   """The oracle restatement (PyTorch CPU, oneDNN) of the same training step on the host cores."""
   import ref_torch
   cfg = st.configs.get_config(cfg_name)
   cfg.device = torch.device('cpu')
+  if fir:
+    cfg.model.fir = True
   sde = st.sde_lib.get_sde(cfg, None)
   # the product model only serves as the parameter initialiser here (same shapes / state_dict keys)
   torch.manual_seed(0)
@@ -193,6 +196,9 @@ def main():
     per_gpu_batch = args.batch
   cfg = st.configs.get_config(cfg_name)
   cfg.device = device
+  if args.fir:
+    cfg.model.fir = True
+    desc += ' with model.fir=True'
   st.engine.ddp.seed_everything(cfg.seed)                  # numpy shared (t_min), torch per rank
 
   sde = st.sde_lib.get_sde(cfg, None)
@@ -291,7 +297,7 @@ def main():
       except Exception as e:                         # the reference's RVE sampling raises: report, do not fail
         out['sampler'] = {'error': repr(e)[:200]}
     if world == 1 and not args.no_cpu_baseline:
-      out['cpu_baseline'] = cpu_baseline(st, cfg_name, args.cpu_batch, args.cpu_steps)
+      out['cpu_baseline'] = cpu_baseline(st, cfg_name, args.cpu_batch, args.cpu_steps, args.fir)
     print(json.dumps(out), flush=True)
   if world > 1:
     dist.destroy_process_group()
