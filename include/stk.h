@@ -124,6 +124,38 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout,
                          float* dx1, int C1, float beta1, float* dx2, int C2, float beta2,
                          float alpha, int N, int H, int W, int Cout, int OH, int OW,
                          int KH, int KW, int stride, int pad, void* ws, long ws_bytes, void* stream);
+/* Prepared weights.  The split kernel reads its weights re-laid out and split into three bf16 planes; the calls above
+ * prepare them into ws on every call.  A caller whose weights change once per optimizer step (training) or never
+ * (a sampling loop: ~2000 network evaluations on fixed weights, sampling.py:365-433) prepares all layers in ONE
+ * launch and hands each call its block:
+ *   stk_conv2d_wp_bytes     bytes of the block of one layer and direction (dir 0 forward, 1 data gradient);
+ *                           0 = this direction of this shape does not take the split kernel: pass wp = NULL
+ *   stk_conv2d_wp_desc      host-side fill of one table entry (wp 256-byte aligned device memory of that size);
+ *                           returns the entry's work items (> 0) or a negative error
+ *   stk_conv2d_wprep_batch  one launch over a DEVICE-resident table of n entries; max_items = the largest work
+ *                           item count of the table
+ *   stk_conv2d_{fwd,dgrad}_wp_f32   as stk_conv2d_{fwd,dgrad}_f32 with wp = the prepared block (results are
+ *                           bit-identical to the wp = NULL call); ws is still needed for the K-split slabs.
+ * The caller owns coherence: a block is valid until the layer's weights change. */
+typedef struct StkWprepDesc {
+  const float* w; void* wp; long sm, sk; int M, Kc, Mpad, taps, flip, reserved;
+} StkWprepDesc;
+long stk_conv2d_wp_bytes(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW,
+                         int stride, int pad);
+long stk_conv2d_wp_desc(int dir, const float* w, int w_layout, int Cin, int Cout, int KH, int KW,
+                        void* wp, StkWprepDesc* out);
+int stk_conv2d_wprep_batch(const StkWprepDesc* descs_dev, int n, long max_items, void* stream);
+int stk_conv2d_fwd_wp_f32(const float* x1, int C1, const float* x2, int C2,
+                          const float* w, int w_layout, const float* bias,
+                          const float* temb, int temb_stride, const float* res, float out_div,
+                          float* y, int N, int H, int W, int Cout, int OH, int OW,
+                          int KH, int KW, int stride, int pad,
+                          const void* wp, void* ws, long ws_bytes, void* stream);
+int stk_conv2d_dgrad_wp_f32(const float* dy, const float* w, int w_layout,
+                            float* dx1, int C1, float beta1, float* dx2, int C2, float beta2,
+                            float alpha, int N, int H, int W, int Cout, int OH, int OW,
+                            int KH, int KW, int stride, int pad,
+                            const void* wp, void* ws, long ws_bytes, void* stream);
 long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW);
 int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const float* dy,
                          float* dw, int w_layout, float alpha, float* ws, long ws_bytes,

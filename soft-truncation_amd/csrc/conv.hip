@@ -836,22 +836,30 @@ inline long x3_ws_bytes(const X3Plan& r, int M, int Kc, int taps) {
   return r.ok ? x3::wp_bytes(M, Kc, taps) + 512 + (r.splits > 1 ? r.splits * r.slab * 4 : 0) : 0;
 }
 // dgrad = 1: rows are input channels, k output channels, taps flipped
+inline void x3_weight_strides(const ConvP& p, int dgrad, long& sm, long& sk) {
+  if (p.w_layout == 0) { sm = dgrad ? p.taps : (long)p.Cin * p.taps; sk = dgrad ? (long)p.Cin * p.taps : p.taps; }
+  else { sm = dgrad ? p.Cout : 1; sk = dgrad ? 1 : p.Cout; }          // NIN w[Cin][Cout]
+}
+// wp_ready: weights already prepared by stk_conv2d_wprep_batch (then ws only holds the K-split slabs)
 template <class EP>
 int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2, int S2, int M, long Ng, int dgrad,
-              void* ws, hipStream_t s) {
+              void* ws, hipStream_t s, const void* wp_ready = nullptr) {
   x3::Src q;
   q.s1 = s1; q.s2 = S2 > 0 ? s2 : s1; q.S1 = S1; q.S2 = S2; q.Kc = S1 + S2; q.Mpad = x3::pad128(M); q.taps = p.taps;
   unsigned short* wp = reinterpret_cast<unsigned short*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  q.wp = wp;
   p.part = reinterpret_cast<float*>(((uintptr_t)wp + x3::wp_bytes(M, q.Kc, p.taps) + 255) & ~(uintptr_t)255);
   p.part_stride = r.slab;
-  const long n = (long)q.Mpad * q.Kc;
-  long sm, sk;
-  if (p.w_layout == 0) { sm = dgrad ? p.taps : (long)p.Cin * p.taps; sk = dgrad ? (long)p.Cin * p.taps : p.taps; }
-  else { sm = dgrad ? p.Cout : 1; sk = dgrad ? 1 : p.Cout; }          // NIN w[Cin][Cout]
-  hipLaunchKernelGGL(x3::wprep_kernel, dim3((unsigned)stk_cdiv(n, 256)), dim3(256), 0, s, p.w, wp, M, q.Kc, q.Mpad, sm, sk,
-                     p.taps, dgrad);
-  STK_CHECK_LAUNCH();
+  if (wp_ready) {
+    q.wp = static_cast<const unsigned short*>(wp_ready);
+  } else {
+    q.wp = wp;
+    const long n = (long)q.Mpad * q.Kc;
+    long sm, sk;
+    x3_weight_strides(p, dgrad, sm, sk);
+    hipLaunchKernelGGL(x3::wprep_kernel, dim3((unsigned)stk_cdiv(n, 256)), dim3(256), 0, s, p.w, wp, M, q.Kc, q.Mpad, sm, sk,
+                       p.taps, dgrad);
+    STK_CHECK_LAUNCH();
+  }
   const int tm = q.Mpad / 128, tn = stk_cdiv((int)Ng, 128), nch = p.taps * (q.Kc / x3::KC);
   const dim3 grid((unsigned)(tm * tn * r.splits));
 #define STK_X3_LAUNCH(E, DUAL, TAPS)                                                                                \
@@ -962,10 +970,10 @@ inline WgradPlan wgrad_plan(int Cin, int N, int Cout, int OH, int OW, int KH, in
 
 extern "C" {
 
-int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* w, int w_layout,
-                       const float* bias, const float* temb, int temb_stride, const float* res, float out_div,
-                       float* y, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad,
-                       void* ws, long ws_bytes, void* stream) {
+int stk_conv2d_fwd_wp_f32(const float* x1, int C1, const float* x2, int C2, const float* w, int w_layout,
+                          const float* bias, const float* temb, int temb_stride, const float* res, float out_div,
+                          float* y, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad,
+                          const void* wp, void* ws, long ws_bytes, void* stream) {
   if (!x1 || !w || !y || (C2 > 0 && !x2) || out_div == 0.f || (w_layout != 0 && w_layout != 1) ||
       (w_layout == 1 && (KH != 1 || KW != 1)))
     return STK_EINVAL;
@@ -998,7 +1006,8 @@ int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const f
   }
   const X3Plan xr = x3_plan(p, p.Cin, C1, C2, Cout, Ng);
   if (ws && xr.ok && ws_bytes >= x3_ws_bytes(xr, Cout, p.Cin, p.taps))
-    return launch_x3<EpFwd>(p, xr, x1, C1, x2, C2, Cout, Ng, 0, ws, s);
+    return launch_x3<EpFwd>(p, xr, x1, C1, x2, C2, Cout, Ng, 0, ws, s, wp);
+  if (wp) return STK_EINVAL;      // prepared weights exist only for the shapes stk_conv2d_wp_bytes reports
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;
     if (C2 > 0) {
@@ -1021,9 +1030,17 @@ int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const f
   return launch<CS, ConvP, AFwdNin<CS>, BFwd<CS, 1, true>, EpFwd>(p, Cout, Ng, K, K, 1, 1, s);
 }
 
-int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* dx1, int C1, float beta1, float* dx2,
-                         int C2, float beta2, float alpha, int N, int H, int W, int Cout, int OH, int OW, int KH,
-                         int KW, int stride, int pad, void* ws, long ws_bytes, void* stream) {
+int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* w, int w_layout,
+                       const float* bias, const float* temb, int temb_stride, const float* res, float out_div,
+                       float* y, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad,
+                       void* ws, long ws_bytes, void* stream) {
+  return stk_conv2d_fwd_wp_f32(x1, C1, x2, C2, w, w_layout, bias, temb, temb_stride, res, out_div, y, N, H, W, Cout, OH, OW,
+                               KH, KW, stride, pad, nullptr, ws, ws_bytes, stream);
+}
+
+int stk_conv2d_dgrad_wp_f32(const float* dy, const float* w, int w_layout, float* dx1, int C1, float beta1, float* dx2,
+                            int C2, float beta2, float alpha, int N, int H, int W, int Cout, int OH, int OW, int KH,
+                            int KW, int stride, int pad, const void* wp, void* ws, long ws_bytes, void* stream) {
   if (!dy || !w || (!dx1 && !dx2) || (w_layout != 0 && w_layout != 1) || (w_layout == 1 && (KH != 1 || KW != 1)))
     return STK_EINVAL;
   ConvP p = {};
@@ -1046,7 +1063,8 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
   }
   const X3Plan xr = x3_plan(p, Cout, Cout, 0, Cin, Ng);
   if (ws && xr.ok && ws_bytes >= x3_ws_bytes(xr, Cin, Cout, p.taps))
-    return launch_x3<EpDgrad>(p, xr, dy, Cout, nullptr, 0, Cin, Ng, 1, ws, s);
+    return launch_x3<EpDgrad>(p, xr, dy, Cout, nullptr, 0, Cin, Ng, 1, ws, s, wp);
+  if (wp) return STK_EINVAL;
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;
     if (big) return launch<CB, ConvP, ADgrad9<CB>, BDgrad<CB, 9>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
@@ -1061,6 +1079,13 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
   if (K % 8 != 0) return launch<CS, ConvP, ADgradNinGen<CS>, BDgrad<CS, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
   if (big) return launch<CB, ConvP, ADgradNin<CB>, BDgrad<CB, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
   return launch<CS, ConvP, ADgradNin<CS>, BDgrad<CS, 1>, EpDgrad>(p, Cin, Ng, K, K, 1, 1, s);
+}
+
+int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* dx1, int C1, float beta1, float* dx2,
+                         int C2, float beta2, float alpha, int N, int H, int W, int Cout, int OH, int OW, int KH,
+                         int KW, int stride, int pad, void* ws, long ws_bytes, void* stream) {
+  return stk_conv2d_dgrad_wp_f32(dy, w, w_layout, dx1, C1, beta1, dx2, C2, beta2, alpha, N, H, W, Cout, OH, OW, KH, KW, stride,
+                                 pad, nullptr, ws, ws_bytes, stream);
 }
 
 /* which kernel family a call with full scratch takes: 0/1 = f32-input MFMA with 64/128 tiles, 2 = bf16 three-way
@@ -1088,6 +1113,43 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
   const bool can9 = stride == 1 && pad == 1 && C2 == 0 && OH == H && OW == W && w_layout == 0;
   const WgradPlan q = wgrad_plan(Cin, N, Cout, OH, OW, KH, KW, can9);
   return q.mode9 ? 3 : q.big;
+}
+
+/* Prepared weights (the bf16 three-way split in the A-tile layout of conv_x3.h), so that a caller whose weights change
+ * once per optimizer step -- or never, in a sampling loop -- prepares them once instead of once per call.
+ * dir: 0 forward, 1 data gradient.  Bytes are 0 for shapes whose call does not take the split kernel. */
+long stk_conv2d_wp_bytes(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
+  if (dir != 0 && dir != 1) return 0;
+  if (stk_conv2d_variant(dir, C1, C2, N, H, W, Cout, H, W, KH, KW, stride, pad, 0) != 2) return 0;
+  const int Cin = C1 + C2;
+  return (dir == 0 ? x3::wp_bytes(Cout, Cin, KH * KW) : x3::wp_bytes(Cin, Cout, KH * KW)) + 256;
+}
+
+/* Host-side fill of one descriptor; returns the number of (row, k) work items of this layer (the caller passes the
+ * maximum over its table to stk_conv2d_wprep_batch) or a negative error.  wp must be 256-byte aligned. */
+long stk_conv2d_wp_desc(int dir, const float* w, int w_layout, int Cin, int Cout, int KH, int KW, void* wp,
+                        StkWprepDesc* out) {
+  if (!w || !wp || !out || (dir != 0 && dir != 1) || (w_layout != 0 && w_layout != 1) || Cin <= 0 || Cout <= 0 ||
+      (KH * KW != 9 && KH * KW != 1) || (w_layout == 1 && KH * KW != 1) || ((uintptr_t)wp & 255))
+    return STK_EINVAL;
+  ConvP p = {};
+  p.Cin = Cin; p.Cout = Cout; p.taps = KH * KW; p.w_layout = w_layout;
+  long sm, sk;
+  x3_weight_strides(p, dir, sm, sk);
+  out->w = w; out->wp = wp; out->sm = sm; out->sk = sk;
+  out->M = dir ? Cin : Cout; out->Kc = dir ? Cout : Cin; out->Mpad = x3::pad128(out->M); out->taps = p.taps;
+  out->flip = dir; out->reserved = 0;
+  return (long)out->Mpad * out->Kc;
+}
+
+int stk_conv2d_wprep_batch(const StkWprepDesc* descs_dev, int n, long max_items, void* stream) {
+  static_assert(sizeof(StkWprepDesc) == sizeof(x3::WprepDesc), "descriptor layout");
+  if (!descs_dev || n <= 0 || max_items <= 0 || n > 65535) return STK_EINVAL;
+  const dim3 grid((unsigned)stk_cdiv(max_items, 256L), (unsigned)n);
+  hipLaunchKernelGGL(x3::wprep_batch_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const x3::WprepDesc*>(descs_dev));
+  STK_CHECK_LAUNCH();
+  return STK_OK;
 }
 
 long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {

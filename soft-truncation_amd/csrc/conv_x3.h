@@ -61,10 +61,12 @@ __device__ __forceinline__ unsigned pack_hi(float lo, float hi) {
 //     forward  [Cout,Cin,kh,kw]: sm = Cin*taps, sk = taps      NIN [Cin,Cout]: sm = 1, sk = Cout
 //     dgrad    [Cout,Cin,kh,kw]: sm = taps, sk = Cin*taps, flip   NIN: sm = Cout, sk = 1
 // One thread per (row, k): reads its taps (contiguous).
-__global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int R,
-                                                    int Kd, int Mpad, long sm, long sk, int taps, int flip) {
+struct WprepDesc {        // == StkWprepDesc (include/stk.h)
+  const float* w; unsigned short* wp; long sm, sk; int M, Kc, Mpad, taps, flip, reserved;
+};
+__device__ __forceinline__ void wprep_one(const float* __restrict__ w, unsigned short* __restrict__ out, int R, int Kd,
+                                          int Mpad, long sm, long sk, int taps, int flip, long i) {
   const long total = (long)Mpad * Kd;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   // k fastest inside a group of 32 so that the 2-byte stores of a wave are contiguous
   const int kl = (int)(i & 31);
@@ -81,6 +83,16 @@ __global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w,
     out[plane + o] = (unsigned short)(__float_as_uint(h1) >> 16);
     out[2 * plane + o] = (unsigned short)(__float_as_uint(h2) >> 16);
   }
+}
+__global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int R,
+                                                    int Kd, int Mpad, long sm, long sk, int taps, int flip) {
+  wprep_one(w, out, R, Kd, Mpad, sm, sk, taps, flip, (long)blockIdx.x * 256 + threadIdx.x);
+}
+// All layers of a network in one launch: blockIdx.y picks the descriptor, blockIdx.x walks its (row, k) pairs
+// (grid.x is sized for the largest layer; blocks past the end of a smaller one exit).
+__global__ __launch_bounds__(256) void wprep_batch_kernel(const WprepDesc* __restrict__ descs) {
+  const WprepDesc d = descs[blockIdx.y];
+  wprep_one(d.w, d.wp, d.M, d.Kc, d.Mpad, d.sm, d.sk, d.taps, d.flip, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
 // Staging is cut into 24 slices so that the kernel can place one slice after each MFMA of a 24-MFMA group (the

@@ -18,9 +18,12 @@ Backend selection is explicit and never silent: the default backend is the HIP l
 (``engine.lib.load()``, raises if it is not built); a test may inject another implementation
 of include/stk.h (the oracle's CPU restatement) with ``set_backend``.
 """
+import contextlib
+import ctypes
 import os
 import warnings
 
+import numpy as np
 import torch
 
 from . import lib as stk_lib
@@ -36,7 +39,13 @@ def _arena(n, device):
     t.fill_(float('nan'))
   return t
 from .flat import FlatParams
-from .graph import Graph, Runtime
+from .graph import Conv, Graph, Runtime
+
+
+class _WprepDesc(ctypes.Structure):        # StkWprepDesc of include/stk.h
+  _fields_ = [('w', ctypes.c_void_p), ('wp', ctypes.c_void_p), ('sm', ctypes.c_long), ('sk', ctypes.c_long),
+              ('M', ctypes.c_int), ('Kc', ctypes.c_int), ('Mpad', ctypes.c_int), ('taps', ctypes.c_int),
+              ('flip', ctypes.c_int), ('reserved', ctypes.c_int)]
 
 
 class Context:
@@ -66,6 +75,38 @@ class Program:
     self.const = const.to(device)
     self.ws = _arena(graph.ws_bytes // 4, device)
     self.free = []
+    # prepared weights (include/stk.h): arena + device-resident descriptor table, built on first use.
+    # Table order: all forward blocks, then all data-gradient blocks, so a no-grad call prepares a prefix.
+    self.wp = None
+    self.wp_table = None
+    self.wp_counts = (0, 0)      # entries: forward only, forward + data gradient
+    self.wp_items = 0
+    self.wp_frozen = 0           # entries valid under Executor.frozen_weights()
+
+  def build_wp(self, lib, param_base):
+    g = self.graph
+    self.wp = torch.empty(max(g.wp_bytes, 256), dtype=torch.uint8, device=self.device)
+    base = self.wp.data_ptr()
+    assert base % 256 == 0
+    descs, items = [], 0
+    for direction in (0, 1):
+      for op in g.ops:
+        if not isinstance(op, Conv) or op.wp_off[direction] is None:
+          continue
+        d = _WprepDesc()
+        n = lib.conv2d_wp_desc(direction, param_base + 4 * op.w.off, op.w_layout, op.C1 + op.C2, op.Cout, op.KH, op.KW,
+                               base + op.wp_off[direction], ctypes.byref(d))
+        if n <= 0:
+          raise RuntimeError(f'stk_conv2d_wp_desc failed for a {op.C1 + op.C2}->{op.Cout} {op.KH}x{op.KW} layer (rc={n})')
+        items = max(items, n)
+        descs.append(d)
+      if direction == 0:
+        n_fwd = len(descs)
+    self.wp_counts = (n_fwd, len(descs))
+    self.wp_items = items
+    if descs:
+      raw = b''.join(bytes(d) for d in descs)
+      self.wp_table = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(self.device)
 
   def acquire(self):
     c = self.free.pop() if self.free else Context(self)
@@ -107,6 +148,10 @@ class Executor:
     self.profiler = None     # engine.profile.KernelTimer or None
     self.use_graphs = os.environ.get('STK_GRAPHS', '1') != '0'
     self.graph_replays = 0
+    # STK_WP=0: every conv call prepares its own weights (the plain C-ABI calls) instead of one batched launch per
+    # forward; a debugging switch, results are bit-identical
+    self.use_wp = os.environ.get('STK_WP', '1') != '0'
+    self._frozen = 0
 
   # -- parameters ---------------------------------------------------------------------------------
   def set_backend(self, backend):
@@ -146,6 +191,34 @@ class Executor:
       prog = self.programs[key] = Program(g, self.flat.device)
     return prog
 
+  # -- prepared weights ---------------------------------------------------------------------------
+  def _prepare_weights(self, prog, need_dgrad):
+    """One launch that splits / re-lays-out the weights of every conv layer of `prog` for the split kernels
+    (forward blocks; data-gradient blocks too when a backward may follow).  Runs before every forward -- the
+    weights may have changed since the last one -- except inside :meth:`frozen_weights`."""
+    if not (self.use_wp and self.lib.is_device):
+      return
+    if prog.wp is None:
+      prog.build_wp(self.lib, self.flat.data.data_ptr())
+    n = prog.wp_counts[1 if need_dgrad else 0]
+    if n == 0 or (self._frozen and prog.wp_frozen >= n):
+      return
+    self.lib.conv2d_wprep_batch(prog.wp_table.data_ptr(), n, prog.wp_items, stk_lib.stream_ptr(self.flat.device))
+    prog.wp_frozen = n if self._frozen else 0
+
+  @contextlib.contextmanager
+  def frozen_weights(self):
+    """Promise that the parameters do not change inside the block (a sampling loop: thousands of network
+    evaluations on fixed weights, sampling.py:365-433): the weights are prepared on the first evaluation only."""
+    self._frozen += 1
+    try:
+      yield self
+    finally:
+      self._frozen -= 1
+      if self._frozen == 0:
+        for prog in self.programs.values():
+          prog.wp_frozen = 0
+
   # -- execution ----------------------------------------------------------------------------------
   def _copy_in(self, c, key, value):
     t = c.prog.graph.inputs.get(key)
@@ -163,6 +236,8 @@ class Executor:
                  flat.data.data_ptr(), flat.grad.data_ptr(), prog.const.data_ptr(),
                  prog.ws.data_ptr(), prog.graph.ws_bytes, training, seed, seed_dev)
     rt.prof = self.profiler
+    if prog.wp is not None and prog.wp_table is not None:
+      rt.wp = prog.wp.data_ptr()
     return rt
 
   def _replay(self, c, direction, training):
@@ -203,6 +278,7 @@ class Executor:
     self._copy_in(c, 'emb', emb_in)
     if sigma is not None:
       self._copy_in(c, 'sigma', sigma)
+    self._prepare_weights(prog, torch.is_grad_enabled())
     seed = 0
     if training and self.model._uses_dropout():
       seed = int(torch.randint(0, 2 ** 62, (1,)).item())

@@ -60,6 +60,7 @@ class Runtime:
     self.training = training
     self.seed = seed
     self.seed_dev = seed_dev
+    self.wp = 0           # base address of the program's prepared-weight arena (0: every conv prepares per call)
     self.prof = None      # optional engine.profile.KernelTimer: HIP events around the contraction launches
 
   def timed(self, kind, flops, fn, *args):
@@ -188,12 +189,34 @@ class Conv(Op):
   def _dims(self):
     return (self.N, self.H, self.W, self.Cout, self.OH, self.OW, self.KH, self.KW, self.stride, self.pad)
 
+  # prepared weights (include/stk.h "Prepared weights"): byte offsets of this layer's blocks in the program's arena,
+  # assigned by Graph.finalize; None = this direction of this shape prepares nothing
+  wp_off = (None, None)
+
+  def plan_wp(self, lib, offset):
+    """Reserve the forward / data-gradient blocks at `offset`; returns the new end of the arena."""
+    shape = (self.C1, self.C2, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self.stride, self.pad)
+    offs = []
+    for direction in (0, 1):
+      nb = int(lib.conv2d_wp_bytes(direction, *shape)) if self.OH == self.H and self.OW == self.W else 0
+      if nb > 0:
+        offs.append(offset)
+        offset = _round_up(offset + nb, 256)
+      else:
+        offs.append(None)
+    self.wp_off = tuple(offs)
+    return offset
+
+  def _wp(self, rt, direction):
+    off = self.wp_off[direction]
+    return rt.wp + off if (rt.wp and off is not None) else None
+
   def forward(self, rt):
     temb = rt.v(self.temb) + 4 * self.temb_col if self.temb is not None else None
-    rt.timed(self._kind(rt.lib, 'fwd'), self.flops, rt.lib.conv2d_fwd_f32,
+    rt.timed(self._kind(rt.lib, 'fwd'), self.flops, rt.lib.conv2d_fwd_wp_f32,
              rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.w), self.w_layout,
              rt.v(self.bias), temb, self.temb_stride, rt.v(self.res), self.out_div,
-             rt.v(self.y), *self._dims(), rt.ws, rt.ws_bytes, rt.stream)
+             rt.v(self.y), *self._dims(), self._wp(rt, 0), rt.ws, rt.ws_bytes, rt.stream)
 
   def backward(self, rt):
     gy = rt.g(self.y)
@@ -216,10 +239,10 @@ class Conv(Op):
                rt.ws, rt.ws_bytes, *self._dims(), rt.stream)
     g1, g2 = rt.g(self.x1), rt.g(self.x2)
     if g1 is not None or g2 is not None:
-      rt.timed(self._kind(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_f32,
+      rt.timed(self._kind(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_wp_f32,
                gy, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
-               alpha, *self._dims(), rt.ws, rt.ws_bytes, rt.stream)
+               alpha, *self._dims(), self._wp(rt, 1), rt.ws, rt.ws_bytes, rt.stream)
 
   def ws_bytes(self, lib):
     shape = (self.C1, self.C2, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self.stride, self.pad)
@@ -598,4 +621,9 @@ class Graph:
       op.plan_backward()
     self.ws_bytes = max([256] + [op.ws_bytes(lib) for op in self.ops])
     self.ws_bytes = _round_up(self.ws_bytes, 256)
+    # prepared-weight arena: one block per conv layer and direction that runs on the split kernel
+    self.wp_bytes = 0
+    for op in self.ops:
+      if isinstance(op, Conv):
+        self.wp_bytes = op.plan_wp(lib, self.wp_bytes)
     return self

@@ -37,6 +37,11 @@ SIGNATURES = {
   'stk_conv2d_dgrad_ws_bytes': [I, I, I, I, I, I, I, I, I, I],
   'stk_conv2d_fwd_f32': [P, I, P, I, P, I, P, P, I, P, F, P, I, I, I, I, I, I, I, I, I, I, P, L, S],
   'stk_conv2d_dgrad_f32': [P, P, I, P, I, F, P, I, F, F, I, I, I, I, I, I, I, I, I, I, P, L, S],
+  'stk_conv2d_wp_bytes': [I, I, I, I, I, I, I, I, I, I, I],
+  'stk_conv2d_wp_desc': [I, P, I, I, I, I, I, P, P],
+  'stk_conv2d_wprep_batch': [P, I, L, S],
+  'stk_conv2d_fwd_wp_f32': [P, I, P, I, P, I, P, P, I, P, F, P, I, I, I, I, I, I, I, I, I, I, P, P, L, S],
+  'stk_conv2d_dgrad_wp_f32': [P, P, I, P, I, F, P, I, F, F, I, I, I, I, I, I, I, I, I, I, P, P, L, S],
   'stk_conv2d_wgrad_ws_bytes': [I, I, I, I, I, I, I, I],
   'stk_conv2d_wgrad_f32': [P, I, P, I, P, P, I, F, P, L, I, I, I, I, I, I, I, I, I, I, S],
   'stk_bias_grad_f32': [P, I, I, I, F, P, I, P, P, S],
@@ -63,7 +68,8 @@ SIGNATURES = {
   'stk_preprocess_u8': [P, P, I, I, I, I, I, I, I, U64, S],
 }
 _RESTYPE = {'stk_strerror': c_char_p, 'stk_backend': c_char_p, 'stk_conv2d_wgrad_ws_bytes': c_long,
-            'stk_conv2d_fwd_ws_bytes': c_long, 'stk_conv2d_dgrad_ws_bytes': c_long, 'stk_gn_ws_bytes': c_long}
+            'stk_conv2d_fwd_ws_bytes': c_long, 'stk_conv2d_dgrad_ws_bytes': c_long, 'stk_gn_ws_bytes': c_long,
+            'stk_conv2d_wp_bytes': c_long, 'stk_conv2d_wp_desc': c_long}
 _NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant'}
 
 

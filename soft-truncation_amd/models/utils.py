@@ -82,6 +82,15 @@ def create_model(config, sde):
   return DataParallel(score_model)
 
 
+def frozen_weights(model):
+  """Context manager for loops that evaluate `model` many times on fixed parameters (samplers, likelihood ODEs): the
+  engine prepares the convolution weights once instead of once per evaluation.  A no-op for models without an engine."""
+  import contextlib
+  inner = getattr(model, 'module', model)
+  engine = getattr(inner, 'engine', None)
+  return engine().frozen_weights() if callable(engine) else contextlib.nullcontext()
+
+
 def get_model_fn(model, train=False):
   """Callable running the model in train or eval mode, re-asserted on every call (models/utils.py:97-126)."""
 

@@ -319,7 +319,8 @@ def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr
   denoise_update_fn = _denoiser(config, sde, probability_flow=True)
 
   def pc_sampler(model):
-    with torch.no_grad():
+    # the parameters are fixed for the whole loop: convolution weights are prepared once (models.utils.frozen_weights)
+    with torch.no_grad(), mutils.frozen_weights(model):
       x = sde.prior_sampling(shape).to(device)
       grid = torch.linspace(sde.T, eps, sde.N, device=device)
       for i in tqdm(range(sde.N)):
@@ -363,7 +364,7 @@ def get_ode_sampler(config, sde, shape, inverse_scaler, denoise=False, rtol=1e-5
     return torch.tensor(solution.y[:, -1]).reshape(shape), solution.nfev
 
   def ode_sampler(model):
-    with torch.no_grad():
+    with torch.no_grad(), mutils.frozen_weights(model):
       x = sde.prior_sampling(shape).to(device)
       x, nfe = (integrate_on_device if method == 'RK45' else integrate_on_host)(model, x)
       x = x.to(device).type(torch.float32)

@@ -353,6 +353,73 @@ def test_conv(ref_lib, hip_lib, case, scratch):
   compare(both(ref_lib, hip_lib, fn), 1e-4, 'conv')
 
 
+WP_CASES = [c for c in CONV_CASES if c[7] == 1 and c[3] == c[9] and c[4] == c[10]]
+
+
+@pytest.mark.parametrize('case', WP_CASES, ids=_conv_id)
+def test_conv_prepared_weights(hip_lib, case):
+  """include/stk.h "Prepared weights": one batched launch prepares the forward and data-gradient blocks of a layer;
+  the _wp calls must then be BIT-identical to the calls that prepare into their scratch (same kernels, same
+  operands).  Shapes that do not run on the split kernel report 0 bytes and reject a block."""
+  import ctypes
+
+  class Desc(ctypes.Structure):
+    _fields_ = [('w', ctypes.c_void_p), ('wp', ctypes.c_void_p), ('sm', ctypes.c_long), ('sk', ctypes.c_long),
+                ('M', ctypes.c_int), ('Kc', ctypes.c_int), ('Mpad', ctypes.c_int), ('taps', ctypes.c_int),
+                ('flip', ctypes.c_int), ('reserved', ctypes.c_int)]
+
+  N, C1, C2, H, W, Cout, K, stride, pad, OH, OW, layout, use_temb, use_res, use_div = case
+  Cin = C1 + C2
+  d = dev_of(hip_lib)
+  lib = hip_lib
+  x1 = rnd(N, C1, H, W, seed=1).to(d)
+  x2 = rnd(N, C2, H, W, seed=2).to(d) if C2 else None
+  w = ((rnd(Cout, Cin, K, K, seed=3) if layout == 0 else rnd(Cin, Cout, seed=3)) * (1.0 / np.sqrt(Cin * K * K))).to(d)
+  bias, dy = rnd(Cout, seed=4).to(d), rnd(N, Cout, OH, OW, seed=7).to(d)
+  dims = (N, H, W, Cout, OH, OW, K, K, stride, pad)
+  shape = (C1, C2, N, H, W, Cout, K, K, stride, pad)
+  fb = max(int(lib.conv2d_fwd_ws_bytes(*shape)), int(lib.conv2d_dgrad_ws_bytes(*shape)))
+  nb = [int(lib.conv2d_wp_bytes(direction, *shape)) for direction in (0, 1)]
+  assert (nb[0] > 0) == (int(lib.conv2d_variant(0, C1, C2, N, H, W, Cout, OH, OW, K, K, stride, pad, layout)) == 2)
+  assert (nb[1] > 0) == (int(lib.conv2d_variant(1, C1, C2, N, H, W, Cout, OH, OW, K, K, stride, pad, layout)) == 2)
+  fws = torch.full((fb // 4 + 64,), float('nan'), device=d)
+  blocks, descs, items = [], [], 0
+  for direction in (0, 1):
+    if nb[direction] == 0:
+      blocks.append(None)
+      continue
+    blk = torch.full((nb[direction] + 256,), 0xff, dtype=torch.uint8, device=d)
+    ptr = (blk.data_ptr() + 255) // 256 * 256
+    desc = Desc()
+    n = lib.conv2d_wp_desc(direction, w.data_ptr(), layout, Cin, Cout, K, K, ptr, ctypes.byref(desc))
+    assert n > 0
+    items = max(items, n)
+    descs.append(desc)
+    blocks.append((blk, ptr))
+  if descs:
+    table = torch.from_numpy(np.frombuffer(b''.join(bytes(x) for x in descs), dtype=np.uint8).copy()).to(d)
+    call(lib, 'conv2d_wprep_batch', table, len(descs), items)
+  y_a, y_b = torch.empty(N, Cout, OH, OW, device=d), torch.empty(N, Cout, OH, OW, device=d)
+  call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, layout, bias, None, 0, None, 1.0, y_a, *dims, fws, fb)
+  dx_a = [torch.zeros(N, C1, H, W, device=d), torch.zeros(N, C2, H, W, device=d) if C2 else None]
+  dx_b = [torch.zeros(N, C1, H, W, device=d), torch.zeros(N, C2, H, W, device=d) if C2 else None]
+  call(lib, 'conv2d_dgrad_f32', dy, w, layout, dx_a[0], C1, 0.0, dx_a[1], C2, 0.0, 1.0, *dims, fws, fb)
+  if blocks[0] is not None:
+    call(lib, 'conv2d_fwd_wp_f32', x1, C1, x2, C2, w, layout, bias, None, 0, None, 1.0, y_b, *dims, blocks[0][1], fws, fb)
+    assert torch.equal(y_a, y_b)
+  else:          # a block for a shape that has none is an error, not silently ignored ... unless a streaming kernel took it
+    if int(lib.conv2d_variant(0, C1, C2, N, H, W, Cout, OH, OW, K, K, stride, pad, layout)) != 4:
+      rc = lib.conv2d_fwd_wp_f32.raw(x1.data_ptr(), C1, x2.data_ptr() if C2 else None, C2, w.data_ptr(), layout, None, None,
+                                     0, None, 1.0, y_b.data_ptr(), *dims, fws.data_ptr(), fws.data_ptr(), fb, None)
+      assert rc != 0
+  if blocks[1] is not None:
+    call(lib, 'conv2d_dgrad_wp_f32', dy, w, layout, dx_b[0], C1, 0.0, dx_b[1], C2, 0.0, 1.0, *dims, blocks[1][1], fws, fb)
+    assert torch.equal(dx_a[0], dx_b[0])
+    if C2:
+      assert torch.equal(dx_a[1], dx_b[1])
+  torch.cuda.synchronize()
+
+
 def test_conv_adjoint_full_size(hip_lib):
   """Size-independent properties at the BASELINE size (DDPM++ 32x32, batch 128, 128->128 3x3):
   <conv(x), g> == <x, dgrad(g)> == <w, wgrad(x, g)>."""
