@@ -26,8 +26,11 @@ STK_HD unsigned long long stk_mix64(unsigned long long seed, unsigned long long 
   return z;
 }
 
+/* One 64-bit mix serves two consecutive indices (24 bits each): kernels that draw for runs of consecutive elements
+ * pay the three 64-bit multiplies once per pair (the compiler merges the two identical stk_mix64 calls). */
 STK_HD float stk_uniform(unsigned long long seed, unsigned long long i) {
-  return (float)(stk_mix64(seed, i) >> 40) * (1.0f / 16777216.0f);
+  const unsigned long long z = stk_mix64(seed, i >> 1);
+  return (float)((i & 1ULL) ? (z >> 8) & 0xFFFFFFULL : z >> 40) * (1.0f / 16777216.0f);
 }
 
 #endif /* STK_RNG_H */

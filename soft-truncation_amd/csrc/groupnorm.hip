@@ -56,9 +56,75 @@ __device__ __forceinline__ void group_segments(const GnArgs& a, int n, int g, Se
   }
 }
 
+// u * sigmoid(u) with the accurate expf and the IEEE division.  The hardware forms were tried and rejected: __expf
+// (argument scaling costs |u| * 2^-24) moved the likelihood ODE's latent to 3e-4 from the reference's fixture, and
+// even the 1-ulp v_rcp_f32 raised the noise floor of the adaptive solver enough for 10 % more function evaluations.
+// Dropout indices of a float4 are written as (multiple of 4) + j with the multiple made visible to the compiler
+// (`& ~3`, a no-op on these values), so the two stk_uniform calls of a pair share one 64-bit mix (stk_rng.h).
 __device__ __forceinline__ float silu_f(float u) { return u / (1.f + expf(-u)); }
 
 // ---- forward ------------------------------------------------------------------------------------
+// Register-resident forward for groups of up to 16384 elements (every group of the 32x32 / 64x64 networks): a thread
+// keeps its <= 4 float4 of the group, so the group is read ONCE (the looping kernel below reads it for the statistics
+// and again for the normalisation; measured 1.6x the tensor at the memory side).  Same arithmetic as gn_fwd_kernel.
+template <int IPT>
+__global__ __launch_bounds__(1024) void gn_fwd_flat_kernel(GnArgs a, float* __restrict__ y, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out, float eps) {
+  __shared__ float red[32];
+  const int ng = blockIdx.x;
+  const int n = ng / a.G, g = ng - n * a.G;
+  Seg seg[2];
+  group_segments(a, n, g, seg);
+  const int L = a.cpg * a.HW, L4 = L >> 2, n0 = seg[0].len >> 2;
+  const float shift = seg[0].len ? seg[0].p[0] : seg[1].p[0];
+  const float4* p0 = reinterpret_cast<const float4*>(seg[0].p);
+  const float4* p1 = reinterpret_cast<const float4*>(seg[1].p);
+  float4 v[IPT];
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const int idx = threadIdx.x + k * blockDim.x;
+    v[k] = make_float4(shift, shift, shift, shift);
+    if (idx < L4) v[k] = idx < n0 ? p0[idx] : p1[idx - n0];
+    const float d0 = v[k].x - shift, d1 = v[k].y - shift, d2 = v[k].z - shift, d3 = v[k].w - shift;
+    s[0] += (d0 + d1) + (d2 + d3);
+    s[1] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  block_sum<2>(s, red);
+  const float inv_l = 1.f / (float)L;
+  const float md = s[0] * inv_l;                       // mean - shift
+  const float var = fmaxf(s[1] * inv_l - md * md, 0.f);
+  const float mean = shift + md;
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_out[ng] = mean;
+    rstd_out[ng] = rstd;
+  }
+  unsigned long long seed = a.seed;
+  if (a.drop_p > 0.f && a.seed_dev) seed += *a.seed_dev;
+  const int C = a.C1 + a.C2;
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    const int idx = threadIdx.x + k * blockDim.x;
+    if (idx >= L4) continue;
+    const int q = idx < n0 ? 0 : 1, i = idx < n0 ? idx : idx - n0;
+    const int c_first = q ? seg[1].c_first : seg[0].c_first;
+    float4* o4 = reinterpret_cast<float4*>(y + ((long)n * C + c_first) * a.HW);
+    const unsigned long long flat0 = ((unsigned long long)n * C + c_first) * a.HW;
+    const int c = c_first + (i * 4) / a.HW;
+    const float ga = a.gamma[c], be = a.beta[c];
+    float r[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float u = ga * ((r[j] - mean) * rstd) + be;
+      float t = a.act ? silu_f(u) : u;
+      if (a.drop_p > 0.f) t = (stk_uniform(seed, ((flat0 + (unsigned long long)(i * 4)) & ~3ULL) + j) >= a.drop_p) ? t * a.keep_scale : 0.f;
+      r[j] = t;
+    }
+    o4[i] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
 // VEC: 4 when HW % 4 == 0 and all pointers are 16-B aligned, else 1.
 template <int VEC>
 __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs a, float* __restrict__ y, float* __restrict__ mean_out,
@@ -125,7 +191,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs a, float* __restrict
         for (int j = 0; j < 4; ++j) {
           float u = ga * ((r[j] - mean) * rstd) + be;
           float t = a.act ? silu_f(u) : u;
-          if (a.drop_p > 0.f) t = (stk_uniform(seed, flat0 + (unsigned long long)(i * 4 + j)) >= a.drop_p) ? t * a.keep_scale : 0.f;
+          if (a.drop_p > 0.f) t = (stk_uniform(seed, ((flat0 + (unsigned long long)(i * 4)) & ~3ULL) + j) >= a.drop_p) ? t * a.keep_scale : 0.f;
           r[j] = t;
         }
         o4[i] = make_float4(r[0], r[1], r[2], r[3]);
@@ -264,7 +330,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
     float cs0 = 0.f, cs1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float d = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, flat + j, xh[k][j]);
+      const float d = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, (flat & ~3ULL) + j, xh[k][j]);
       du[k][j] = valid ? d : 0.f;
       cs0 += du[k][j];
       cs1 += du[k][j] * xh[k][j];
@@ -384,7 +450,7 @@ __global__ __launch_bounds__(256) void gn_split_fwd_kernel(GnArgs a, const float
     for (int j = 0; j < 4; ++j) {
       const float u = ga * ((r[j] - mean) * rstd) + be;
       float t = a.act ? silu_f(u) : u;
-      if (a.drop_p > 0.f) t = (stk_uniform(seed, flat0 + (unsigned long long)(e * 4 + j)) >= a.drop_p) ? t * a.keep_scale : 0.f;
+      if (a.drop_p > 0.f) t = (stk_uniform(seed, ((flat0 + (unsigned long long)(e * 4)) & ~3ULL) + j) >= a.drop_p) ? t * a.keep_scale : 0.f;
       r[j] = t;
     }
     o4[e] = make_float4(r[0], r[1], r[2], r[3]);
@@ -416,7 +482,7 @@ __global__ __launch_bounds__(256) void gn_split_bwd_part_kernel(GnArgs a, const 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float xh;
-      const float du = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, flat0 + (unsigned long long)(e * 4 + j), xh);
+      const float du = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, ((flat0 + (unsigned long long)(e * 4)) & ~3ULL) + j, xh);
       s[0] += du;
       s[1] += du * xh;
     }
@@ -473,7 +539,7 @@ __global__ __launch_bounds__(256) void gn_split_bwd_kernel(GnArgs a, const float
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float xh;
-      const float du = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, flat0 + (unsigned long long)(e * 4 + j), xh);
+      const float du = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, ((flat0 + (unsigned long long)(e * 4)) & ~3ULL) + j, xh);
       r[j] = rstd * (du * ga - m1 - xh * m2);
     }
     if (ob != 0.f) {
@@ -538,7 +604,20 @@ int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float
     STK_CHECK_LAUNCH();
     return STK_OK;
   }
-  if (vec)
+  const long L = (long)a.cpg * HW;
+  if (vec && L <= 16384) {
+    const int L4 = (int)(L >> 2);
+    int T = 64;
+    while (T < 1024 && T * 4 < L4) T <<= 1;
+    const int ipt = stk_cdiv(L4, T);
+#define STK_GN_FWD_FLAT(IPT)                                                                                     \
+  hipLaunchKernelGGL((gn_fwd_flat_kernel<IPT>), dim3(N * G), dim3(T), 0, (hipStream_t)stream, a, y, mean, rstd, eps)
+    if (ipt <= 1) STK_GN_FWD_FLAT(1);
+    else if (ipt <= 2) STK_GN_FWD_FLAT(2);
+    else if (ipt <= 3) STK_GN_FWD_FLAT(3);
+    else STK_GN_FWD_FLAT(4);
+#undef STK_GN_FWD_FLAT
+  } else if (vec)
     hipLaunchKernelGGL((gn_fwd_kernel<4>), dim3(N * G), dim3(256), 0, (hipStream_t)stream, a, y, mean, rstd, eps);
   else
     hipLaunchKernelGGL((gn_fwd_kernel<1>), dim3(N * G), dim3(256), 0, (hipStream_t)stream, a, y, mean, rstd, eps);

@@ -259,7 +259,7 @@ def golden_likelihood(st, model, cfg, family, tol, nfe_exact=True):
     # error estimate lands next to the acceptance threshold; the two solutions then agree to the solver tolerance
     # (rtol = atol = 1e-5, the reference's defaults), not to the arithmetic tolerance.
     assert not nfe_exact, (nfe, int(g['nll.nfe']))
-    assert abs(nfe - int(g['nll.nfe'])) <= 0.1 * int(g['nll.nfe'])
+    assert abs(nfe - int(g['nll.nfe'])) <= 0.1 * int(g['nll.nfe']), (nfe, int(g['nll.nfe']))
     b, zz = bpd.detach().cpu().double().numpy(), z.detach().cpu().double().numpy()
     assert np.abs(b - g['nll.bpd']).max() <= 1e-3 * np.abs(g['nll.bpd']).max(), ('nll bpd', b, g['nll.bpd'])
     assert np.abs(zz - g['nll.z']).max() <= 1e-2 * np.abs(g['nll.z']).max(), 'nll latent'
