@@ -450,6 +450,42 @@ def test_conv_adjoint_full_size(hip_lib):
   assert abs(a - b) <= tol and abs(a - c) <= tol, (a, b, c, tol)
 
 
+THIN_FULL = [
+  # N, Cin, Cout, H, K  -- the thin-side layers at the BASELINE sizes
+  (128, 3, 128, 32, 3),      # DDPM++ CIFAR-10 stem
+  (128, 128, 3, 32, 3),      # ... and head
+  (4, 3, 128, 256, 1),       # NCSN++ 256x256 input_skip Combine (3 -> C, 1x1)
+  (4, 128, 3, 256, 3),       # ... output_skip conv (C -> 3)
+  (4, 256, 3, 32, 3),        # output_skip at a deeper level (two weight blocks of 128 channels)
+]
+
+
+@pytest.mark.parametrize('case', THIN_FULL, ids=str)
+def test_thin_conv_adjoint_full_size(hip_lib, case):
+  """<conv(x), g> == <x, dgrad(g)> == <w, wgrad(x, g)> for the streaming kernels (conv_thin.h) at full size."""
+  d = dev_of(hip_lib)
+  N, Cin, Cout, H, K = case
+  pad = K // 2
+  x = rnd(N, Cin, H, H, seed=1).to(d)
+  w = (rnd(Cout, Cin, K, K, seed=2) / float(np.sqrt(Cin * K * K))).to(d)
+  g = rnd(N, Cout, H, H, seed=3).to(d)
+  dims = (N, H, H, Cout, H, H, K, K, 1, pad)
+  assert int(hip_lib.conv2d_variant(0, Cin, 0, N, H, H, Cout, H, H, K, K, 1, pad, 0)) == 4
+  assert int(hip_lib.conv2d_variant(2, Cin, 0, N, H, H, Cout, H, H, K, K, 1, pad, 0)) == 4
+  y = torch.full((N, Cout, H, H), float('nan'), device=d)
+  call(hip_lib, 'conv2d_fwd_f32', x, Cin, None, 0, w, 0, None, None, 0, None, 1.0, y, *dims, None, 0)
+  dx = torch.full((N, Cin, H, H), float('nan'), device=d)
+  call(hip_lib, 'conv2d_dgrad_f32', g, w, 0, dx, Cin, 0.0, None, 0, 0.0, 1.0, *dims, None, 0)
+  ws = torch.full((int(hip_lib.conv2d_wgrad_ws_bytes(Cin, 0, N, Cout, H, H, K, K)) // 4 + 64,), float('nan'), device=d)
+  dw = torch.zeros_like(w)
+  call(hip_lib, 'conv2d_wgrad_f32', x, Cin, None, 0, g, dw, 0, 1.0, ws, ws.numel() * 4, *dims)
+  a = (y.double() * g.double()).sum().item()
+  b = (x.double() * dx.double()).sum().item()
+  c = (w.double() * dw.double()).sum().item()
+  tol = 1e-8 * (y.double().abs() * g.double().abs()).sum().item()      # see test_conv_adjoint_full_size
+  assert abs(a - b) <= tol and abs(a - c) <= tol, (a, b, c, tol)
+
+
 # ---------------------------------------------------------------------------------------------------
 # batched strided GEMM, softmax
 # ---------------------------------------------------------------------------------------------------
