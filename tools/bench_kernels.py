@@ -61,6 +61,9 @@ def main():
     (128, 0, 16, 256, 3), (384, 0, 32, 128, 3), (512, 0, 16, 256, 3), (512, 0, 8, 256, 3),
     (256, 256, 16, 256, 1), (256, 0, 16, 256, 1), (128, 0, 16, 256, 1),
   ]
+  if 'hq' in args.only:        # the 256x256 network's layers (use with --batch 4)
+    conv_shapes = [(128, 0, 256, 128, 3), (128, 0, 128, 128, 3), (128, 0, 64, 256, 3), (256, 0, 64, 256, 3),
+                   (256, 0, 32, 256, 3), (256, 128, 256, 128, 3), (256, 0, 256, 128, 1)]
   if not args.only or 'conv' in args.only:
     for C1, C2, H, Cout, K in conv_shapes:
       if 'k1' in args.only and K != 1:
