@@ -86,6 +86,8 @@ class Program:
   def build_wp(self, lib, param_base):
     g = self.graph
     self.wp = torch.empty(max(g.wp_bytes, 256), dtype=torch.uint8, device=self.device)
+    if _POISON:
+      self.wp.fill_(0xff)          # bf16 0xffff = NaN: a block that is used without having been prepared shows up
     base = self.wp.data_ptr()
     assert base % 256 == 0
     descs, items = [], 0
@@ -125,7 +127,8 @@ class _NetFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, ex, training, anchor, x, emb_in, sigma):
     need_xgrad = bool(ctx.needs_input_grad[3])
-    out, c = ex.run_forward(x, emb_in, sigma, training, need_xgrad)
+    # grad mode is OFF inside autograd.Function.forward: say explicitly that a backward will follow
+    out, c = ex.run_forward(x, emb_in, sigma, training, need_xgrad, with_backward=True)
     ctx.ex, ctx.c, ctx.need_xgrad = ex, c, need_xgrad
     return out
 
@@ -236,7 +239,7 @@ class Executor:
                  flat.data.data_ptr(), flat.grad.data_ptr(), prog.const.data_ptr(),
                  prog.ws.data_ptr(), prog.graph.ws_bytes, training, seed, seed_dev)
     rt.prof = self.profiler
-    if prog.wp is not None and prog.wp_table is not None:
+    if self.use_wp and prog.wp is not None and prog.wp_table is not None:
       rt.wp = prog.wp.data_ptr()
     return rt
 
@@ -268,7 +271,7 @@ class Executor:
     self.graph_replays += 1
     return True
 
-  def run_forward(self, x, emb_in, sigma, training, need_xgrad):
+  def run_forward(self, x, emb_in, sigma, training, need_xgrad, with_backward=False):
     flat = self.ensure_flat()
     B, _, H, W = x.shape
     prog = self.program(B, H, W, need_xgrad)
@@ -278,7 +281,7 @@ class Executor:
     self._copy_in(c, 'emb', emb_in)
     if sigma is not None:
       self._copy_in(c, 'sigma', sigma)
-    self._prepare_weights(prog, torch.is_grad_enabled())
+    self._prepare_weights(prog, with_backward)
     seed = 0
     if training and self.model._uses_dropout():
       seed = int(torch.randint(0, 2 ** 62, (1,)).item())

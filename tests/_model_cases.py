@@ -28,10 +28,10 @@ def _inputs(cfg, sde, B, seed=1):
   return x, t, cond
 
 
-def forward_backward(st, lib, family):
+def forward_backward(st, lib, family, B=3):
   cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, family), lib)
   dev = cfg.device
-  x, t, cond = _inputs(cfg, sde, 3)
+  x, t, cond = _inputs(cfg, sde, B)
   model.eval(); ref.eval()
   xg = x.clone().to(dev).requires_grad_(True)
   y = model(xg, cond.to(dev))
@@ -58,7 +58,7 @@ def score_fn_parity(st, lib, family):
   assert rel_err(s, sr) <= TOL
 
 
-def train_steps(st, lib, family, steps=3, num_micro_batch=1, mixed=False):
+def train_steps(st, lib, family, steps=3, num_micro_batch=1, mixed=False, B=4):
   base = tiny_config(st, family)
   base.optim.num_micro_batch = num_micro_batch
   base.optim.warmup = 2
@@ -73,7 +73,6 @@ def train_steps(st, lib, family, steps=3, num_micro_batch=1, mixed=False):
   assert type(rstate['optimizer']).__name__ == 'Adam'
   step_fn = st.losses.get_step_fn(cfg, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg))
   rstep_fn = st.losses.get_step_fn(cfg_cpu, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg_cpu))
-  B = 4
   for i in range(steps):
     batch = st.datasets.synthetic_batch(cfg_cpu, B, generator=torch.Generator().manual_seed(100 + i))
     np.random.seed(7 + i)
@@ -282,3 +281,60 @@ def golden_likelihood_product(st, lib, family):
   # fp32 kernels vs the reference's CPU arithmetic: the adaptive solver may take a different number of steps only if
   # an error estimate lands within rounding of the acceptance threshold; the fixture's tolerance keeps it identical
   golden_likelihood(st, model, cfg, family, tol=TOL, nfe_exact=False)
+
+
+def prepared_weights_coherence(st, lib):
+  """Engine-level contract of the prepared convolution weights (engine/executor.py): a forward always sees the current
+  parameters -- after an in-place update (optimizer step, EMA swap) the batched preparation runs again -- and the
+  results are bit-identical to per-call preparation (STK_WP=0), forward and backward.  Uses a net wide enough
+  (96 channels) for the split kernels; the tiny parity configs never reach them."""
+  base = st.configs.cifar10_ddpmpp_nll_st()
+  cfg = st.configs.tiny(base, nf=96, ch_mult=(1,), num_res_blocks=1, image_size=16, attn_resolutions=(), dropout=0.0)
+  dev = torch.device('cuda:0')
+  cfg.device = dev
+  torch.manual_seed(3)
+  net = st.models.ncsnpp.NCSNpp(cfg, None)
+  net.set_backend(lib)
+  net = net.to(dev).eval()
+  ex = net.engine()
+  g = torch.Generator().manual_seed(7)
+  x = torch.randn(12, 3, 16, 16, generator=g).to(dev)
+  cond = (torch.rand(12, generator=g) * 999).to(dev)
+
+  def fwd():
+    with torch.no_grad():
+      return net(x, cond)
+
+  def fwd_bwd():
+    xi = x.clone().requires_grad_(True)
+    net.zero_grad()
+    (net(xi, cond) ** 2).sum().backward()
+    return xi.grad.clone(), torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.grad is not None])
+
+  assert ex.use_wp
+  y1 = fwd()
+  progs = list(ex.programs.values())
+  assert progs and progs[0].wp_counts[0] > 0, 'no layer of this net took the prepared-weight path'
+  for p in net.parameters():
+    p.data.mul_(1.25)
+  y2 = fwd()
+  gx2, gw2 = fwd_bwd()
+  assert progs[0].wp_counts[1] > progs[0].wp_counts[0] or any(pr.wp_counts[1] > pr.wp_counts[0] for pr in ex.programs.values())
+  ex.use_wp = False                    # per-call preparation of the same (updated) weights
+  y3 = fwd()
+  gx3, gw3 = fwd_bwd()
+  ex.use_wp = True
+  assert not torch.equal(y1, y2)
+  assert torch.equal(y2, y3), 'a forward after an in-place parameter update used stale prepared weights'
+  assert torch.equal(gx2, gx3), float((gx2 - gx3).abs().max())
+  assert torch.equal(gw2, gw3), (float((gw2 - gw3).abs().max()), float(gw2.abs().max()), float((gw3 / gw2).nanmedian()))
+  with ex.frozen_weights():            # promise kept: same values, one preparation
+    ya, yb = fwd(), fwd()
+  assert torch.equal(ya, y2) and torch.equal(yb, y2)
+  for p in net.parameters():
+    p.data.mul_(0.8)
+  y4 = fwd()                           # outside the block the next forward prepares again
+  ex.use_wp = False
+  y5 = fwd()
+  ex.use_wp = True
+  assert torch.equal(y4, y5) and not torch.equal(y4, y2)

@@ -59,6 +59,23 @@ def test_golden_likelihood(st, hip_lib, family):
   cases.golden_likelihood_product(st, hip_lib, family)
 
 
+def test_forward_backward_wide(st, hip_lib):
+  """96 / 192 channels, batch 96: the bf16-split kernels (direct, K-split, few-tile), the 1x1 split layers and the
+  prepared-weight path inside the engine, against the oracle RefNet."""
+  cases.forward_backward(st, hip_lib, 'wide', B=96)
+  ex_variants = {int(hip_lib.conv2d_variant(d, 96, 0, 96, 16, 16, 96, 16, 16, 3, 3, 1, 1, 0)) for d in (0, 1, 2)}
+  assert ex_variants == {2}                      # this shape does run on the split kernels
+
+
+def test_train_steps_wide(st, hip_lib):
+  """Optimizer updates between forwards: the prepared weights must follow them (parameters vs the oracle after 3 steps)."""
+  cases.train_steps(st, hip_lib, 'wide', steps=3, B=24)
+
+
+def test_prepared_weights_follow_parameter_updates(st, hip_lib):
+  cases.prepared_weights_coherence(st, hip_lib)
+
+
 def test_train_steps_with_rccl_process_group(st, hip_lib, monkeypatch):
   """The multi-GPU code path on the one GPU a test box has: an RCCL ("nccl") process group of one rank, the
   gradient exchange forced on (bucketed async all-reduce of the flat gradient buffer + averaging by world size 1),
