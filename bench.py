@@ -34,16 +34,18 @@ import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)": the f32-input MFMA kernels (t64 / t128)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md dense bf16 MFMA peak
-# The x3 kernels issue six bf16 MFMAs per fp32 product (three-way operand split, include/stk.h), so the fp32-equivalent
-# ceiling of the matrix pipe for them is the bf16 peak / 6.
+# The x3 kernels (weight gradient) issue six bf16 MFMAs per fp32 product (three-way operand split), the x2 kernels
+# (forward, data gradient) three fp16 MFMAs (two-way split of power-of-two-scaled operands; fp16 and bf16 MFMAs run at
+# the same rate): the fp32-equivalent ceiling of the matrix pipe is the 16-bit peak / 6 resp. / 3.
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 
 
 # rocprofv3 symbol of the kernel behind a profiler label (for the committed PMC summary, see traffic_of)
 KERNEL_SYMBOL = {
   'conv3x3.wgrad.x3': 'wgrad3_kernel<false>',
-  'conv3x3.fwd.x3': 'gemm_kernel<WpLoader, ActLoader<false, 9>, EpFwd, true>',
-  'conv3x3.dgrad.x3': 'gemm_kernel<WpLoader, ActLoader<false, 9>, EpDgrad, true>',
+  'conv3x3.fwd.x2': 'x2::gemm_kernel<x2::ActLoader<false, 9>, EpFwd>',
+  'conv3x3.dgrad.x2': 'x2::gemm_kernel<x2::ActLoader<false, 9>, EpDgrad>',
 }
 
 
@@ -64,6 +66,8 @@ def traffic_of(kind):
 
 
 def kernel_peak(kind):
+  if kind.endswith('.x2'):
+    return PEAK_X2_TFLOPS
   return PEAK_X3_TFLOPS if kind.endswith('.x3') else PEAK_F32_MFMA_TFLOPS
 TRAIN_FLOPS_PER_IMG = {'cifar10_ddpmpp_nll_st': 65.072e9, 'imagenet32_ddpmpp_st': 65.072e9,
                        'celeba_uncsnpp_st': 252.128e9, 'celebahq_uncsnpp_st': 1598.169e9}
@@ -167,13 +171,13 @@ def arithmetic_check(device):
   ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=device)
   stream = torch.cuda.current_stream(device).cuda_stream
   out = {}
-  for name, wsp, wsb in (('x3_bf16_split', ws.data_ptr(), nbytes), ('f32_input_mfma', None, 0)):
+  for name, wsp, wsb in (('fp16_two_way_split', ws.data_ptr(), nbytes), ('f32_input_mfma', None, 0)):
     y = torch.empty(N, C, H, H, dtype=torch.float32, device=device)
     lib.conv2d_fwd_f32(x.data_ptr(), C, None, 0, w.data_ptr(), 0, None, None, 0, None, 1.0, y.data_ptr(), N, H, H, C, H, H,
                        3, 3, 1, 1, wsp, wsb, stream)
     torch.cuda.synchronize()
     out[name + '_max_err_over_max_abs'] = float((y.double() - ref).abs().max() / ref.abs().max())
-  out['x3_path_selected'] = nbytes > 0
+  out['split_path_selected'] = nbytes > 0
   return out
 
 
@@ -254,10 +258,11 @@ def main():
       'value': ips, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-      'arithmetic': 'fp32 tensors and fp32 accumulation everywhere; the large 3x3 convolutions evaluate each fp32 '
-                    'product exactly-split into bf16 terms on the bf16 matrix pipe (6 MFMAs, error at fp32 rounding '
-                    'level, parity-tested against the double-precision oracle at the same tolerance as the '
-                    'f32-input MFMA path)',
+      'arithmetic': 'fp32 tensors and fp32 accumulation everywhere; the large convolutions evaluate each fp32 product '
+                    'from split operands on the 16-bit matrix pipe -- forward / data gradient: power-of-two-scaled '
+                    'operands as two fp16 terms, 3 MFMAs; weight gradient: three bf16 terms, 6 MFMAs -- with errors at '
+                    'the fp32 rounding level (arithmetic_check; parity-tested against the double-precision oracle at '
+                    'the same tolerance as the f32-input MFMA path)',
       'config': {'workload': desc, 'per_gpu_batch': per_gpu_batch, 'global_batch': global_batch,
                  'parallelism': f'dp{world}', 'loss_mean': float(losses_.mean()),
                  'hipgraph_replays': score_model.module.engine().graph_replays},
@@ -276,6 +281,7 @@ def main():
                            'frac': a['tflops'] / kernel_peak(dom), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                            'traffic_source': traffic_src, 'kernel': dom,
                            'peak_note': ('bf16 MFMA dense peak / 6 products per fp32 product' if dom.endswith('.x3')
+                                         else 'fp16 MFMA dense peak / 3 products per fp32 product' if dom.endswith('.x2')
                                          else 'f32-input MFMA peak'),
                            'avg_us': a['avg_us'], 'launches': a['count'], 'flops_per_launch': a['flops_per_launch'],
                            'share_of_step': (a['total_ms'] / max(args.prof_steps, 1)) / (1e3 * elapsed / args.steps),

@@ -101,16 +101,19 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
  *   wgrad: dw += alpha * sum_{n,oy,ox} dy * x        (same layout as w)
  *          ws: scratch of stk_conv2d_wgrad_ws_bytes(...) bytes for the split-K partial slabs.
  * fwd / dgrad scratch: with ws of at least stk_conv2d_{fwd,dgrad}_ws_bytes(...) bytes (0 = the shape does not
- * qualify) a 3x3 / stride-1 / pad-1 layer runs on the bf16 matrix pipe with every fp32 operand split exactly
- * into three bf16 terms and the six significant partial products accumulated in fp32 (error at the level of
- * fp32 rounding, same as the f32-input MFMA path); ws holds the re-laid-out, split weights of this call.
+ * qualify) a 3x3 / stride-1 / pad-1 or 1x1 layer runs on the fp16 matrix pipe: each operand tensor is scaled by a
+ * power of two (from its |x| maximum, computed inside the call) and every fp32 value split into two fp16 terms;
+ * the three significant partial products are accumulated in fp32 and the scales undone exactly (error at the level
+ * of fp32 rounding, same as the f32-input MFMA path).  ws holds the prepared weights of this call, the partial
+ * maxima and the K-split slabs.  The weight gradient uses a bf16 three-way split of both operands instead.
  * ws = NULL / too small selects the f32-input MFMA path (v_mfma_f32_32x32x2_f32) for every shape.
  * ------------------------------------------------------------------------------------------ */
 long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW,
                              int stride, int pad);
 /* Which kernel family a call with full scratch takes (for profiling labels): dir 0 fwd, 1 dgrad, 2 wgrad;
  * returns 0 / 1 = f32-input MFMA with 64 / 128 tiles, 2 = bf16 three-way split, 3 = f32-input all-taps wgrad,
- * 4 = streaming kernel for a <= 4 channel side (stem, head, 3-channel pyramids), < 0 = unsupported shape. */
+ * 4 = streaming kernel for a <= 4 channel side (stem, head, 3-channel pyramids), 5 = fp16 two-way split,
+ * < 0 = unsupported shape. */
 int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, int OH, int OW,
                        int KH, int KW, int stride, int pad, int w_layout);
 long stk_conv2d_dgrad_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW,

@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256) void slab_dgrad_kernel(ConvP p, int splits, in
 
 #include "conv_x3.h"
 #include "conv_thin.h"
+#include "conv_x2.h"
 
 // dw (in the weight's own layout) += alpha * sum over splits of slab[tap][co][ci]
 // Threads walk the SLAB order four elements at a time, so the `splits` reads per element are 16-byte and coalesced
@@ -833,9 +834,14 @@ inline X3Plan x3_plan(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
   return r;
 }
 inline long x3_ws_bytes(const X3Plan& r, int M, int Kc, int taps) {
-  return r.ok ? x3::wp_bytes(M, Kc, taps) + 512 + (r.splits > 1 ? r.splits * r.slab * 4 : 0) : 0;
+  // [prepared weights of this call][|x| partial maxima, 2 x 256 floats][K-split slabs], each 256-byte aligned
+  return r.ok ? x3::wp_bytes(M, Kc, taps) + 2048 + 1024 + (r.splits > 1 ? r.splits * r.slab * 4 : 0) : 0;
 }
 // dgrad = 1: rows are input channels, k output channels, taps flipped
+// Forward / data gradient on the split kernels: true = fp16 two-way split (conv_x2.h, 3 MFMAs per fp32 product),
+// false = bf16 three-way split (conv_x3.h, 6).  The weight gradient stays on the bf16 kernels of conv_x3.h.
+constexpr bool SPLIT_FWD_DGRAD_X2 = true;
+
 inline void x3_weight_strides(const ConvP& p, int dgrad, long& sm, long& sk) {
   if (p.w_layout == 0) { sm = dgrad ? p.taps : (long)p.Cin * p.taps; sk = dgrad ? (long)p.Cin * p.taps : p.taps; }
   else { sm = dgrad ? p.Cout : 1; sk = dgrad ? 1 : p.Cout; }          // NIN w[Cin][Cout]
@@ -847,8 +853,52 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
   x3::Src q;
   q.s1 = s1; q.s2 = S2 > 0 ? s2 : s1; q.S1 = S1; q.S2 = S2; q.Kc = S1 + S2; q.Mpad = x3::pad128(M); q.taps = p.taps;
   unsigned short* wp = reinterpret_cast<unsigned short*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  p.part = reinterpret_cast<float*>(((uintptr_t)wp + x3::wp_bytes(M, q.Kc, p.taps) + 255) & ~(uintptr_t)255);
+  float* xpart = reinterpret_cast<float*>(((uintptr_t)wp + x3::wp_bytes(M, q.Kc, p.taps) + 255) & ~(uintptr_t)255);
+  p.part = reinterpret_cast<float*>(((uintptr_t)(xpart + 2 * x2::NPART) + 255) & ~(uintptr_t)255);
   p.part_stride = r.slab;
+  if (SPLIT_FWD_DGRAD_X2) {
+    // fp16 two-way split (conv_x2.h): |x| maxima of the activation operand(s), weights prepared here unless the caller did
+    hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(256), 0, s, s1, (long)p.N * S1 * p.HW, xpart);
+    if (S2 > 0)
+      hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(256), 0, s, s2, (long)p.N * S2 * p.HW,
+                         xpart + x2::NPART);
+    STK_CHECK_LAUNCH();
+    const int nx = S2 > 0 ? 2 * x2::NPART : x2::NPART;
+    if (wp_ready) {
+      q.wp = static_cast<const unsigned short*>(wp_ready);
+    } else {
+      x2::WprepDesc one = {};
+      one.w = p.w; one.wp = reinterpret_cast<unsigned char*>(wp); one.M = M; one.Kc = q.Kc; one.Mpad = q.Mpad;
+      one.taps = p.taps; one.flip = dgrad;
+      x3_weight_strides(p, dgrad, one.sm, one.sk);
+      hipLaunchKernelGGL(x2::wamax_kernel, dim3(1), dim3(256), 0, s, nullptr, one);
+      hipLaunchKernelGGL(x2::wprep_kernel, dim3((unsigned)stk_cdiv((long)q.Mpad * q.Kc, 256L)), dim3(256), 0, s, nullptr, one);
+      STK_CHECK_LAUNCH();
+      q.wp = wp;
+    }
+    const int tm = q.Mpad / 128, tn = stk_cdiv((int)Ng, 128), nch = p.taps * (q.Kc / x3::KC);
+    const dim3 grid((unsigned)(tm * tn * r.splits));
+#define STK_X2_LAUNCH(E, DUAL, TAPS)                                                                              \
+  hipLaunchKernelGGL((x2::gemm_kernel<x2::ActLoader<DUAL, TAPS>, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, \
+                     nch, r.chunks_per_split, xpart, nx)
+#define STK_X2_LAUNCH_E(E)                                                                                        \
+  if (p.taps == 9) { if (S2 > 0) STK_X2_LAUNCH(E, true, 9); else STK_X2_LAUNCH(E, false, 9); }                    \
+  else { if (S2 > 0) STK_X2_LAUNCH(E, true, 1); else STK_X2_LAUNCH(E, false, 1); }
+    if (r.splits == 1) {
+      STK_X2_LAUNCH_E(EP)
+      STK_CHECK_LAUNCH();
+      return STK_OK;
+    }
+    STK_X2_LAUNCH_E(EpSlab)
+    STK_CHECK_LAUNCH();
+    const dim3 rgrid((unsigned)stk_ew_grid((long)M * Ng));
+    if (dgrad) hipLaunchKernelGGL(slab_dgrad_kernel, rgrid, dim3(256), 0, s, p, r.splits, M, (int)Ng);
+    else hipLaunchKernelGGL(slab_fwd_kernel, rgrid, dim3(256), 0, s, p, r.splits, M, (int)Ng);
+#undef STK_X2_LAUNCH_E
+#undef STK_X2_LAUNCH
+    STK_CHECK_LAUNCH();
+    return STK_OK;
+  }
   if (wp_ready) {
     q.wp = static_cast<const unsigned short*>(wp_ready);
   } else {
@@ -1089,7 +1139,7 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
 }
 
 /* which kernel family a call with full scratch takes: 0/1 = f32-input MFMA with 64/128 tiles, 2 = bf16 three-way
- * split, 3 = f32-input all-taps weight gradient, 4 = thin-side streaming kernels.  dir: 0 fwd, 1 dgrad, 2 wgrad. */
+ * split, 3 = f32-input all-taps weight gradient, 4 = thin-side streaming kernels, 5 = fp16 two-way split.  dir: 0 fwd, 1 dgrad, 2 wgrad. */
 int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW,
                        int stride, int pad, int w_layout) {
   ConvP p = {};
@@ -1099,13 +1149,13 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
   if (dir == 0) {
     const long Ng = (long)N * p.OHW;
     if (thin::geometry_ok(p) && ((C2 == 0 && Cin <= 4) || Cout <= 4)) return 4;
-    if (x3_plan(p, Cin, C1, C2, Cout, Ng).ok) return 2;
+    if (x3_plan(p, Cin, C1, C2, Cout, Ng).ok) return SPLIT_FWD_DGRAD_X2 ? 5 : 2;
     return use_big_tile(Cout, Ng, 1) && !(p.taps == 1 && w_layout == 0 && (Cin % 8)) ? 1 : 0;
   }
   if (dir == 1) {
     const long Ng = (long)N * p.HW;
     if (thin::geometry_ok(p) && Cout <= 4) return 4;
-    if (x3_plan(p, Cout, Cout, 0, Cin, Ng).ok) return 2;
+    if (x3_plan(p, Cout, Cout, 0, Cin, Ng).ok) return SPLIT_FWD_DGRAD_X2 ? 5 : 2;
     return use_big_tile(Cin, Ng, 1) && !(p.taps == 1 && w_layout == 1 && (Cout % 8)) ? 1 : 0;
   }
   if (thin::geometry_ok(p) && ((C2 == 0 && Cin <= 4) || Cout <= 4)) return 4;
@@ -1120,7 +1170,8 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
  * dir: 0 forward, 1 data gradient.  Bytes are 0 for shapes whose call does not take the split kernel. */
 long stk_conv2d_wp_bytes(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   if (dir != 0 && dir != 1) return 0;
-  if (stk_conv2d_variant(dir, C1, C2, N, H, W, Cout, H, W, KH, KW, stride, pad, 0) != 2) return 0;
+  const int v = stk_conv2d_variant(dir, C1, C2, N, H, W, Cout, H, W, KH, KW, stride, pad, 0);
+  if (v != 2 && v != 5) return 0;
   const int Cin = C1 + C2;
   return (dir == 0 ? x3::wp_bytes(Cout, Cin, KH * KW) : x3::wp_bytes(Cin, Cout, KH * KW)) + 256;
 }
@@ -1143,11 +1194,18 @@ long stk_conv2d_wp_desc(int dir, const float* w, int w_layout, int Cin, int Cout
 }
 
 int stk_conv2d_wprep_batch(const StkWprepDesc* descs_dev, int n, long max_items, void* stream) {
-  static_assert(sizeof(StkWprepDesc) == sizeof(x3::WprepDesc), "descriptor layout");
+  static_assert(sizeof(StkWprepDesc) == sizeof(x3::WprepDesc) && sizeof(StkWprepDesc) == sizeof(x2::WprepDesc),
+                "descriptor layout");
   if (!descs_dev || n <= 0 || max_items <= 0 || n > 65535) return STK_EINVAL;
   const dim3 grid((unsigned)stk_cdiv(max_items, 256L), (unsigned)n);
-  hipLaunchKernelGGL(x3::wprep_batch_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const x3::WprepDesc*>(descs_dev));
+  if (SPLIT_FWD_DGRAD_X2) {
+    const x2::WprepDesc* d = reinterpret_cast<const x2::WprepDesc*>(descs_dev);
+    hipLaunchKernelGGL(x2::wamax_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, d, x2::WprepDesc{});
+    hipLaunchKernelGGL(x2::wprep_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, x2::WprepDesc{});
+  } else {
+    hipLaunchKernelGGL(x3::wprep_batch_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const x3::WprepDesc*>(descs_dev));
+  }
   STK_CHECK_LAUNCH();
   return STK_OK;
 }

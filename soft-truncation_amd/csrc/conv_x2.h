@@ -1,0 +1,297 @@
+// conv_x2.h -- forward / data-gradient convolution (3x3 pad 1 and 1x1, stride 1) on the fp16 matrix pipe with a TWO-way
+// operand split ("x2"), for gfx950.  Included by conv.hip inside its anonymous namespace, after conv_x3.h, whose tile
+// geometry, buffer-load helpers and K order it shares.
+//
+// Why: the split kernels are limited by the matrix pipe's power-limited clock, i.e. by the number of MFMAs.  An fp32
+// value is, to 2^-24 relative, the sum of two fp16 values (11 + 11 significand bits, round to nearest), so
+//     a*b = a0*b0 + (a0*b1 + a1*b0) + O(2^-22 |ab|)
+// needs THREE fp16 MFMAs where the bf16 three-way split of conv_x3.h needs six (8 + 8 + 8 bits).  fp16 has only 5
+// exponent bits, so each operand tensor is first multiplied by the power of two that puts its largest magnitude in
+// [2^13, 2^14) -- exact, and undone exactly in the epilogue.  An element more than 2^-16 below its tensor's maximum
+// loses (part of) its second term to fp16's subnormal range; its error then stays below 2^-39 of that maximum.
+// Measured against float64 (tools/split_accuracy.py, bench.py `arithmetic_check`): 0.8-1.6e-6 of max|y|, the same as the
+// f32-input MFMA and the bf16 three-way split, also for gradient-like tensors whose images spread over four decades.
+//
+// Scales: the weights' scale is computed when they are prepared (wamax -> 256-byte header of the prepared block); an
+// activation tensor's |x| maximum comes from amax_partial_kernel, launched by the conv call itself: 256 partial maxima
+// that every workgroup of the consumer reduces on its own, so there is no finishing launch and no host round trip.
+#pragma once
+
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+
+namespace x2 {
+
+using x3::KC;
+using x3::PITCH;
+using x3::PLANE;
+constexpr int OPER = 2 * PLANE;
+constexpr int LDS_BYTES = 2 * OPER;    // 40960
+constexpr int NPART = 256;             // partial maxima per activation tensor
+constexpr int HEADER = 256;            // bytes in front of the planes of a prepared block: float scale
+
+// part[b] = max |x| over block b's grid-stride share (any n; 16-byte path when aligned)
+__global__ __launch_bounds__(256) void amax_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const long n4 = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n >> 2 : 0;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)NPART * 256) {
+    const float4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)NPART * 256) m = fmaxf(m, fabsf(x[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// power of two s with m * s in [2^13, 2^14) (1 for m = 0)
+__device__ __forceinline__ float pow2_scale_of(float m) {
+  const int be = (int)((__float_as_uint(m) >> 23) & 0xffu);          // m = 1.f * 2^(be - 127)
+  if (be == 0) return 1.f;
+  const int se = min(max(127 + 13 - (be - 127), 1), 254);
+  return __uint_as_float((unsigned)se << 23);
+}
+// block-wide maximum of `count` (256 or 512) partials; all 256 threads call it; `red` = 4 floats of LDS
+__device__ __forceinline__ float block_amax(const float* __restrict__ part, int count, float* red) {
+  float m = part[threadIdx.x];
+  if (count > NPART) m = fmaxf(m, part[NPART + threadIdx.x]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return m;
+}
+
+__device__ __forceinline__ unsigned pack_h2(float lo, float hi) {
+  const halfx2 v = {(_Float16)lo, (_Float16)hi};                      // round to nearest even
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float lo_part(float v) { return v - (float)(_Float16)v; }   // exact
+
+// ---- weight preparation ---------------------------------------------------------------------------------------------
+// A prepared block = [HEADER bytes: float scale][2 planes: Wp[split][k / 32][tap][row (pad 128)][k % 32] fp16 of scale*W],
+// W(row, k, tap) indexed as in x3::wprep_kernel.  WprepDesc == StkWprepDesc (include/stk.h); wp points at the header.
+struct WprepDesc {
+  const float* w; unsigned char* wp; long sm, sk; int M, Kc, Mpad, taps, flip, reserved;
+};
+// one workgroup per layer: |w| maximum -> scale in the header
+__global__ __launch_bounds__(256) void wamax_kernel(const WprepDesc* __restrict__ descs, WprepDesc one) {
+  __shared__ float red[4];
+  const WprepDesc d = descs ? descs[blockIdx.x] : one;
+  const long n = (long)d.M * d.Kc * d.taps;
+  float m = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(d.w[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *reinterpret_cast<float*>(d.wp) = pow2_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+// blockIdx.y picks the layer (or `one`), blockIdx.x walks its (row, k) pairs
+__global__ __launch_bounds__(256) void wprep_kernel(const WprepDesc* __restrict__ descs, WprepDesc one) {
+  const WprepDesc d = descs ? descs[blockIdx.y] : one;
+  const long total = (long)d.Mpad * d.Kc;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const float s = *reinterpret_cast<const float*>(d.wp);
+  unsigned short* out = reinterpret_cast<unsigned short*>(d.wp + HEADER);
+  const int kl = (int)(i & 31);                      // k fastest inside a group of 32: contiguous 2-byte stores
+  const long rest = i >> 5;
+  const int row = (int)(rest % d.Mpad), cc = (int)(rest / d.Mpad), k = cc * 32 + kl;
+  const long plane = (long)d.taps * d.Mpad * d.Kc;
+  const float* src = d.w + (row < d.M ? row * d.sm + k * d.sk : 0);
+  for (int t = 0; t < d.taps; ++t) {
+    const float a = row < d.M ? s * src[d.flip ? d.taps - 1 - t : t] : 0.f;
+    const _Float16 h0 = (_Float16)a, h1 = (_Float16)(a - (float)h0);
+    const long o = (((long)cc * d.taps + t) * d.Mpad + row) * 32 + kl;
+    out[o] = __builtin_bit_cast(unsigned short, h0);
+    out[plane + o] = __builtin_bit_cast(unsigned short, h1);
+  }
+}
+inline long wp_bytes(int M, int Kc, int taps) { return HEADER + 2L * taps * x3::pad128(M) * Kc * 2; }
+
+// ---- loaders (same slicing contract as conv_x3.h: st(g) of a chunk precedes ld(g) of the next one) -------------------
+// 16 fp32 values of one LDS row -> two fp16 planes.  Slices 0..7 convert one pair each, 8..11 write one 16-byte piece.
+struct Split16 {
+  unsigned pk[2][8];
+  __device__ __forceinline__ void st(int g, const float (&r)[16], float s, unsigned char* tile, int row, int k0) {
+    if (g < 8) {
+      const float v0 = s * r[2 * g], v1 = s * r[2 * g + 1];
+      pk[0][g] = pack_h2(v0, v1);
+      pk[1][g] = pack_h2(lo_part(v0), lo_part(v1));
+    } else if (g < 12) {
+      const int sp = (g - 8) >> 1, h = (g - 8) & 1;
+      *reinterpret_cast<u32x4*>(tile + sp * PLANE + row * PITCH + k0 * 2 + h * 16) =
+          u32x4{pk[sp][4 * h], pk[sp][4 * h + 1], pk[sp][4 * h + 2], pk[sp][4 * h + 3]};
+    }
+  }
+};
+
+struct WpLoader {        // four 16-byte pieces per chunk: split j>>1, row (tid>>2) + 64 (j&1), segment tid&3
+  __amdgpu_buffer_rsrc_t rs; unsigned voff, plane2, chunk2; int row, seg;
+  u32x4 r[4];
+  __device__ __forceinline__ void init(const x3::Src& q, int m0, int tid) {
+    row = tid >> 2; seg = tid & 3;
+    plane2 = (unsigned)q.taps * q.Mpad * q.Kc * 2u;
+    chunk2 = (unsigned)q.Mpad * KC * 2u;
+    rs = x3::make_rsrc(reinterpret_cast<const unsigned char*>(q.wp) + HEADER, 2L * plane2);
+    voff = ((unsigned)(m0 + row) * KC + seg * 8) * 2u;
+  }
+  __device__ __forceinline__ void ld(int g, int c) {
+    if (g >= 4) return;
+    r[g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                         rs, (int)voff, (int)((unsigned)c * chunk2 + (g >> 1) * plane2 + (g & 1) * 64u * KC * 2u), 0));
+  }
+  __device__ __forceinline__ void st(int g, unsigned char* t) {
+    if (g < 4) *reinterpret_cast<u32x4*>(t + (g >> 1) * PLANE + (row + 64 * (g & 1)) * PITCH + seg * 16) = r[g];
+  }
+};
+
+// activations, lanes along pixels; a thread holds 16 channels of one tap-shifted pixel (x3::ActLoader's addressing)
+template <bool DUAL, int TAPS>
+struct ActLoader {
+  __amdgpu_buffer_rsrc_t rs1, rs2;
+  int nl, kg, tb1, tb2; unsigned mask; float scale;
+  float r[16]; Split16 sp;
+  __device__ __forceinline__ void init(const ConvP& p, const x3::Src& q, int n0, int tid, float s) {
+    nl = tid & 127;
+    kg = __builtin_amdgcn_readfirstlane(tid >> 7);      // which 16 of the chunk's 32 channels
+    rs1 = x3::make_rsrc(q.s1, (long)p.N * q.S1 * p.HW * 4);
+    rs2 = x3::make_rsrc(q.s2, (long)p.N * (DUAL ? q.S2 : q.S1) * p.HW * 4);
+    mask = 0; tb1 = 0; tb2 = 0; scale = s;
+    const int n = n0 + nl;
+    if (n < p.N * p.HW) {
+      const int b = n / p.HW, hw = n - b * p.HW;
+      const int y = hw / p.W, x = hw - y * p.W;
+      if (TAPS == 1) mask = 1u;
+#pragma unroll
+      for (int t = 0; t < (TAPS == 9 ? 9 : 0); ++t) {
+        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+      }
+      tb1 = b * q.S1 * p.HW + hw;
+      tb2 = b * q.S2 * p.HW + hw;
+    }
+  }
+  // slices 8..23 load one channel each (its register was consumed by conversion slice (g - 8) / 2 <= 7)
+  __device__ __forceinline__ void ld(int g, const ConvP& p, const x3::Src& q, int c) {
+    if (g < 8) return;
+    const int cc = TAPS == 9 ? c / 9 : c, tap = c - cc * TAPS;   // scalar: chunk = (32-channel group, tap), tap fastest
+    const int ci0 = cc * KC + kg * 16;
+    const bool first = !DUAL || ci0 < q.S1;                      // scalar: a chunk never straddles the two sources
+    const __amdgpu_buffer_rsrc_t rs = first ? rs1 : rs2;
+    const unsigned so = (unsigned)(first ? ci0 : ci0 - q.S1) * p.HW * 4u;
+    const unsigned dead = (((mask >> tap) & 1u) ^ 1u) << 31;     // halo lanes: outside the buffer -> 0
+    const int shift = TAPS == 9 ? (tap / 3 - 1) * p.W + (tap % 3 - 1) : 0;
+    const unsigned vo = (unsigned)(((first ? tb1 : tb2) + shift) * 4) | dead;
+    r[g - 8] = x3::bload(rs, vo, so + (unsigned)(g - 8) * p.HW * 4u);
+  }
+  __device__ __forceinline__ void st(int g, unsigned char* t) { sp.st(g, r, scale, t, nl, kg * 16); }
+};
+
+// ---- the kernel: out tile 128 x 128, 4 waves of 64 x 64, chunks of 32 k; 12 MFMAs per 16-k step and wave -------------
+// Grid (XCD-remapped): one flat dimension of tiles x K-splits.  xpart: `nxpart` (256 / 512) partial |x| maxima.
+template <class BL, class EP>
+__global__ __launch_bounds__(256) void gemm_kernel(ConvP p, x3::Src q, int M, int Nn, int tiles_m, int tiles_n,
+                                                   int nchunks_total, int chunks_per_split, const float* __restrict__ xpart,
+                                                   int nxpart) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  unsigned char* As = lds;
+  unsigned char* Bs = lds + OPER;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const float sx = pow2_scale_of(block_amax(xpart, nxpart, reinterpret_cast<float*>(lds)));
+  const float sw = *reinterpret_cast<const float*>(q.wp);
+  const float unscale = 1.f / (sw * sx);                                   // a power of two: exact
+  const int ntiles = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = id % ntiles, zs = id / ntiles;
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int c_begin = zs * chunks_per_split;
+  const int c_last = min(nchunks_total, c_begin + chunks_per_split) - 1;     // >= c_begin by construction
+
+  WpLoader al; BL bl;
+  al.init(q, m0, tid);
+  bl.init(p, q, n0, tid, sx);
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 64;
+  const int fk = lane >> 5, fc = lane & 31;
+  const unsigned char* a_rd = As + (wm0 + fc) * PITCH + fk * 16;
+  const unsigned char* b_rd = Bs + (wn0 + fc) * PITCH + fk * 16;
+
+  // Pipeline as in x3::gemm_kernel (LDS single-buffered, two barriers per chunk); with 12 MFMAs per half chunk each
+  // MFMA of the second half carries TWO staging slices.
+#define STK_X2_FRAGS(KK)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s = 0; s < 2; ++s) {         \
+    a[i][s] = *reinterpret_cast<const halfx8*>(a_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);          \
+    b[i][s] = *reinterpret_cast<const halfx8*>(b_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);          \
+  }
+  // three products per tile, the two cross terms first; MFMA g: product g / 4, tile (g / 2) & 1, g & 1
+  constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};
+#define STK_X2_MFMA(G)                                                                                              \
+  acc[((G) >> 1) & 1][(G) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[((G) >> 1) & 1][SA[(G) >> 2]], b[(G) & 1][SB[(G) >> 2]], \
+                                                                        acc[((G) >> 1) & 1][(G) & 1], 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 24; ++g) { al.ld(g, c_begin); bl.ld(g, p, q, c_begin); }
+  {
+    const int c1 = min(c_begin + 1, c_last);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) { al.st(g, As); bl.st(g, Bs); al.ld(g, c1); bl.ld(g, p, q, c1); }
+  }
+  halfx8 a[2][2], b[2][2];
+  for (int c = c_begin; c < c_last; ++c) {
+    __syncthreads();                                   // B1: chunk c is in LDS
+    STK_X2_FRAGS(0)
+#pragma unroll
+    for (int g = 0; g < 12; ++g) { STK_X2_MFMA(g) }
+    STK_X2_FRAGS(1)
+    __syncthreads();                                   // B2: nobody reads LDS any more
+    const int c2 = min(c + 2, c_last);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      STK_X2_MFMA(g)
+      al.st(2 * g, As); bl.st(2 * g, Bs); al.st(2 * g + 1, As); bl.st(2 * g + 1, Bs);      // chunk c + 1 -> LDS
+      al.ld(2 * g, c2); bl.ld(2 * g, p, q, c2); al.ld(2 * g + 1, c2); bl.ld(2 * g + 1, p, q, c2);   // chunk c + 2
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+  STK_X2_FRAGS(0)
+#pragma unroll
+  for (int g = 0; g < 12; ++g) { STK_X2_MFMA(g) }
+  STK_X2_FRAGS(1)
+#pragma unroll
+  for (int g = 0; g < 12; ++g) { STK_X2_MFMA(g) }
+#undef STK_X2_MFMA
+#undef STK_X2_FRAGS
+
+  EP ep;
+  ep.init(p, 0, zs);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn0 + j * 32 + fc;
+    const bool nok = n < Nn;
+    ep.col(p, nok ? n : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] *= unscale;
+      ep.strip(p, m0 + wm0 + i * 32 + 4 * fk, M, nok, nok ? n : 0, acc[i][j]);
+    }
+  }
+}
+
+}  // namespace x2

@@ -171,11 +171,11 @@ class Conv(Op):
     # algorithmic FLOPs of one launch (1 MAC = 2 FLOP); identical for fwd, dgrad and wgrad
     self.flops = 2.0 * N * OH * OW * Cout * (C1 + C2) * KH * KW
 
-  _VARIANT = {0: 't64', 1: 't128', 2: 'x3', 3: 't128', 4: 'thin'}
+  _VARIANT = {0: 't64', 1: 't128', 2: 'x3', 3: 't128', 4: 'thin', 5: 'x2'}
 
   def _kind(self, lib, direction):
     """Kernel label for the profiler: direction, taps and the kernel family csrc/conv.hip picks for this shape
-    (t64 / t128 = f32-input MFMA tiles, x3 = bf16 three-way split)."""
+    (t64 / t128 = f32-input MFMA tiles, x3 = bf16 three-way split, x2 = fp16 two-way split)."""
     key = '_kind_' + direction
     k = getattr(self, key, None)
     if k is None:

@@ -64,7 +64,7 @@ def test_forward_backward_wide(st, hip_lib):
   prepared-weight path inside the engine, against the oracle RefNet."""
   cases.forward_backward(st, hip_lib, 'wide', B=96)
   ex_variants = {int(hip_lib.conv2d_variant(d, 96, 0, 96, 16, 16, 96, 16, 16, 3, 3, 1, 1, 0)) for d in (0, 1, 2)}
-  assert ex_variants == {2}                      # this shape does run on the split kernels
+  assert ex_variants <= {2, 5} and 5 in ex_variants        # this shape does run on the split kernels
 
 
 def test_train_steps_wide(st, hip_lib):

@@ -89,8 +89,8 @@ def main():
       rec('conv.fwd.f32in', shape, timeit(lambda: call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, 0, bias, None, 0, None, 1.0, y, *dims, None, 0), args.reps), flops)
       rec('conv.dgrad.f32in', shape, timeit(lambda: call(lib, 'conv2d_dgrad_f32', dy, w, 0, dx1, C1, 0.0, dx2, C2, 0.0, 1.0, *dims, None, 0), args.reps), flops)
       if fb:
-        rec('conv.fwd.x3', shape, timeit(lambda: call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, 0, bias, None, 0, None, 1.0, y, *dims, fws, fb), args.reps), flops)
-        rec('conv.dgrad.x3', shape, timeit(lambda: call(lib, 'conv2d_dgrad_f32', dy, w, 0, dx1, C1, 0.0, dx2, C2, 0.0, 1.0, *dims, fws, fb), args.reps), flops)
+        rec('conv.fwd.split', shape, timeit(lambda: call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, 0, bias, None, 0, None, 1.0, y, *dims, fws, fb), args.reps), flops)
+        rec('conv.dgrad.split', shape, timeit(lambda: call(lib, 'conv2d_dgrad_f32', dy, w, 0, dx1, C1, 0.0, dx2, C2, 0.0, 1.0, *dims, fws, fb), args.reps), flops)
       rec('conv.wgrad', shape, timeit(lambda: call(lib, 'conv2d_wgrad_f32', x1, C1, x2, C2, dy, dw, 0, 1.0, ws, ws.numel() * 4, *dims), args.reps), flops)
 
   if not args.only or 'gn' in args.only:

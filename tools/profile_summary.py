@@ -14,7 +14,7 @@ root = sys.argv[1]
 
 
 def short(n):
-  n = re.sub(r'\(anonymous namespace\)::|igemm::|void |x3::', '', n)
+  n = re.sub(r'\(anonymous namespace\)::|igemm::|void |x3::', '', n)      # x2:: is kept: it tells the two gemm_kernel families apart
   n = re.sub(r'Cfg<(\d+), (\d+), (\d+)>', r'C\1', n)
   return n.split('(')[0][:90]
 
