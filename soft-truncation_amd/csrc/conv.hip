@@ -858,9 +858,9 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
   p.part_stride = r.slab;
   if (SPLIT_FWD_DGRAD_X2) {
     // fp16 two-way split (conv_x2.h): |x| maxima of the activation operand(s), weights prepared here unless the caller did
-    hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(256), 0, s, s1, (long)p.N * S1 * p.HW, xpart);
+    hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s1, (long)p.N * S1 * p.HW, xpart);
     if (S2 > 0)
-      hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(256), 0, s, s2, (long)p.N * S2 * p.HW,
+      hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s2, (long)p.N * S2 * p.HW,
                          xpart + x2::NPART);
     STK_CHECK_LAUNCH();
     const int nx = S2 > 0 ? 2 * x2::NPART : x2::NPART;
@@ -871,7 +871,7 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
       one.w = p.w; one.wp = reinterpret_cast<unsigned char*>(wp); one.M = M; one.Kc = q.Kc; one.Mpad = q.Mpad;
       one.taps = p.taps; one.flip = dgrad;
       x3_weight_strides(p, dgrad, one.sm, one.sk);
-      hipLaunchKernelGGL(x2::wamax_kernel, dim3(1), dim3(256), 0, s, nullptr, one);
+      hipLaunchKernelGGL(x2::wamax_kernel, dim3(x2::WPART, 1), dim3(256), 0, s, nullptr, one);
       hipLaunchKernelGGL(x2::wprep_kernel, dim3((unsigned)stk_cdiv((long)q.Mpad * q.Kc, 256L)), dim3(256), 0, s, nullptr, one);
       STK_CHECK_LAUNCH();
       q.wp = wp;
@@ -1200,7 +1200,7 @@ int stk_conv2d_wprep_batch(const StkWprepDesc* descs_dev, int n, long max_items,
   const dim3 grid((unsigned)stk_cdiv(max_items, 256L), (unsigned)n);
   if (SPLIT_FWD_DGRAD_X2) {
     const x2::WprepDesc* d = reinterpret_cast<const x2::WprepDesc*>(descs_dev);
-    hipLaunchKernelGGL(x2::wamax_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, d, x2::WprepDesc{});
+    hipLaunchKernelGGL(x2::wamax_kernel, dim3(x2::WPART, (unsigned)n), dim3(256), 0, (hipStream_t)stream, d, x2::WprepDesc{});
     hipLaunchKernelGGL(x2::wprep_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, x2::WprepDesc{});
   } else {
     hipLaunchKernelGGL(x3::wprep_batch_kernel, grid, dim3(256), 0, (hipStream_t)stream,

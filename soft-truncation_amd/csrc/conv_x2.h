@@ -12,7 +12,7 @@
 // Measured against float64 (tools/split_accuracy.py, bench.py `arithmetic_check`): 0.8-1.6e-6 of max|y|, the same as the
 // f32-input MFMA and the bf16 three-way split, also for gradient-like tensors whose images spread over four decades.
 //
-// Scales: the weights' scale is computed when they are prepared (wamax -> 256-byte header of the prepared block); an
+// Scales: the weights' |w| maximum is taken when they are prepared (wamax -> 256-byte header of the prepared block); an
 // activation tensor's |x| maximum comes from amax_partial_kernel, launched by the conv call itself: 256 partial maxima
 // that every workgroup of the consumer reduces on its own, so there is no finishing launch and no host round trip.
 #pragma once
@@ -28,23 +28,37 @@ using x3::PLANE;
 constexpr int OPER = 2 * PLANE;
 constexpr int LDS_BYTES = 2 * OPER;    // 40960
 constexpr int NPART = 256;             // partial maxima per activation tensor
-constexpr int HEADER = 256;            // bytes in front of the planes of a prepared block: float scale
+constexpr int HEADER = 256;            // bytes in front of the planes of a prepared block: WPART partial |w| maxima
 
-// part[b] = max |x| over block b's grid-stride share (any n; 16-byte path when aligned)
-__global__ __launch_bounds__(256) void amax_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
-  __shared__ float red[4];
-  float m = 0.f;
+// part[b] = max |x| over block b's grid-stride share (any n; 16-byte path when aligned).  1024 threads per block and two
+// independent 16-byte loads per thread and trip: with 256 x 256 threads the pass ran at 2.6 TB/s, latency-bound.
+constexpr int AMAX_THREADS = 1024;
+__global__ __launch_bounds__(AMAX_THREADS) void amax_partial_kernel(const float* __restrict__ x, long n,
+                                                                   float* __restrict__ part) {
+  __shared__ float red[AMAX_THREADS / 64];
+  float m0 = 0.f, m1 = 0.f;
   const long n4 = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n >> 2 : 0;
   const float4* x4 = reinterpret_cast<const float4*>(x);
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)NPART * 256) {
-    const float4 v = x4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  const long stride = (long)NPART * AMAX_THREADS;
+  long i = (long)blockIdx.x * AMAX_THREADS + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 u = x4[i], v = x4[i + stride];
+    m0 = fmaxf(fmaxf(m0, fmaxf(fabsf(u.x), fabsf(u.y))), fmaxf(fabsf(u.z), fabsf(u.w)));
+    m1 = fmaxf(fmaxf(m1, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
-  for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)NPART * 256) m = fmaxf(m, fabsf(x[i]));
-  m = wave_max(m);
+  if (i < n4) {
+    const float4 u = x4[i];
+    m0 = fmaxf(fmaxf(m0, fmaxf(fabsf(u.x), fabsf(u.y))), fmaxf(fabsf(u.z), fabsf(u.w)));
+  }
+  for (long j = 4 * n4 + (long)blockIdx.x * AMAX_THREADS + threadIdx.x; j < n; j += stride) m1 = fmaxf(m1, fabsf(x[j]));
+  float m = wave_max(fmaxf(m0, m1));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < AMAX_THREADS / 64; ++w) m = fmaxf(m, red[w]);
+    part[blockIdx.x] = m;
+  }
 }
 
 // power of two s with m * s in [2^13, 2^14) (1 for m = 0)
@@ -73,22 +87,31 @@ __device__ __forceinline__ unsigned pack_h2(float lo, float hi) {
 __device__ __forceinline__ float lo_part(float v) { return v - (float)(_Float16)v; }   // exact
 
 // ---- weight preparation ---------------------------------------------------------------------------------------------
-// A prepared block = [HEADER bytes: float scale][2 planes: Wp[split][k / 32][tap][row (pad 128)][k % 32] fp16 of scale*W],
+// A prepared block = [HEADER bytes: partial |w| maxima][2 planes: Wp[split][k / 32][tap][row (pad 128)][k % 32] fp16 of scale*W],
 // W(row, k, tap) indexed as in x3::wprep_kernel.  WprepDesc == StkWprepDesc (include/stk.h); wp points at the header.
 struct WprepDesc {
   const float* w; unsigned char* wp; long sm, sk; int M, Kc, Mpad, taps, flip, reserved;
 };
-// one workgroup per layer: |w| maximum -> scale in the header
+// |w| maxima: WPART workgroups per layer (blockIdx.y = layer, blockIdx.x = share) write one partial each into the header;
+// the consumers (wprep_kernel, gemm_kernel) take the maximum of the WPART floats.  No atomics, nothing to zero.
+constexpr int WPART = 16;
 __global__ __launch_bounds__(256) void wamax_kernel(const WprepDesc* __restrict__ descs, WprepDesc one) {
   __shared__ float red[4];
-  const WprepDesc d = descs ? descs[blockIdx.x] : one;
+  const WprepDesc d = descs ? descs[blockIdx.y] : one;
   const long n = (long)d.M * d.Kc * d.taps;
   float m = 0.f;
-  for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(d.w[i]));
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)WPART * 256) m = fmaxf(m, fabsf(d.w[i]));
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) *reinterpret_cast<float*>(d.wp) = pow2_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+  if (threadIdx.x == 0) reinterpret_cast<float*>(d.wp)[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float weight_scale(const void* header) {
+  const float* h = static_cast<const float*>(header);
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < WPART; ++i) m = fmaxf(m, h[i]);
+  return pow2_scale_of(m);
 }
 // blockIdx.y picks the layer (or `one`), blockIdx.x walks its (row, k) pairs
 __global__ __launch_bounds__(256) void wprep_kernel(const WprepDesc* __restrict__ descs, WprepDesc one) {
@@ -96,7 +119,7 @@ __global__ __launch_bounds__(256) void wprep_kernel(const WprepDesc* __restrict_
   const long total = (long)d.Mpad * d.Kc;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const float s = *reinterpret_cast<const float*>(d.wp);
+  const float s = weight_scale(d.wp);
   unsigned short* out = reinterpret_cast<unsigned short*>(d.wp + HEADER);
   const int kl = (int)(i & 31);                      // k fastest inside a group of 32: contiguous 2-byte stores
   const long rest = i >> 5;
@@ -204,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ConvP p, x3::Src q, int M, in
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const float sx = pow2_scale_of(block_amax(xpart, nxpart, reinterpret_cast<float*>(lds)));
-  const float sw = *reinterpret_cast<const float*>(q.wp);
+  const float sw = weight_scale(q.wp);
   const float unscale = 1.f / (sw * sx);                                   // a power of two: exact
   const int ntiles = tiles_m * tiles_n;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
