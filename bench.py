@@ -34,8 +34,8 @@ import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)": the f32-input MFMA kernels (t64 / t128)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md dense bf16 MFMA peak
-# The x3 kernels (weight gradient) issue six bf16 MFMAs per fp32 product (three-way operand split), the x2 kernels
-# (forward, data gradient) three fp16 MFMAs (two-way split of power-of-two-scaled operands; fp16 and bf16 MFMAs run at
+# The x3 kernels (1x1 / small-map weight gradients) issue six bf16 MFMAs per fp32 product (three-way operand split), the
+# x2 kernels (forward, data gradient, 3x3 weight gradient) three fp16 MFMAs (two-way split of power-of-two-scaled operands; fp16 and bf16 MFMAs run at
 # the same rate): the fp32-equivalent ceiling of the matrix pipe is the 16-bit peak / 6 resp. / 3.
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
@@ -43,7 +43,7 @@ PEAK_X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 
 # rocprofv3 symbol of the kernel behind a profiler label (for the committed PMC summary, see traffic_of)
 KERNEL_SYMBOL = {
-  'conv3x3.wgrad.x3': 'wgrad3_kernel<false>',
+  'conv3x3.wgrad.x2': 'x2::wgrad3_kernel<false>',
   'conv3x3.fwd.x2': 'x2::gemm_kernel<x2::ActLoader<false, 9>, EpFwd>',
   'conv3x3.dgrad.x2': 'x2::gemm_kernel<x2::ActLoader<false, 9>, EpDgrad>',
 }
@@ -259,8 +259,9 @@ def main():
       'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'arithmetic': 'fp32 tensors and fp32 accumulation everywhere; the large convolutions evaluate each fp32 product '
-                    'from split operands on the 16-bit matrix pipe -- forward / data gradient: power-of-two-scaled '
-                    'operands as two fp16 terms, 3 MFMAs; weight gradient: three bf16 terms, 6 MFMAs -- with errors at '
+                    'from split operands on the 16-bit matrix pipe: power-of-two-scaled '
+                    'operands as two fp16 terms, 3 MFMAs (forward, data gradient, 3x3 weight gradient); three bf16 terms, 6 MFMAs '
+                    '(1x1 and small-map weight gradients) -- with errors at '
                     'the fp32 rounding level (arithmetic_check; parity-tested against the double-precision oracle at '
                     'the same tolerance as the f32-input MFMA path)',
       'config': {'workload': desc, 'per_gpu_batch': per_gpu_batch, 'global_batch': global_batch,

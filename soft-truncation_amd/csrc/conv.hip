@@ -841,6 +841,7 @@ inline long x3_ws_bytes(const X3Plan& r, int M, int Kc, int taps) {
 // Forward / data gradient on the split kernels: true = fp16 two-way split (conv_x2.h, 3 MFMAs per fp32 product),
 // false = bf16 three-way split (conv_x3.h, 6).  The weight gradient stays on the bf16 kernels of conv_x3.h.
 constexpr bool SPLIT_FWD_DGRAD_X2 = true;
+constexpr bool SPLIT_WGRAD3_X2 = true;      // the three-taps-per-workgroup 3x3 weight gradient on the fp16 split too
 
 inline void x3_weight_strides(const ConvP& p, int dgrad, long& sm, long& sk) {
   if (p.w_layout == 0) { sm = dgrad ? p.taps : (long)p.Cin * p.taps; sk = dgrad ? (long)p.Cin * p.taps : p.taps; }
@@ -1159,7 +1160,10 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
     return use_big_tile(Cin, Ng, 1) && !(p.taps == 1 && w_layout == 1 && (Cout % 8)) ? 1 : 0;
   }
   if (thin::geometry_ok(p) && ((C2 == 0 && Cin <= 4) || Cout <= 4)) return 4;
-  if (x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad).ok) return 2;
+  {
+    const X3WgradPlan xq = x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad);
+    if (xq.ok) return xq.rows3 && SPLIT_WGRAD3_X2 ? 5 : 2;
+  }
   const bool can9 = stride == 1 && pad == 1 && C2 == 0 && OH == H && OW == W && w_layout == 0;
   const WgradPlan q = wgrad_plan(Cin, N, Cout, OH, OW, KH, KW, can9);
   return q.mode9 ? 3 : q.big;
@@ -1230,7 +1234,7 @@ long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, 
   long m = na > nb ? na : nb;
   if (C2 == 0 && C1 <= 4) { const long t = (long)thin::wgrad_slabs(N, (long)OH * OW, Cout) * Cout * C1 * KH * KW; m = t > m ? t : m; }
   if (Cout <= 4) { const long t = (long)thin::wgrad_slabs(N, (long)OH * OW, C1 + C2) * Cout * (C1 + C2) * KH * KW; m = t > m ? t : m; }
-  return (m > nx ? m : nx) * 4 + 256;
+  return (m > nx ? m : nx) * 4 + 256 + 256 + 3L * x2::NPART * 4;      // + partial maxima of dy, x1, x2
 }
 
 int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const float* dy, float* dw, int w_layout,
@@ -1274,8 +1278,23 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
     if (xq.rows3) {
       const int tn64 = stk_cdiv(p.Cin, 64);
       const dim3 grid3((unsigned)(3 * tm * tn64 * xq.splits));
-      if (C2 > 0) hipLaunchKernelGGL((x3::wgrad3_kernel<true>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split);
-      else hipLaunchKernelGGL((x3::wgrad3_kernel<false>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split);
+      float* parts = reinterpret_cast<float*>(((uintptr_t)(ws + (long)xq.splits * xq.slab) + 255) & ~(uintptr_t)255);
+      if (SPLIT_WGRAD3_X2 && ws_bytes >= (long)xq.splits * xq.slab * 4 + 256 + 3L * x2::NPART * 4) {
+        // fp16 two-way split of both operands (conv_x2.h): |dy| and |x| maxima first
+        const dim3 ab(x2::NPART), at(x2::AMAX_THREADS);
+        hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, dy, (long)N * Cout * p.OHW, parts);
+        hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, x1, (long)N * C1 * p.HW, parts + x2::NPART);
+        if (C2 > 0) hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, x2, (long)N * C2 * p.HW, parts + 2 * x2::NPART);
+        const int nx = C2 > 0 ? 2 * x2::NPART : x2::NPART;
+        if (C2 > 0) hipLaunchKernelGGL((x2::wgrad3_kernel<true>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split,
+                                       parts, parts + x2::NPART, nx);
+        else hipLaunchKernelGGL((x2::wgrad3_kernel<false>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split,
+                                parts, parts + x2::NPART, nx);
+      } else if (C2 > 0) {
+        hipLaunchKernelGGL((x3::wgrad3_kernel<true>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split);
+      } else {
+        hipLaunchKernelGGL((x3::wgrad3_kernel<false>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split);
+      }
       STK_CHECK_LAUNCH();
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((xq.slab + 3) / 4)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
                          xq.slab, alpha, w_layout, Cout, p.Cin, p.taps);

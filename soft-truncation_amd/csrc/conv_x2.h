@@ -140,9 +140,10 @@ inline long wp_bytes(int M, int Kc, int taps) { return HEADER + 2L * taps * x3::
 // 16 fp32 values of one LDS row -> two fp16 planes.  Slices 0..7 convert one pair each, 8..11 write one 16-byte piece.
 struct Split16 {
   unsigned pk[2][8];
-  __device__ __forceinline__ void st(int g, const float (&r)[16], float s, unsigned char* tile, int row, int k0) {
+  __device__ __forceinline__ void st(int g, const float (&r)[16], float s, unsigned char* tile, int row, int k0,
+                                     unsigned okm = 0xffffu) {
     if (g < 8) {
-      const float v0 = s * r[2 * g], v1 = s * r[2 * g + 1];
+      const float v0 = s * igemm::keep_if(r[2 * g], okm, 2 * g), v1 = s * igemm::keep_if(r[2 * g + 1], okm, 2 * g + 1);
       pk[0][g] = pack_h2(v0, v1);
       pk[1][g] = pack_h2(lo_part(v0), lo_part(v1));
     } else if (g < 12) {
@@ -314,6 +315,159 @@ __global__ __launch_bounds__(256) void gemm_kernel(ConvP p, x3::Src q, int M, in
       for (int e = 0; e < 16; ++e) acc[i][j][e] *= unscale;
       ep.strip(p, m0 + wm0 + i * 32 + 4 * fk, M, nok, nok ? n : 0, acc[i][j]);
     }
+  }
+}
+
+// ---- 3x3 weight gradient, three taps per workgroup, on the two-way split ---------------------------------------------
+// x3::wgrad3_kernel (same tiling, same loads, same slab layout) with both operands scaled and split into two fp16
+// terms: 18 instead of 36 MFMAs per wave and half chunk.  The loaders are x3's with the splitter replaced.
+constexpr int W3_BPLANE = 64 * PITCH;
+constexpr int W3_BTAP = 2 * W3_BPLANE;
+constexpr int W3_LDS = OPER + 3 * W3_BTAP;       // 20480 + 30720 = 51200 bytes
+
+struct RowsA : x3::RowsLoader<false, false, 16> {          // dy: 16 consecutive pixels of one output channel
+  Split16 sp2; float scale;
+  __device__ __forceinline__ void st(int g, unsigned char* t) { sp2.st(g, r, scale, t, row, half * 16, okm); }
+};
+
+template <bool DUAL>
+struct Rows3 : x3::Rows3Loader<DUAL> {                     // x: the 10-pixel run of one input channel, three windows
+  using B = x3::Rows3Loader<DUAL>;
+  _Float16 hh[2][10]; float scale;
+  // slices 0..4 split two elements each, 5..10 pack + write one (tap, plane) window each
+  __device__ __forceinline__ void st(int g, unsigned char* t) {
+    if (g < 5) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = 2 * g + u;
+        const float v = scale * igemm::keep_if(B::r[e], B::okm, e);
+        hh[0][e] = (_Float16)v;
+        hh[1][e] = (_Float16)(v - (float)hh[0][e]);
+      }
+    } else if (g < 11) {
+      const int tap = (g - 5) >> 1, s = (g - 5) & 1;        // window of tap kw: elements kw - 1 .. kw + 6 -> hh[kw .. kw + 7]
+      unsigned char* d = t + tap * W3_BTAP + s * W3_BPLANE + B::row * PITCH + B::quarter * 16;
+      unsigned w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const halfx2 v = {hh[s][tap + 2 * j], hh[s][tap + 2 * j + 1]};
+        w[j] = __builtin_bit_cast(unsigned, v);
+      }
+      *reinterpret_cast<u32x4*>(d) = u32x4{w[0], w[1], w[2], w[3]};
+    }
+  }
+};
+
+// dypart: 256 partial |dy| maxima; xpart: nxpart (256 / 512) partial |x| maxima
+template <bool DUAL>
+__global__ __launch_bounds__(256) void wgrad3_kernel(ConvP p, int tiles_m, int tiles_n, int nchunks_total, int chunks_per_split,
+                                                     const float* __restrict__ dypart, const float* __restrict__ xpart, int nxpart) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[W3_LDS];
+  unsigned char* As = lds;
+  unsigned char* Bs = lds + OPER;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const float sa = pow2_scale_of(block_amax(dypart, NPART, reinterpret_cast<float*>(lds)));
+  const float sb = pow2_scale_of(block_amax(xpart, nxpart, reinterpret_cast<float*>(lds)));
+  const float unscale = 1.f / (sa * sb);
+  const int ntiles = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);       // kernel row fastest: the three blocks share dy / x panels
+  const int kh = id % 3;
+  const int rest = id / 3;
+  const int tile = rest % ntiles;
+  const int zs = rest / ntiles;
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int m0 = tm * 128, n0 = tn * 64;
+  const int c_begin = zs * chunks_per_split;
+  const int c_last = min(nchunks_total, c_begin + chunks_per_split) - 1;
+
+  x3::Src q = {};
+  RowsA al;
+  Rows3<DUAL> bl;
+  al.init(p, q, m0, tid, 4); al.scale = sa;
+  bl.init(p, n0, tid, kh); bl.scale = sb;
+
+  floatx16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.f;
+
+  const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 32;
+  const int fk = lane >> 5, fc = lane & 31;
+  const unsigned char* a_rd = As + (wm0 + fc) * PITCH + fk * 16;
+  const unsigned char* b_rd = Bs + (wn0 + fc) * PITCH + fk * 16;
+
+#define STK_W3_FRAGS(KK)                                                                                   \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+      a[i][s] = *reinterpret_cast<const halfx8*>(a_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);             \
+    _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                            \
+      b[t][s] = *reinterpret_cast<const halfx8*>(b_rd + t * W3_BTAP + s * W3_BPLANE + (KK) * 32);            \
+  }
+  constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};
+#define STK_W3_MFMAS                                                                                       \
+  _Pragma("unroll") for (int pr = 0; pr < 3; ++pr) _Pragma("unroll") for (int i = 0; i < 2; ++i)              \
+    _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                            \
+      acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][SA[pr]], b[t][SB[pr]], acc[i][t], 0, 0, 0);
+
+#pragma unroll
+  for (int g = 0; g < 24; ++g) { al.ld(g, p, q, c_begin); bl.ld(g, p, c_begin); }
+  {
+    const int c1 = min(c_begin + 1, c_last);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) { al.st(g, As); bl.st(g, Bs); }
+#pragma unroll
+    for (int g = 0; g < 24; ++g) { al.ld(g, p, q, c1); bl.ld(g, p, c1); }
+  }
+  halfx8 a[2][2], b[3][2];
+  for (int c = c_begin; c < c_last; ++c) {
+    __syncthreads();                                   // chunk c is in LDS
+    STK_W3_FRAGS(0)
+    STK_W3_MFMAS
+    STK_W3_FRAGS(1)
+    __syncthreads();                                   // nobody reads LDS any more
+    const int c2 = min(c + 2, c_last);
+    STK_W3_MFMAS
+#pragma unroll
+    for (int g = 0; g < 24; ++g) al.st(g, As);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) bl.st(g, Bs);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) al.ld(g, p, q, c2);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) bl.ld(g, p, c2);
+#pragma unroll
+    for (int g = 0; g < 18; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);     // VALU
+      if (g < 10) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write (4 + 6 per thread and chunk)
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);     // VMEM read
+    }
+  }
+  __syncthreads();
+  STK_W3_FRAGS(0)
+  STK_W3_MFMAS
+  STK_W3_FRAGS(1)
+  STK_W3_MFMAS
+#undef STK_W3_MFMAS
+#undef STK_W3_FRAGS
+
+  // partial slab of split zs as [tap][Cout][Cin] (lanes = ci, contiguous); splitk_reduce_kernel re-lays it out
+  float* slab = p.part + (long)zs * p.part_stride;
+  const int n = n0 + wn0 + fc;
+  if (n < p.Cin) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm0 + i * 32 + 4 * fk + igemm::strip_row(e);
+          if (m < p.Cout) slab[((long)(kh * 3 + t) * p.Cout + m) * p.Cin + n] = unscale * acc[i][t][e];
+        }
   }
 }
 
