@@ -153,12 +153,22 @@ int stk_conv2d_fwd_wp_f32(const float* x1, int C1, const float* x2, int C2,
                           const float* temb, int temb_stride, const float* res, float out_div,
                           float* y, int N, int H, int W, int Cout, int OH, int OW,
                           int KH, int KW, int stride, int pad,
-                          const void* wp, void* ws, long ws_bytes, void* stream);
+                          const void* wp, float* amax, void* ws, long ws_bytes, void* stream);
 int stk_conv2d_dgrad_wp_f32(const float* dy, const float* w, int w_layout,
                             float* dx1, int C1, float beta1, float* dx2, int C2, float beta2,
                             float alpha, int N, int H, int W, int Cout, int OH, int OW,
                             int KH, int KW, int stride, int pad,
-                            const void* wp, void* ws, long ws_bytes, void* stream);
+                            const void* wp, float* amax, void* ws, long ws_bytes, void* stream);
+/* amax (may be NULL): a caller-owned buffer of 768 floats per layer and forward/backward pair.  The split kernels
+ * scale each operand tensor by its |x| maximum; the forward call leaves the partial maxima of x1 / x2 in
+ * amax[0..511], the data-gradient call those of dy in amax[512..767], and stk_conv2d_wgrad_amax_f32 reuses them
+ * (have: bit 0 = the x part is valid, bit 1 = the dy part) instead of repeating the passes.  Only calls that took
+ * the split kernel (stk_conv2d_variant == 5) write their part. */
+int stk_conv2d_wgrad_amax_f32(const float* x1, int C1, const float* x2, int C2, const float* dy,
+                              float* dw, int w_layout, float alpha, float* ws, long ws_bytes,
+                              int N, int H, int W, int Cout, int OH, int OW,
+                              int KH, int KW, int stride, int pad,
+                              const float* amax, int have, void* stream);
 long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW);
 int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const float* dy,
                          float* dw, int w_layout, float alpha, float* ws, long ws_bytes,

@@ -850,7 +850,7 @@ inline void x3_weight_strides(const ConvP& p, int dgrad, long& sm, long& sk) {
 // wp_ready: weights already prepared by stk_conv2d_wprep_batch (then ws only holds the K-split slabs)
 template <class EP>
 int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2, int S2, int M, long Ng, int dgrad,
-              void* ws, hipStream_t s, const void* wp_ready = nullptr) {
+              void* ws, hipStream_t s, const void* wp_ready = nullptr, float* amax = nullptr) {
   x3::Src q;
   q.s1 = s1; q.s2 = S2 > 0 ? s2 : s1; q.S1 = S1; q.S2 = S2; q.Kc = S1 + S2; q.Mpad = x3::pad128(M); q.taps = p.taps;
   unsigned short* wp = reinterpret_cast<unsigned short*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
@@ -859,6 +859,9 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
   p.part_stride = r.slab;
   if (SPLIT_FWD_DGRAD_X2) {
     // fp16 two-way split (conv_x2.h): |x| maxima of the activation operand(s), weights prepared here unless the caller did
+    // with a caller-owned amax buffer (768 floats: |x1|, |x2|, |dy| partials) the maxima stay available to the layer's
+    // weight gradient, which would otherwise repeat these passes
+    if (amax) xpart = amax + (dgrad ? 2 * x2::NPART : 0);
     hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s1, (long)p.N * S1 * p.HW, xpart);
     if (S2 > 0)
       hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s2, (long)p.N * S2 * p.HW,
@@ -1024,7 +1027,7 @@ extern "C" {
 int stk_conv2d_fwd_wp_f32(const float* x1, int C1, const float* x2, int C2, const float* w, int w_layout,
                           const float* bias, const float* temb, int temb_stride, const float* res, float out_div,
                           float* y, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad,
-                          const void* wp, void* ws, long ws_bytes, void* stream) {
+                          const void* wp, float* amax, void* ws, long ws_bytes, void* stream) {
   if (!x1 || !w || !y || (C2 > 0 && !x2) || out_div == 0.f || (w_layout != 0 && w_layout != 1) ||
       (w_layout == 1 && (KH != 1 || KW != 1)))
     return STK_EINVAL;
@@ -1057,7 +1060,7 @@ int stk_conv2d_fwd_wp_f32(const float* x1, int C1, const float* x2, int C2, cons
   }
   const X3Plan xr = x3_plan(p, p.Cin, C1, C2, Cout, Ng);
   if (ws && xr.ok && ws_bytes >= x3_ws_bytes(xr, Cout, p.Cin, p.taps))
-    return launch_x3<EpFwd>(p, xr, x1, C1, x2, C2, Cout, Ng, 0, ws, s, wp);
+    return launch_x3<EpFwd>(p, xr, x1, C1, x2, C2, Cout, Ng, 0, ws, s, wp, amax);
   if (wp) return STK_EINVAL;      // prepared weights exist only for the shapes stk_conv2d_wp_bytes reports
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;
@@ -1086,12 +1089,13 @@ int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const f
                        float* y, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad,
                        void* ws, long ws_bytes, void* stream) {
   return stk_conv2d_fwd_wp_f32(x1, C1, x2, C2, w, w_layout, bias, temb, temb_stride, res, out_div, y, N, H, W, Cout, OH, OW,
-                               KH, KW, stride, pad, nullptr, ws, ws_bytes, stream);
+                               KH, KW, stride, pad, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
 int stk_conv2d_dgrad_wp_f32(const float* dy, const float* w, int w_layout, float* dx1, int C1, float beta1, float* dx2,
                             int C2, float beta2, float alpha, int N, int H, int W, int Cout, int OH, int OW, int KH,
-                            int KW, int stride, int pad, const void* wp, void* ws, long ws_bytes, void* stream) {
+                            int KW, int stride, int pad, const void* wp, float* amax, void* ws, long ws_bytes,
+                            void* stream) {
   if (!dy || !w || (!dx1 && !dx2) || (w_layout != 0 && w_layout != 1) || (w_layout == 1 && (KH != 1 || KW != 1)))
     return STK_EINVAL;
   ConvP p = {};
@@ -1114,7 +1118,7 @@ int stk_conv2d_dgrad_wp_f32(const float* dy, const float* w, int w_layout, float
   }
   const X3Plan xr = x3_plan(p, Cout, Cout, 0, Cin, Ng);
   if (ws && xr.ok && ws_bytes >= x3_ws_bytes(xr, Cin, Cout, p.taps))
-    return launch_x3<EpDgrad>(p, xr, dy, Cout, nullptr, 0, Cin, Ng, 1, ws, s, wp);
+    return launch_x3<EpDgrad>(p, xr, dy, Cout, nullptr, 0, Cin, Ng, 1, ws, s, wp, amax);
   if (wp) return STK_EINVAL;
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;
@@ -1136,7 +1140,7 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
                          int C2, float beta2, float alpha, int N, int H, int W, int Cout, int OH, int OW, int KH,
                          int KW, int stride, int pad, void* ws, long ws_bytes, void* stream) {
   return stk_conv2d_dgrad_wp_f32(dy, w, w_layout, dx1, C1, beta1, dx2, C2, beta2, alpha, N, H, W, Cout, OH, OW, KH, KW, stride,
-                                 pad, nullptr, ws, ws_bytes, stream);
+                                 pad, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
 /* which kernel family a call with full scratch takes: 0/1 = f32-input MFMA with 64/128 tiles, 2 = bf16 three-way
@@ -1237,9 +1241,9 @@ long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, 
   return (m > nx ? m : nx) * 4 + 256 + 256 + 3L * x2::NPART * 4;      // + partial maxima of dy, x1, x2
 }
 
-int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const float* dy, float* dw, int w_layout,
-                         float alpha, float* ws, long ws_bytes, int N, int H, int W, int Cout, int OH, int OW, int KH,
-                         int KW, int stride, int pad, void* stream) {
+int stk_conv2d_wgrad_amax_f32(const float* x1, int C1, const float* x2, int C2, const float* dy, float* dw, int w_layout,
+                              float alpha, float* ws, long ws_bytes, int N, int H, int W, int Cout, int OH, int OW, int KH,
+                              int KW, int stride, int pad, const float* amax, int have, void* stream) {
   if (!x1 || !dy || !dw || !ws || (C2 > 0 && !x2) || (w_layout != 0 && w_layout != 1) ||
       (w_layout == 1 && (KH != 1 || KW != 1)))
     return STK_EINVAL;
@@ -1282,14 +1286,22 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
       if (SPLIT_WGRAD3_X2 && ws_bytes >= (long)xq.splits * xq.slab * 4 + 256 + 3L * x2::NPART * 4) {
         // fp16 two-way split of both operands (conv_x2.h): |dy| and |x| maxima first
         const dim3 ab(x2::NPART), at(x2::AMAX_THREADS);
-        hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, dy, (long)N * Cout * p.OHW, parts);
-        hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, x1, (long)N * C1 * p.HW, parts + x2::NPART);
-        if (C2 > 0) hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, x2, (long)N * C2 * p.HW, parts + 2 * x2::NPART);
+        // maxima the layer's forward (x) / data-gradient (dy) calls left in `amax` are reused, the others taken here
+        const float* dyp = parts;
+        const float* xp = parts + x2::NPART;
+        if (amax && (have & 2)) dyp = amax + 2 * x2::NPART;
+        else hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, dy, (long)N * Cout * p.OHW, parts);
+        if (amax && (have & 1)) {
+          xp = amax;
+        } else {
+          hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, x1, (long)N * C1 * p.HW, parts + x2::NPART);
+          if (C2 > 0) hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, x2, (long)N * C2 * p.HW, parts + 2 * x2::NPART);
+        }
         const int nx = C2 > 0 ? 2 * x2::NPART : x2::NPART;
         if (C2 > 0) hipLaunchKernelGGL((x2::wgrad3_kernel<true>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split,
-                                       parts, parts + x2::NPART, nx);
+                                       dyp, xp, nx);
         else hipLaunchKernelGGL((x2::wgrad3_kernel<false>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split,
-                                parts, parts + x2::NPART, nx);
+                                dyp, xp, nx);
       } else if (C2 > 0) {
         hipLaunchKernelGGL((x3::wgrad3_kernel<true>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split);
       } else {
@@ -1343,6 +1355,13 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
                      q.slab, alpha, w_layout, Cout, p.Cin, p.taps);
   STK_CHECK_LAUNCH();
   return STK_OK;
+}
+
+int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const float* dy, float* dw, int w_layout,
+                         float alpha, float* ws, long ws_bytes, int N, int H, int W, int Cout, int OH, int OW, int KH,
+                         int KW, int stride, int pad, void* stream) {
+  return stk_conv2d_wgrad_amax_f32(x1, C1, x2, C2, dy, dw, w_layout, alpha, ws, ws_bytes, N, H, W, Cout, OH, OW, KH, KW, stride,
+                                   pad, nullptr, 0, stream);
 }
 
 int stk_gemm_f32(const float* A, long sam, long sak, long sab, const float* B, long sbk, long sbn, long sbb, float* C,

@@ -167,6 +167,9 @@ class Conv(Op):
     self.temb_stride = temb.shape[1] if temb is not None else 0
     self.res, self.out_div = res, float(out_div)
     self.y = g.new((N, Cout, OH, OW), name=name)
+    # partial |x1|, |x2|, |dy| maxima of the split kernels (include/stk.h "amax"): written by this layer's forward /
+    # data-gradient calls, reused by its weight gradient; lives with the activations, i.e. per forward context
+    self.amax = g.new((768,), needs_grad=False, name=name + '.amax')
     self.inputs = (x1, x2, res)
     # algorithmic FLOPs of one launch (1 MAC = 2 FLOP); identical for fwd, dgrad and wgrad
     self.flops = 2.0 * N * OH * OW * Cout * (C1 + C2) * KH * KW
@@ -216,7 +219,7 @@ class Conv(Op):
     rt.timed(self._kind(rt.lib, 'fwd'), self.flops, rt.lib.conv2d_fwd_wp_f32,
              rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.w), self.w_layout,
              rt.v(self.bias), temb, self.temb_stride, rt.v(self.res), self.out_div,
-             rt.v(self.y), *self._dims(), self._wp(rt, 0), rt.ws, rt.ws_bytes, rt.stream)
+             rt.v(self.y), *self._dims(), self._wp(rt, 0), rt.v(self.amax), rt.ws, rt.ws_bytes, rt.stream)
 
   def backward(self, rt):
     gy = rt.g(self.y)
@@ -232,17 +235,21 @@ class Conv(Op):
     if dtemb is not None or gb is not None:
       lib.bias_grad_f32(gy, self.N, self.Cout, self.OH * self.OW, alpha, dtemb, self.temb_stride, gb,
                         rt.ws, rt.stream)
-    gw = rt.g(self.w)
-    if gw is not None:
-      rt.timed(self._kind(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_f32,
-               rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, gy, gw, self.w_layout, alpha,
-               rt.ws, rt.ws_bytes, *self._dims(), rt.stream)
+    # data gradient first: its |dy| maxima are reused by the weight gradient (the two are independent otherwise)
+    have = 1 if self._kind(lib, 'fwd').endswith('.x2') else 0
     g1, g2 = rt.g(self.x1), rt.g(self.x2)
     if g1 is not None or g2 is not None:
       rt.timed(self._kind(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_wp_f32,
                gy, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
-               alpha, *self._dims(), self._wp(rt, 1), rt.ws, rt.ws_bytes, rt.stream)
+               alpha, *self._dims(), self._wp(rt, 1), rt.v(self.amax), rt.ws, rt.ws_bytes, rt.stream)
+      if self._kind(lib, 'dgrad').endswith('.x2'):
+        have |= 2
+    gw = rt.g(self.w)
+    if gw is not None:
+      rt.timed(self._kind(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_amax_f32,
+               rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, gy, gw, self.w_layout, alpha,
+               rt.ws, rt.ws_bytes, *self._dims(), rt.v(self.amax), have, rt.stream)
 
   def ws_bytes(self, lib):
     shape = (self.C1, self.C2, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self.stride, self.pad)

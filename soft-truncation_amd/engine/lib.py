@@ -40,10 +40,11 @@ SIGNATURES = {
   'stk_conv2d_wp_bytes': [I, I, I, I, I, I, I, I, I, I, I],
   'stk_conv2d_wp_desc': [I, P, I, I, I, I, I, P, P],
   'stk_conv2d_wprep_batch': [P, I, L, S],
-  'stk_conv2d_fwd_wp_f32': [P, I, P, I, P, I, P, P, I, P, F, P, I, I, I, I, I, I, I, I, I, I, P, P, L, S],
-  'stk_conv2d_dgrad_wp_f32': [P, P, I, P, I, F, P, I, F, F, I, I, I, I, I, I, I, I, I, I, P, P, L, S],
+  'stk_conv2d_fwd_wp_f32': [P, I, P, I, P, I, P, P, I, P, F, P, I, I, I, I, I, I, I, I, I, I, P, P, P, L, S],
+  'stk_conv2d_dgrad_wp_f32': [P, P, I, P, I, F, P, I, F, F, I, I, I, I, I, I, I, I, I, I, P, P, P, L, S],
   'stk_conv2d_wgrad_ws_bytes': [I, I, I, I, I, I, I, I],
   'stk_conv2d_wgrad_f32': [P, I, P, I, P, P, I, F, P, L, I, I, I, I, I, I, I, I, I, I, S],
+  'stk_conv2d_wgrad_amax_f32': [P, I, P, I, P, P, I, F, P, L, I, I, I, I, I, I, I, I, I, I, P, I, S],
   'stk_bias_grad_f32': [P, I, I, I, F, P, I, P, P, S],
   'stk_gemm_f32': [P, L, L, L, P, L, L, L, P, L, L, L, P, I, I, I, I, I, F, F, S],
   'stk_softmax_fwd_f32': [P, P, L, I, F, S],

@@ -399,24 +399,33 @@ def test_conv_prepared_weights(hip_lib, case):
   if descs:
     table = torch.from_numpy(np.frombuffer(b''.join(bytes(x) for x in descs), dtype=np.uint8).copy()).to(d)
     call(lib, 'conv2d_wprep_batch', table, len(descs), items)
+  amax = torch.full((768,), float('nan'), device=d)       # the layer's amax buffer (include/stk.h)
   y_a, y_b = torch.empty(N, Cout, OH, OW, device=d), torch.empty(N, Cout, OH, OW, device=d)
   call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, layout, bias, None, 0, None, 1.0, y_a, *dims, fws, fb)
   dx_a = [torch.zeros(N, C1, H, W, device=d), torch.zeros(N, C2, H, W, device=d) if C2 else None]
   dx_b = [torch.zeros(N, C1, H, W, device=d), torch.zeros(N, C2, H, W, device=d) if C2 else None]
   call(lib, 'conv2d_dgrad_f32', dy, w, layout, dx_a[0], C1, 0.0, dx_a[1], C2, 0.0, 1.0, *dims, fws, fb)
   if blocks[0] is not None:
-    call(lib, 'conv2d_fwd_wp_f32', x1, C1, x2, C2, w, layout, bias, None, 0, None, 1.0, y_b, *dims, blocks[0][1], fws, fb)
+    call(lib, 'conv2d_fwd_wp_f32', x1, C1, x2, C2, w, layout, bias, None, 0, None, 1.0, y_b, *dims, blocks[0][1], amax, fws, fb)
     assert torch.equal(y_a, y_b)
   else:          # a block for a shape that has none is an error, not silently ignored ... unless a streaming kernel took it
     if int(lib.conv2d_variant(0, C1, C2, N, H, W, Cout, OH, OW, K, K, stride, pad, layout)) != 4:
       rc = lib.conv2d_fwd_wp_f32.raw(x1.data_ptr(), C1, x2.data_ptr() if C2 else None, C2, w.data_ptr(), layout, None, None,
-                                     0, None, 1.0, y_b.data_ptr(), *dims, fws.data_ptr(), fws.data_ptr(), fb, None)
+                                     0, None, 1.0, y_b.data_ptr(), *dims, fws.data_ptr(), None, fws.data_ptr(), fb, None)
       assert rc != 0
   if blocks[1] is not None:
-    call(lib, 'conv2d_dgrad_wp_f32', dy, w, layout, dx_b[0], C1, 0.0, dx_b[1], C2, 0.0, 1.0, *dims, blocks[1][1], fws, fb)
+    call(lib, 'conv2d_dgrad_wp_f32', dy, w, layout, dx_b[0], C1, 0.0, dx_b[1], C2, 0.0, 1.0, *dims, blocks[1][1], amax, fws, fb)
     assert torch.equal(dx_a[0], dx_b[0])
     if C2:
       assert torch.equal(dx_a[1], dx_b[1])
+  # weight gradient with the maxima its forward / data-gradient calls left behind == with its own passes
+  have = (1 if blocks[0] is not None else 0) | (2 if blocks[1] is not None else 0)
+  nbw = int(lib.conv2d_wgrad_ws_bytes(C1, C2, N, Cout, OH, OW, K, K))
+  wws = torch.full((nbw // 4 + 64,), float('nan'), device=d)
+  dw_a, dw_b = torch.zeros_like(w), torch.zeros_like(w)
+  call(lib, 'conv2d_wgrad_f32', x1, C1, x2, C2, dy, dw_a, layout, 1.0, wws, wws.numel() * 4, *dims)
+  call(lib, 'conv2d_wgrad_amax_f32', x1, C1, x2, C2, dy, dw_b, layout, 1.0, wws, wws.numel() * 4, *dims, amax, have)
+  assert torch.equal(dw_a, dw_b)
   torch.cuda.synchronize()
 
 
