@@ -105,7 +105,8 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
  * power of two (from its |x| maximum, computed inside the call) and every fp32 value split into two fp16 terms;
  * the three significant partial products are accumulated in fp32 and the scales undone exactly (error at the level
  * of fp32 rounding, same as the f32-input MFMA path).  ws holds the prepared weights of this call, the partial
- * maxima and the K-split slabs.  The weight gradient uses a bf16 three-way split of both operands instead.
+ * maxima and the K-split slabs.  The 3x3 weight gradient on maps of >= 8 columns splits both of its operands the
+ * same way; 1x1 layers and 4-wide maps use a bf16 three-way split (six products, no scaling needed).
  * ws = NULL / too small selects the f32-input MFMA path (v_mfma_f32_32x32x2_f32) for every shape.
  * ------------------------------------------------------------------------------------------ */
 long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW,
@@ -127,7 +128,8 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout,
                          float* dx1, int C1, float beta1, float* dx2, int C2, float beta2,
                          float alpha, int N, int H, int W, int Cout, int OH, int OW,
                          int KH, int KW, int stride, int pad, void* ws, long ws_bytes, void* stream);
-/* Prepared weights.  The split kernel reads its weights re-laid out and split into three bf16 planes; the calls above
+/* Prepared weights.  The split kernel reads its weights re-laid out, scaled and split into two fp16 planes (behind a
+ * 256-byte header holding their partial maxima); the calls above
  * prepare them into ws on every call.  A caller whose weights change once per optimizer step (training) or never
  * (a sampling loop: ~2000 network evaluations on fixed weights, sampling.py:365-433) prepares all layers in ONE
  * launch and hands each call its block:
