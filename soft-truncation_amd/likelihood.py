@@ -77,7 +77,8 @@ def get_likelihood_fn(config, sde, inverse_scaler, hutchinson_type='Rademacher',
     return get_div_fn(lambda xx, tt: drift_fn(model, xx, tt))(x, t, noise)
 
   def likelihood_fn(model, data, logdet=0., eps=1e-5, mode='correct'):
-    with torch.no_grad():
+    # hundreds of network evaluations on fixed parameters: prepare the convolution weights once
+    with torch.no_grad(), mutils.frozen_weights(model):
       score_fn = mutils.get_score_fn(config, sde, model, train=False, continuous=True)
       shape = data.shape
       B = shape[0]
