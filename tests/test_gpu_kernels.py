@@ -459,6 +459,48 @@ def test_conv_adjoint_full_size(hip_lib):
   assert abs(a - b) <= tol and abs(a - c) <= tol, (a, b, c, tol)
 
 
+RANGE_CASES = [
+  # N, Cin, Cout, H, activation scale, weight scale, gradient scale, per-image spread (decades)
+  (24, 128, 128, 32, 1.0, 0.03, 1.0e-4, 0.0),
+  (43, 64, 128, 24, 300.0, 2.0e-4, 1.0, 0.0),        # large activations, small weights: the power-of-two scales do the work
+  (32, 128, 128, 16, 1.0e-6, 5.0, 1.0e-9, 0.0),      # tiny magnitudes (fp16 would flush them without the scaling)
+  (32, 128, 128, 16, 1.0, 0.03, 1.0e-3, 6.0),        # images whose magnitudes spread over six decades (loss weights)
+  (24, 96, 160, 16, 2.0e4, 1.0e3, 1.0e5, 0.0),       # products far above fp16's largest value
+]
+
+
+@pytest.mark.parametrize('case', RANGE_CASES, ids=str)
+def test_conv_split_dynamic_range(ref_lib, hip_lib, case):
+  """The fp16 two-way split kernels (conv_x2.h) scale every operand tensor by a power of two taken from its |x| maximum:
+  forward, data gradient and weight gradient must hold the usual 1e-4 of max|result| for magnitudes far outside fp16's
+  range and for batches whose images differ by orders of magnitude."""
+  N, Cin, Cout, H, xs, wsc, gs, spread = case
+  ramp = (10.0 ** (-spread * torch.arange(N).float() / (N - 1))).view(N, 1, 1, 1) if spread else 1.0
+  x = rnd(N, Cin, H, H, seed=1) * xs * ramp
+  w = rnd(Cout, Cin, 3, 3, seed=2) * wsc
+  dy = rnd(N, Cout, H, H, seed=3) * gs * ramp
+  dims = (N, H, H, Cout, H, H, 3, 3, 1, 1)
+  shape = (Cin, 0, N, H, H, Cout, 3, 3, 1, 1)
+
+  def fn(lib, to):
+    fb = max(int(lib.conv2d_fwd_ws_bytes(*shape)), int(lib.conv2d_dgrad_ws_bytes(*shape)))
+    if lib.is_device:
+      assert fb > 0 and int(lib.conv2d_variant(0, Cin, 0, N, H, H, Cout, H, H, 3, 3, 1, 1, 0)) == 5
+    fws = to(torch.full((fb // 4 + 64,), float('nan'))) if fb else None
+    xx, ww, dd = to(x), to(w), to(dy)
+    y = to(torch.full((N, Cout, H, H), float('nan')))
+    call(lib, 'conv2d_fwd_f32', xx, Cin, None, 0, ww, 0, None, None, 0, None, 1.0, y, *dims, fws, fb)
+    dx = to(torch.full((N, Cin, H, H), float('nan')))
+    call(lib, 'conv2d_dgrad_f32', dd, ww, 0, dx, Cin, 0.0, None, 0, 0.0, 1.0, *dims, fws, fb)
+    nb = int(lib.conv2d_wgrad_ws_bytes(Cin, 0, N, Cout, H, H, 3, 3))
+    ws = to(torch.full((max(nb // 4, 64) + 64,), float('nan')))
+    dw = to(torch.zeros(Cout, Cin, 3, 3))
+    call(lib, 'conv2d_wgrad_f32', xx, Cin, None, 0, dd, dw, 0, 1.0, ws, ws.numel() * 4, *dims)
+    return {'y': y, 'dx': dx, 'dw': dw}
+
+  compare(both(ref_lib, hip_lib, fn), 1e-4, 'conv split range')
+
+
 THIN_FULL = [
   # N, Cin, Cout, H, K  -- the thin-side layers at the BASELINE sizes
   (128, 3, 128, 32, 3),      # DDPM++ CIFAR-10 stem
