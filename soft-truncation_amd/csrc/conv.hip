@@ -959,10 +959,10 @@ inline X3WgradPlan x3_wgrad_plan(int C1, int C2, int N, int Cout, int H, int W, 
   q.rows3 = (taps == 9 && W >= 8 && (C2 == 0 || C1 % 16 == 0)) ? 1 : 0;
   const long tiles = q.rows3 ? 3L * stk_cdiv(Cout, 128) * stk_cdiv(Cin, 64)
                              : (long)taps * stk_cdiv(Cout, 128) * stk_cdiv(Cin, 128);
-  // a 1x1 layer with few tiles needs so many K splits that writing / re-reading the partial slabs eats the gain:
-  // 4 tiles (256->256, the attention NIN layers) pay with one wave of 256 workgroups (54 us against 74 us for the
-  // f32-input kernel, 65 us with 512 workgroups); 2 tiles (128->256) do not
-  if (taps == 1 && tiles < 4) return q;
+  // a 1x1 layer with few tiles needs many K splits: with ONE wave of 256 workgroups the slab traffic still pays
+  // (256->256 NIN, 4 tiles: 54 us against 74 us for the f32-input kernel; 384->128 at 32x32, 3 tiles: 110 against
+  // 255; 128->256 at 16x16, 2 tiles: 32 against 41); with 512 workgroups it did not
+  if (taps == 1 && tiles < 2) return q;
   const long chunks = K / 32;
   long splits = (taps == 1 && tiles < 6 ? 256 : 512) / tiles;
   if (splits > chunks / 8) splits = chunks / 8;

@@ -59,7 +59,7 @@ def main():
     # C1, C2, H, Cout, K
     (128, 0, 32, 128, 3), (256, 0, 16, 256, 3), (256, 0, 8, 256, 3), (256, 0, 4, 256, 3),
     (128, 0, 16, 256, 3), (384, 0, 32, 128, 3), (512, 0, 16, 256, 3), (512, 0, 8, 256, 3),
-    (256, 256, 16, 256, 1), (256, 0, 16, 256, 1), (128, 0, 16, 256, 1),
+    (256, 256, 16, 256, 1), (256, 0, 16, 256, 1), (128, 0, 16, 256, 1), (256, 128, 32, 128, 1),
   ]
   if 'hq' in args.only:        # the 256x256 network's layers (use with --batch 4)
     conv_shapes = [(128, 0, 256, 128, 3), (128, 0, 128, 128, 3), (128, 0, 64, 256, 3), (256, 0, 64, 256, 3),
