@@ -88,8 +88,11 @@ WORKLOADS = {
 def parse():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=20)
-  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--steps', type=int, default=50)      # >= 50 timed steps after >= 10 warm-ups
+  ap.add_argument('--warmup', type=int, default=10)
+  ap.add_argument('--launch-check', action='store_true',
+                  help='only bring up the N-rank process group (RCCL on GPUs, gloo without), count the ranks with one '
+                       'all-reduce and print {"launch_check": true, "n_gpus": N}: tests the --gpus launcher without a GPU')
   ap.add_argument('--workload', default='cifar10', choices=sorted(WORKLOADS))
   ap.add_argument('--batch', type=int, default=0, help='per-GPU batch override')
   ap.add_argument('--fir', action='store_true', help='same net with model.fir=True (FIR resampling through upfirdn2d); SURVEY 8(d)')
@@ -181,14 +184,61 @@ def arithmetic_check(device):
   return out
 
 
+def free_port():
+  import socket
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def relaunch(args):
+  """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves -- the same command the driver
+  uses (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1) -- and pass their output through."""
+  import subprocess
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL across processes needs it on this driver
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+         '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd, env=env)
+
+
+def launch_check(world, rank, local_rank):
+  """The multi-process plumbing alone: process group up, every rank counted, rank 0 prints one JSON line."""
+  on_gpu = torch.cuda.is_available()
+  if on_gpu:
+    torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank) if on_gpu else torch.device('cpu')
+  n = 1
+  backend = 'none'
+  if world > 1:
+    backend = 'nccl' if on_gpu else 'gloo'
+    dist.init_process_group(backend, **({'device_id': device} if on_gpu else {}))
+    t = torch.ones(1, device=device)
+    dist.all_reduce(t)
+    n = int(t.item())
+    dist.barrier()
+  if rank == 0:
+    print(json.dumps({'launch_check': True, 'n_gpus': world, 'ranks_counted': n, 'backend': backend}), flush=True)
+  if world > 1:
+    dist.destroy_process_group()
+
+
 def main():
   args = parse()
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    sys.exit(relaunch(args))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  if args.gpus != world and rank == 0:
+    print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}', file=sys.stderr)
+  if args.launch_check:
+    return launch_check(world, rank, local_rank)
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
   if world > 1:

@@ -50,6 +50,7 @@ def device_batch(config, images_u8, seed, evaluation=False, backend=None):
   out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
   flip = int(bool(d.random_flip) and not evaluation)
   dequant = int(getattr(d, 'dequantization', 'none') == 'uniform')
-  lib.preprocess_u8(x.data_ptr(), out.data_ptr(), N, C, H, W, flip, dequant, int(bool(d.centered)),
-                    int(seed) & 0xFFFFFFFFFFFFFFFF, stk_lib.stream_ptr(x.device))
+  with stk_lib.device_guard(x.device):
+    lib.preprocess_u8(x.data_ptr(), out.data_ptr(), N, C, H, W, flip, dequant, int(bool(d.centered)),
+                      int(seed) & 0xFFFFFFFFFFFFFFFF, stk_lib.stream_ptr(x.device))
   return out

@@ -139,6 +139,34 @@ def load():
   return load_path(PRODUCT_LIB)
 
 
+class _NoGuard:
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device):
+  """Context that makes `device` the current HIP device for the raw C-ABI launches inside it.
+
+  The kernels are launched through ctypes on torch's current stream of `device`; that handle is 0 (the NULL stream)
+  unless a side stream is active, and the NULL stream belongs to whichever device is CURRENT -- so a model on
+  cuda:1 in a process whose current device is cuda:0 would launch on the wrong GPU with another GPU's pointers.
+  Every launch site of the package runs under this guard (no-op for host / oracle backends and when `device`
+  already is current)."""
+  import torch
+  if device.type != 'cuda':
+    return _NO_GUARD
+  idx = device.index if device.index is not None else torch.cuda.current_device()
+  if idx == torch.cuda.current_device():
+    return _NO_GUARD
+  return torch.cuda.device(idx)
+
+
 def stream_ptr(device):
   """Raw hipStream_t of torch's current stream on `device` (0 for host / oracle backends)."""
   import torch

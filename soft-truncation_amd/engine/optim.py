@@ -80,8 +80,9 @@ class FusedAdam(torch.optim.Optimizer):
   def clip_grad_norm(self, max_norm):
     """Device-side equivalent of clip_grad_norm_: records sum g^2; the scaling happens in step()."""
     flat = self._bind()
-    self._lib().sumsq_f32(flat.grad.data_ptr(), flat.n_train, self._sumsq.data_ptr(), self._ws.data_ptr(),
-                          stk_lib.stream_ptr(flat.device))
+    with stk_lib.device_guard(flat.device):
+      self._lib().sumsq_f32(flat.grad.data_ptr(), flat.n_train, self._sumsq.data_ptr(), self._ws.data_ptr(),
+                            stk_lib.stream_ptr(flat.device))
     self._pending_clip = float(max_norm)
     return self._sumsq
 
@@ -95,11 +96,12 @@ class FusedAdam(torch.optim.Optimizer):
     bc2 = 1.0 - b2 ** self._step
     clip = self._pending_clip
     self._pending_clip = None
-    self._lib().adam_f32(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
-                         flat.n_train, float(group['lr']), b1, b2, group['eps'], group['weight_decay'],
-                         int(self.adamw), bc1, bc2,
-                         self._sumsq.data_ptr() if clip is not None else None,
-                         clip if clip is not None else -1.0, stk_lib.stream_ptr(flat.device))
+    with stk_lib.device_guard(flat.device):
+      self._lib().adam_f32(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
+                           flat.n_train, float(group['lr']), b1, b2, group['eps'], group['weight_decay'],
+                           int(self.adamw), bc1, bc2,
+                           self._sumsq.data_ptr() if clip is not None else None,
+                           clip if clip is not None else -1.0, stk_lib.stream_ptr(flat.device))
 
   def state_dict(self):
     if self._flat is not None:

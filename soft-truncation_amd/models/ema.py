@@ -47,8 +47,9 @@ class ExponentialMovingAverage:
     with torch.no_grad():
       if self._flat is not None:
         flat = self._flat
-        self._lib().ema_f32(self._shadow.data_ptr(), flat.data.data_ptr(), flat.n_train, one_minus_decay,
-                            stk_lib.stream_ptr(flat.device))
+        with stk_lib.device_guard(flat.device):
+          self._lib().ema_f32(self._shadow.data_ptr(), flat.data.data_ptr(), flat.n_train, one_minus_decay,
+                              stk_lib.stream_ptr(flat.device))
         return
       parameters = [p for p in parameters if p.requires_grad]
       for s_param, param in zip(self.shadow_params, parameters):

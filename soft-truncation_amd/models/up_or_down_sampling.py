@@ -82,8 +82,9 @@ class _NaiveResample(torch.autograd.Function):
     N, C, H, W = x.shape
     ctx.up, ctx.shape = up, (N, C, H, W)
     out = torch.empty((N, C, H * 2, W * 2) if up else (N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
-    lib.resample_naive_f32(x.data_ptr(), out.data_ptr(), N * C, H, W, 0 if up else 1, 1.0, 0.0,
-                           stk_lib.stream_ptr(x.device))
+    with stk_lib.device_guard(x.device):
+      lib.resample_naive_f32(x.data_ptr(), out.data_ptr(), N * C, H, W, 0 if up else 1, 1.0, 0.0,
+                             stk_lib.stream_ptr(x.device))
     return out
 
   @staticmethod
@@ -92,12 +93,13 @@ class _NaiveResample(torch.autograd.Function):
     g = g.contiguous()
     N, C, H, W = ctx.shape
     gx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
-    if ctx.up:
-      lib.resample_naive_f32(g.data_ptr(), gx.data_ptr(), N * C, 2 * H, 2 * W, 1, 4.0, 0.0,
-                             stk_lib.stream_ptr(g.device))
-    else:
-      lib.resample_naive_f32(g.data_ptr(), gx.data_ptr(), N * C, H // 2, W // 2, 0, 0.25, 0.0,
-                             stk_lib.stream_ptr(g.device))
+    with stk_lib.device_guard(g.device):
+      if ctx.up:
+        lib.resample_naive_f32(g.data_ptr(), gx.data_ptr(), N * C, 2 * H, 2 * W, 1, 4.0, 0.0,
+                               stk_lib.stream_ptr(g.device))
+      else:
+        lib.resample_naive_f32(g.data_ptr(), gx.data_ptr(), N * C, H // 2, W // 2, 0, 0.25, 0.0,
+                               stk_lib.stream_ptr(g.device))
     return gx, None
 
 
@@ -109,6 +111,66 @@ def naive_upsample_2d(x, factor=2):
 def naive_downsample_2d(x, factor=2):
   assert factor == 2, 'the kernel implements the factor-2 case used by every config'
   return _NaiveResample.apply(x, False)
+
+
+class _Conv2dNoPad(torch.autograd.Function):
+  """y = conv2d(x, w, stride, padding 0) on the C-ABI convolution kernels (forward, data gradient, weight gradient);
+  the tensor-level counterpart of engine.graph.Conv for callers outside the planned graph."""
+
+  @staticmethod
+  def _dims(x, w, stride):
+    N, C, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    return N, H, W, Cout, (H - KH) // stride + 1, (W - KW) // stride + 1, KH, KW, stride, 0
+
+  @staticmethod
+  def forward(ctx, x, w, stride):
+    lib = _backend.get()
+    _backend.check(x, lib)
+    x, w = x.contiguous(), w.contiguous()
+    dims = _Conv2dNoPad._dims(x, w, stride)
+    y = torch.empty((dims[0], dims[3], dims[4], dims[5]), dtype=x.dtype, device=x.device)
+    with stk_lib.device_guard(x.device):
+      lib.conv2d_fwd_f32(x.data_ptr(), x.shape[1], None, 0, w.data_ptr(), 0, None, None, 0, None, 1.0, y.data_ptr(),
+                         *dims, None, 0, stk_lib.stream_ptr(x.device))
+    ctx.save_for_backward(x, w)
+    ctx.stride = stride
+    return y
+
+  @staticmethod
+  @torch.autograd.function.once_differentiable
+  def backward(ctx, gy):
+    lib = _backend.get()
+    x, w = ctx.saved_tensors
+    gy = gy.contiguous()
+    dims = _Conv2dNoPad._dims(x, w, ctx.stride)
+    C = x.shape[1]
+    gx = gw = None
+    with stk_lib.device_guard(x.device):
+      stream = stk_lib.stream_ptr(x.device)
+      if ctx.needs_input_grad[0]:
+        gx = torch.empty_like(x)
+        lib.conv2d_dgrad_f32(gy.data_ptr(), w.data_ptr(), 0, gx.data_ptr(), C, 0.0, None, 0, 0.0, 1.0, *dims,
+                             None, 0, stream)
+      if ctx.needs_input_grad[1]:
+        gw = torch.zeros_like(w)
+        nb = int(lib.conv2d_wgrad_ws_bytes(C, 0, dims[0], dims[3], dims[4], dims[5], dims[6], dims[7]))
+        ws = torch.empty(max(nb // 4, 64), dtype=torch.float32, device=x.device)
+        lib.conv2d_wgrad_f32(x.data_ptr(), C, None, 0, gy.data_ptr(), gw.data_ptr(), 0, 1.0, ws.data_ptr(), nb, *dims,
+                             stream)
+    return gx, gw, None
+
+
+def conv_downsample_2d(x, w, k=None, factor=2, gain=1):
+  """Fused ``downsample_2d`` + ``conv2d`` (models/up_or_down_sampling.py:144-178): FIR pre-filter with padding
+  ((p+1)//2, p//2), p = (len(k) - factor) + (conv_w - 1), then the convolution with stride `factor`, padding 0.
+  x [N, C, H, W], w [Cout, C, kh, kw] (kh == kw)."""
+  assert isinstance(factor, int) and factor >= 1
+  _, _, conv_h, conv_w = w.shape
+  assert conv_w == conv_h
+  taps, pad = _conv_down_taps(k, factor, gain, conv_w)
+  x = upfirdn2d(x, torch.tensor(taps, device=x.device), pad=pad)
+  return _Conv2dNoPad.apply(x, w, factor)
 
 
 def upsample_conv_2d(x, w, k=None, factor=2, gain=1):

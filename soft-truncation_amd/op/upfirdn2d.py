@@ -1,84 +1,80 @@
-"""`op.upfirdn2d` -- FIR up/down-sampling (reference: op/upfirdn2d.py:19-156).
+"""`op.upfirdn2d` -- FIR up/down-sampling (interface of reference op/upfirdn2d.py:145-156, NCHW input,
+`upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0))`).
 
-Same call signature as the reference (`upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0))` on
-an NCHW tensor) and the same autograd structure: the backward of the operator is the operator
-itself with the flipped taps, up and down swapped and the ``g_pad`` paddings
-(op/upfirdn2d.py:111-114), and that backward is itself differentiable (:62-85).
+upfirdn2d is a LINEAR map of its input, and its transpose is again an upfirdn2d: the flipped taps, up and down
+swapped, and the paddings of op/upfirdn2d.py:111-114.  The autograd side is built on exactly that and nothing else:
+one :class:`FirMap` value describes a member of the family (factors, paddings, input and output extent) and knows its
+transpose; one autograd function applies a `FirMap`, and its backward applies the transposed `FirMap` through the
+same function.  Differentiating any number of times therefore needs no further code (the reference spells out a second
+Function for the double backward, :62-85; here `transpose(transpose(m))` is `m` again, up to padding no output reads).
 
-The reference JIT-builds a CUDA extension at import and silently falls back to a PyTorch
-implementation for CPU tensors (:145-156).  Here the work is done by
-``stk_upfirdn2d_f32`` (hand-written HIP for gfx950, csrc/upfirdn2d.hip) on the current HIP
-stream; a tensor that does not live on the GPU is an error, never a fallback.
+The work is done by ``stk_upfirdn2d_f32`` (hand-written HIP for gfx950, csrc/upfirdn2d.hip) on torch's current HIP
+stream.  The reference JIT-builds a CUDA extension at import and silently runs a PyTorch implementation for CPU
+tensors (:145-156); here a tensor that does not live on the GPU is an error, never a fallback.
 """
+import collections
+
 import torch
-from torch.autograd import Function
 
 from ..engine import lib as stk_lib
 from . import _backend
 
 
-def _launch(inp, kernel, out_hw, up, down, pad):
-  """inp: [major, in_h, in_w, 1] contiguous.  Returns [major, out_h, out_w, 1]."""
+class FirMap(collections.namedtuple('FirMap', 'up down pad in_hw out_hw')):
+  """One upfirdn2d operator on planes: per-axis factors ``up = (x, y)``, ``down = (x, y)``, paddings
+  ``pad = (x0, x1, y0, y1)``, and the plane extents it maps between."""
+  __slots__ = ()
+
+  @staticmethod
+  def of(in_hw, taps_hw, up, down, pad):
+    (h, w), (kh, kw) = in_hw, taps_hw
+    out_h = (h * up[1] + pad[2] + pad[3] - kh) // down[1] + 1
+    out_w = (w * up[0] + pad[0] + pad[1] - kw) // down[0] + 1
+    return FirMap(tuple(up), tuple(down), tuple(pad), (h, w), (out_h, out_w))
+
+  def transpose(self, taps_hw):
+    """The adjoint operator (applied with the flipped taps): out-extent planes -> in-extent planes."""
+    (h, w), (oh, ow), (kh, kw) = self.in_hw, self.out_hw, taps_hw
+    (ux, uy), (dx, dy), (px0, _, py0, _) = self.up, self.down, self.pad
+    pad_t = (kw - px0 - 1, w * ux - ow * dx + px0 - ux + 1,
+             kh - py0 - 1, h * uy - oh * dy + py0 - uy + 1)
+    return FirMap(self.down, self.up, pad_t, self.out_hw, self.in_hw)
+
+
+def _run(planes, taps, m):
+  """planes [P, h, w] contiguous float32 on the device -> [P, oh, ow]."""
   lib = _backend.get()
-  _backend.check(inp, lib)
-  inp = inp.contiguous()
-  kernel = kernel.contiguous().to(device=inp.device, dtype=torch.float32)
-  major, in_h, in_w, minor = inp.shape
-  out = torch.empty((major, out_hw[0], out_hw[1], minor), dtype=inp.dtype, device=inp.device)
-  lib.upfirdn2d_f32(inp.data_ptr(), kernel.data_ptr(), out.data_ptr(), major, in_h, in_w, minor,
-                    kernel.shape[0], kernel.shape[1], up[0], up[1], down[0], down[1],
-                    pad[0], pad[1], pad[2], pad[3], stk_lib.stream_ptr(inp.device))
+  _backend.check(planes, lib)
+  out = torch.empty((planes.shape[0],) + m.out_hw, dtype=planes.dtype, device=planes.device)
+  with stk_lib.device_guard(planes.device):
+    lib.upfirdn2d_f32(planes.data_ptr(), taps.data_ptr(), out.data_ptr(), planes.shape[0], m.in_hw[0], m.in_hw[1], 1,
+                      taps.shape[0], taps.shape[1], m.up[0], m.up[1], m.down[0], m.down[1],
+                      m.pad[0], m.pad[1], m.pad[2], m.pad[3], stk_lib.stream_ptr(planes.device))
   return out
 
 
-class UpFirDn2dBackward(Function):
-  @staticmethod
-  def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
-    grad_output = grad_output.reshape(-1, out_size[0], out_size[1], 1)
-    grad_input = _launch(grad_output, grad_kernel, (in_size[2], in_size[3]), down, up, g_pad)
-    grad_input = grad_input.view(in_size[0], in_size[1], in_size[2], in_size[3])
-    ctx.save_for_backward(kernel)
-    ctx.up, ctx.down, ctx.pad = up, down, pad
-    ctx.in_size, ctx.out_size = in_size, out_size
-    return grad_input
+class _ApplyFir(torch.autograd.Function):
+  """y = M x for a FirMap M; dL/dx = M^T dL/dy, computed by this same function."""
 
   @staticmethod
-  def backward(ctx, gradgrad_input):
-    kernel, = ctx.saved_tensors
-    gradgrad_input = gradgrad_input.reshape(-1, ctx.in_size[2], ctx.in_size[3], 1)
-    gradgrad_out = _launch(gradgrad_input, kernel, ctx.out_size, ctx.up, ctx.down, ctx.pad)
-    gradgrad_out = gradgrad_out.view(ctx.in_size[0], ctx.in_size[1], ctx.out_size[0], ctx.out_size[1])
-    return gradgrad_out, None, None, None, None, None, None, None, None
-
-
-class UpFirDn2d(Function):
-  @staticmethod
-  def forward(ctx, input, kernel, up, down, pad):
-    up_x, up_y = up
-    down_x, down_y = down
-    pad_x0, pad_x1, pad_y0, pad_y1 = pad
-    kernel_h, kernel_w = kernel.shape
-    batch, channel, in_h, in_w = input.shape
-    ctx.in_size = input.shape
-    out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h) // down_y + 1
-    out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w) // down_x + 1
-    ctx.out_size = (out_h, out_w)
-    ctx.up, ctx.down, ctx.pad = (up_x, up_y), (down_x, down_y), (pad_x0, pad_x1, pad_y0, pad_y1)
-    ctx.g_pad = (kernel_w - pad_x0 - 1,
-                 in_w * up_x - out_w * down_x + pad_x0 - up_x + 1,
-                 kernel_h - pad_y0 - 1,
-                 in_h * up_y - out_h * down_y + pad_y0 - up_y + 1)
-    ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
-    out = _launch(input.reshape(-1, in_h, in_w, 1), kernel, ctx.out_size, ctx.up, ctx.down, ctx.pad)
-    return out.view(-1, channel, out_h, out_w)
+  def forward(ctx, x, taps, m):
+    lead = x.shape[:-2]
+    assert tuple(x.shape[-2:]) == m.in_hw, (x.shape, m)
+    ctx.m = m
+    ctx.save_for_backward(taps)
+    y = _run(x.reshape((-1,) + m.in_hw).contiguous(), taps, m)
+    return y.view(lead + m.out_hw)
 
   @staticmethod
-  def backward(ctx, grad_output):
-    kernel, grad_kernel = ctx.saved_tensors
-    grad_input = UpFirDn2dBackward.apply(grad_output, kernel, grad_kernel, ctx.up, ctx.down, ctx.pad,
-                                         ctx.g_pad, ctx.in_size, ctx.out_size)
-    return grad_input, None, None, None, None
+  def backward(ctx, gy):
+    taps, = ctx.saved_tensors
+    mt = ctx.m.transpose(tuple(taps.shape))
+    return _ApplyFir.apply(gy, torch.flip(taps, (0, 1)).contiguous(), mt), None, None
 
 
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
-  return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+  """[B, C, H, W] -> [B, C, H', W']: zero-insert by `up`, pad by `pad = (before, after)` on both axes (negative =
+  crop), correlate with the flipped `kernel`, keep every `down`-th sample (reference op/upfirdn2d.py:159-200)."""
+  taps = kernel.detach().to(device=input.device, dtype=torch.float32).contiguous()
+  m = FirMap.of(tuple(input.shape[-2:]), tuple(taps.shape), (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+  return _ApplyFir.apply(input, taps, m)

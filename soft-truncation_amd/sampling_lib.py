@@ -36,7 +36,8 @@ def samples_to_uint8(samples, backend=None):
   if lib.is_device != (x.device.type == 'cuda'):
     raise RuntimeError(f'backend {lib.backend} cannot convert samples on {x.device}')
   out = torch.empty((N, H, W, C), dtype=torch.uint8, device=x.device)
-  lib.samples_to_uint8(x.data_ptr(), out.data_ptr(), N, C, H * W, stk_lib.stream_ptr(x.device))
+  with stk_lib.device_guard(x.device):
+    lib.samples_to_uint8(x.data_ptr(), out.data_ptr(), N, C, H * W, stk_lib.stream_ptr(x.device))
   return out.cpu().numpy()
 
 

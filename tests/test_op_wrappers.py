@@ -1,0 +1,44 @@
+"""Host logic of the `op` autograd wrappers and the tensor-level resampling functions on CPU tensors, with the
+oracle's checker library bound in as the backend (the product binds the HIP library and refuses CPU tensors)."""
+import pytest
+import torch
+
+import _op_cases as cases
+
+
+@pytest.fixture()
+def checker_ops(st, ref_lib):
+  from importlib import import_module
+  be = import_module('soft-truncation_amd.op._backend')
+  saved = be._backend
+  be.set_backend(ref_lib)
+  yield torch.device('cpu')
+  be._backend = saved
+
+
+def test_upfirdn2d_forward_backward_double_backward(st, checker_ops):
+  cases.upfirdn2d_autograd(st, checker_ops)
+
+
+def test_upfirdn2d_against_reference_outputs(st, checker_ops):
+  cases.upfirdn2d_golden(st, checker_ops)
+
+
+def test_resampling_wrappers(st, checker_ops):
+  cases.resampling_wrappers_golden(st, checker_ops)
+
+
+def test_fused_leaky_relu_grad_and_gradgrad(st, checker_ops):
+  cases.fused_leaky_relu_autograd(st, checker_ops)
+
+
+def test_firmap_transpose_is_an_involution(st):
+  from importlib import import_module
+  FirMap = import_module('soft-truncation_amd.op.upfirdn2d').FirMap
+  for up, down, pad in cases.TRIPLES:
+    m = FirMap.of((12, 10), (4, 4), (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+    mt = m.transpose((4, 4))
+    mtt = mt.transpose((4, 4))
+    assert mt.in_hw == m.out_hw and mt.out_hw == m.in_hw
+    assert (mtt.up, mtt.down, mtt.in_hw, mtt.out_hw) == (m.up, m.down, m.in_hw, m.out_hw)
+    assert mtt.pad[0] == m.pad[0] and mtt.pad[2] == m.pad[2] and mtt.pad[1] <= m.pad[1] and mtt.pad[3] <= m.pad[3]
