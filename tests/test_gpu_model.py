@@ -59,6 +59,12 @@ def test_golden_likelihood(st, hip_lib, family):
   cases.golden_likelihood_product(st, hip_lib, family)
 
 
+def test_golden_sampler_registry(st, hip_lib):
+  """ancestral_sampling / ald / reverse_diffusion + langevin on VP / euler_maruyama on VE / sub-VP predictor updates
+  on the HIP engine against the reference's outputs (tests/golden/samplers.npz)."""
+  cases.golden_sampler_registry_product(st, hip_lib)
+
+
 def test_forward_backward_wide(st, hip_lib):
   """96 / 192 channels, batch 96: the bf16-split kernels (direct, K-split, few-tile), the 1x1 split layers and the
   prepared-weight path inside the engine, against the oracle RefNet."""

@@ -181,6 +181,24 @@ def test_pc_sampler_matches_reference(st, family):
   assert np.allclose(xs.numpy(), g['pc.samples'], rtol=0, atol=2e-6 * np.abs(g['pc.samples']).max())
 
 
+def test_sampler_registry_matches_reference(st):
+  """ancestral_sampling, ald, reverse_diffusion / langevin on VP, euler_maruyama on VE, and the sub-VP SDE: the host
+  code shared by product and oracle (sampling.py, sde_lib.py) on RefNet against the reference's outputs."""
+  import _model_cases as cases
+
+  def make(family):
+    cfg, sd, ref = _ref_model(st, family, load(f'model_{family}.npz'))
+    return cfg, ref
+
+  cases.golden_sampler_registry(st, make, 5e-6)
+
+
+def test_sampler_registry_on_checker(st, ref_lib):
+  """Same, with the planned-graph engine on the C checker as the network."""
+  import _model_cases as cases
+  cases.golden_sampler_registry_product(st, ref_lib)
+
+
 @pytest.mark.parametrize('family', ['vp', 'rve', 've'])
 def test_engine_on_checker_matches_reference(st, ref_lib, family):
   """Host logic of the product path (graph lowering, flat parameters, backward planning) on the C checker."""

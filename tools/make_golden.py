@@ -224,15 +224,80 @@ def model_fixture(ns, family):
   print(family, 'params', sum(p.numel() for p in model.parameters()), 'keys', len(out))
 
 
+# sampler registry entries beyond each config's default pair (sampling.py:185-329): (family, sde override, predictor,
+# corrector).  The reference's Langevin / ALD correctors read `sde.alphas`, which its subVPSDE does not define
+# (sampling.py:278-279 vs sde_lib.py:209-246), so sub-VP runs pair with the `none` corrector.
+SAMPLER_CASES = [
+  ('vp', None, 'reverse_diffusion', 'langevin'),
+  ('vp', None, 'ancestral_sampling', 'ald'),
+  ('vp', None, 'euler_maruyama', 'langevin'),
+  ('ve', None, 'ancestral_sampling', 'ald'),
+  ('ve', None, 'euler_maruyama', 'none'),
+]
+# The reference's subVPSDE has no `eps` attribute (sde_lib.py:209-246), so its PC loop raises at the denoising step
+# (sampling.py:406); what works there are single predictor updates on it:
+SUBVP_PREDICTORS = ['euler_maruyama', 'reverse_diffusion']
+
+
+def samplers_fixture(ns):
+  """Three PC iterations + the denoising step for every SAMPLER_CASES entry on the fixture model of
+  model_{family}.npz (same weights: build_model is deterministic), noise injected; plus the sub-VP SDE's own
+  functions (sde_lib.py:209-246), which no config instantiates."""
+  out = {}
+  for family, sde_name, pred, corr in SAMPLER_CASES:
+    cfg, sde, model, _ = build_model(ns, family)
+    if sde_name is not None:
+      cfg.training.sde = sde_name
+      sde = ns.sde_lib.get_sde(cfg, None)
+    model.eval()
+    cfg.sampling.method, cfg.sampling.predictor, cfg.sampling.corrector = 'pc', pred, corr
+    sde.N = 3
+    H = cfg.data.image_size
+    inv = (lambda v: (v + 1.) / 2.) if cfg.data.centered else (lambda v: v)
+    fn = ns.sampling.get_sampling_fn(cfg, sde, (2, 3, H, H), inv, 1e-3)
+    with patched_rng(13):
+      xs, nfe = fn(model)
+    key = f'{family}.{sde_name or "default"}.{pred}.{corr}'
+    out[key + '.samples'], out[key + '.nfe'] = npy(xs), np.asarray(nfe)
+    print('sampler', key, 'nfe', nfe, 'max|x|', float(xs.abs().max()))
+  cfg, _, model, g = build_model(ns, 'vp')
+  cfg.training.sde = 'subvpsde'
+  sde = ns.sde_lib.get_sde(cfg, None)
+  model.eval()
+  H = cfg.data.image_size
+  xs = torch.randn(2, 3, H, H, generator=g)
+  ts = torch.tensor([0.8, 0.3])
+  out['subvp.pred.x'], out['subvp.pred.t'] = npy(xs), npy(ts)
+  for pred in SUBVP_PREDICTORS:
+    with patched_rng(17), torch.no_grad():
+      xn, xm = ns.sampling.shared_predictor_update_fn(xs, ts, sde, model, ns.sampling.get_predictor(pred), False, True, cfg)
+    out[f'subvp.pred.{pred}.x'], out[f'subvp.pred.{pred}.x_mean'] = npy(xn), npy(xm)
+  with torch.no_grad():
+    out['subvp.score'] = npy(ns.mutils.get_score_fn(cfg, sde, model, train=False, continuous=True)(xs, ts))
+  g = torch.Generator().manual_seed(0)
+  x = torch.randn(3, 3, 4, 4, generator=g)
+  t = torch.tensor([1e-5, 0.37, 1.0])
+  mean, std = sde.marginal_prob(x, t)
+  drift, diff = sde.sde(x, t)
+  f, G = sde.discretize(x, t)
+  out.update({'subvp.x': npy(x), 'subvp.t': npy(t), 'subvp.mean': npy(mean), 'subvp.std': npy(std),
+              'subvp.drift': npy(drift), 'subvp.diffusion': npy(diff), 'subvp.prior_logp': npy(sde.prior_logp(x)),
+              'subvp.disc_f': npy(f), 'subvp.disc_G': npy(G)})
+  np.savez_compressed(os.path.join(OUT, 'samplers.npz'), **out)
+
+
 def main():
   os.makedirs(OUT, exist_ok=True)
   ns = refimport.load()
+  if len(sys.argv) > 1 and sys.argv[1] == 'samplers':
+    return samplers_fixture(ns)
   sde_fixture(ns)
   op_fixture(ns)
   for fam in FAMILIES:
     model_fixture(ns, fam)
   for fam in ('vp', 've'):
     likelihood_fixture(ns, fam)
+  samplers_fixture(ns)
   for f in sorted(os.listdir(OUT)):
     print(f, os.path.getsize(os.path.join(OUT, f)))
 
