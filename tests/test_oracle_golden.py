@@ -190,7 +190,7 @@ def test_sampler_registry_matches_reference(st):
     cfg, sd, ref = _ref_model(st, family, load(f'model_{family}.npz'))
     return cfg, ref
 
-  cases.golden_sampler_registry(st, make, 5e-6)
+  cases.golden_sampler_registry(st, make, 5e-6, bit_exact_sde=True)
 
 
 def test_sampler_registry_on_checker(st, ref_lib):
