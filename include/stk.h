@@ -176,6 +176,37 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
                          float* dw, int w_layout, float alpha, float* ws, long ws_bytes,
                          int N, int H, int W, int Cout, int OH, int OW,
                          int KH, int KW, int stride, int pad, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Planes: an activation tensor pre-split for the fp16 two-way-split kernels (csrc/conv_pl.h).
+ *   planes(N, C, HW) = P[split][n][c / 32][pixel][c % 32] IEEE binary16 of  s * x[n, c, pixel],
+ *   split 0 = round-to-nearest(s x), split 1 = round-to-nearest(s x - split 0); C padded to a multiple of 32 with
+ *   zeros; s = the power of two that puts max(amax[0..namax)) into [2^13, 2^14) (1 if that maximum is 0).
+ * `amax` is the tensor's scale record: non-negative floats whose maximum bounds |x| -- the 256 partial maxima of
+ * stk_amax_partial_f32, or an a-priori bound in amax[0] with zeros behind it.  Consumers read a record of 256.
+ *   stk_planes_bytes          bytes of both planes
+ *   stk_amax_partial_f32      part[0..256) = partial maxima of |x| (any partition)
+ *   stk_split_planes_f32      fp32 NCHW -> planes
+ *   stk_conv2d_pl_ok          1 if stk_conv2d_{fwd (dir 0), dgrad (dir 1)}_pl_f32 take this shape (3x3 pad 1 or 1x1,
+ *                             stride 1, single-source operand in whole 32-channel blocks, split-kernel geometry)
+ *   stk_conv2d_fwd_pl_f32     stk_conv2d_fwd_wp_f32 with x given as planes (+ its scale record); OH = H, OW = W,
+ *                             stride 1, pad = KH / 2; wp may be NULL (weights are then prepared into ws)
+ *   stk_conv2d_dgrad_pl_f32   stk_conv2d_dgrad_wp_f32 with dy given as planes
+ * Results equal the fp32-input calls up to the position of the split (errors at the fp32 rounding level).
+ * ------------------------------------------------------------------------------------------ */
+/* Scale record of a GroupNorm (+SiLU) (+dropout) output from its parameters alone: rec[0] = (max|gamma| sqrt(L - 1) +
+ * max|beta|) / (1 - drop_p) >= |y| for ANY input (L = (C / G) HW elements per group), rec[1..255] = 0. */
+int stk_gn_bound_f32(const float* gamma, const float* beta, int C, int G, int HW, float drop_p, float* rec, void* stream);
+long stk_planes_bytes(int N, int C, int HW);
+int stk_amax_partial_f32(const float* x, long n, float* part, void* stream);
+int stk_split_planes_f32(const float* x, int N, int C, int HW, const float* amax, int namax, void* planes, void* stream);
+int stk_conv2d_pl_ok(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad);
+int stk_conv2d_fwd_pl_f32(const void* xpl, const float* xamax, int C, const float* w, int w_layout, const float* bias,
+                          const float* temb, int temb_stride, const float* res, float out_div, float* y, int N, int H,
+                          int W, int Cout, int KH, int KW, const void* wp, void* ws, long ws_bytes, void* stream);
+int stk_conv2d_dgrad_pl_f32(const void* dypl, const float* dyamax, const float* w, int w_layout, float* dx1, int C1,
+                            float beta1, float* dx2, int C2, float beta2, float alpha, int N, int H, int W, int Cout,
+                            int KH, int KW, const void* wp, void* ws, long ws_bytes, void* stream);
+
 /* dtemb[n*temb_stride + c] = alpha * sum_hw dy[n,c,:]  (written; may be NULL);
  * dbias[c] += alpha * sum_{n,hw} dy[n,c,:]              (accumulated; may be NULL).
  * ws: >= N*C floats of scratch (only used when dtemb is NULL). */

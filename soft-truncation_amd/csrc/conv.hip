@@ -531,6 +531,7 @@ __global__ __launch_bounds__(256) void slab_dgrad_kernel(ConvP p, int splits, in
 #include "conv_x3.h"
 #include "conv_thin.h"
 #include "conv_x2.h"
+#include "conv_pl.h"
 
 // dw (in the weight's own layout) += alpha * sum over splits of slab[tap][co][ci]
 // Threads walk the SLAB order four elements at a time, so the `splits` reads per element are 16-byte and coalesced
@@ -850,9 +851,11 @@ inline void x3_weight_strides(const ConvP& p, int dgrad, long& sm, long& sk) {
 // wp_ready: weights already prepared by stk_conv2d_wprep_batch (then ws only holds the K-split slabs)
 template <class EP>
 int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2, int S2, int M, long Ng, int dgrad,
-              void* ws, hipStream_t s, const void* wp_ready = nullptr, float* amax = nullptr) {
+              void* ws, hipStream_t s, const void* wp_ready = nullptr, float* amax = nullptr,
+              const void* planes = nullptr, const float* planes_amax = nullptr) {
   x3::Src q;
   q.s1 = s1; q.s2 = S2 > 0 ? s2 : s1; q.S1 = S1; q.S2 = S2; q.Kc = S1 + S2; q.Mpad = x3::pad128(M); q.taps = p.taps;
+  q.pl = static_cast<const unsigned char*>(planes); q.pl_stride = planes ? pl::plane_bytes(p.N, S1, p.HW) : 0;
   unsigned short* wp = reinterpret_cast<unsigned short*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   float* xpart = reinterpret_cast<float*>(((uintptr_t)wp + x3::wp_bytes(M, q.Kc, p.taps) + 255) & ~(uintptr_t)255);
   p.part = reinterpret_cast<float*>(((uintptr_t)(xpart + 2 * x2::NPART) + 255) & ~(uintptr_t)255);
@@ -862,11 +865,15 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
     // with a caller-owned amax buffer (768 floats: |x1|, |x2|, |dy| partials) the maxima stay available to the layer's
     // weight gradient, which would otherwise repeat these passes
     if (amax) xpart = amax + (dgrad ? 2 * x2::NPART : 0);
-    hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s1, (long)p.N * S1 * p.HW, xpart);
-    if (S2 > 0)
-      hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s2, (long)p.N * S2 * p.HW,
-                         xpart + x2::NPART);
-    STK_CHECK_LAUNCH();
+    if (planes) {
+      xpart = const_cast<float*>(planes_amax);      // the scale record the planes were written with
+    } else {
+      hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s1, (long)p.N * S1 * p.HW, xpart);
+      if (S2 > 0)
+        hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s2, (long)p.N * S2 * p.HW,
+                           xpart + x2::NPART);
+      STK_CHECK_LAUNCH();
+    }
     const int nx = S2 > 0 ? 2 * x2::NPART : x2::NPART;
     if (wp_ready) {
       q.wp = static_cast<const unsigned short*>(wp_ready);
@@ -885,8 +892,33 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
 #define STK_X2_LAUNCH(E, DUAL, TAPS)                                                                              \
   hipLaunchKernelGGL((x2::gemm_kernel<x2::ActLoader<DUAL, TAPS>, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, \
                      nch, r.chunks_per_split, xpart, nx)
+#define STK_PL_ABL(A)                                                                                             \
+  hipLaunchKernelGGL((pl::gemm_db_kernel<pl::PlaneLoader<9>, EpFwd, A>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, \
+                     nch, r.chunks_per_split, xpart, nx)
+    if (planes && pl::kernel_choice() >= 16 && p.taps == 9 && !dgrad && r.splits == 1) {      // ablation builds (benchmarks)
+      switch (pl::kernel_choice() >> 4) {
+        case 1: STK_PL_ABL(1); break;
+        case 2: STK_PL_ABL(2); break;
+        case 3: STK_PL_ABL(3); break;
+        case 4: STK_PL_ABL(4); break;
+        case 5: STK_PL_ABL(5); break;
+        case 7: STK_PL_ABL(7); break;
+        default: return STK_EINVAL;
+      }
+      STK_CHECK_LAUNCH();
+      return STK_OK;
+    }
+#undef STK_PL_ABL
+#define STK_PL_LAUNCH(E, TAPS)                                                                                    \
+  if (pl::kernel_choice() == 1)                                                                                   \
+    hipLaunchKernelGGL((pl::gemm_db_kernel<pl::PlaneLoader<TAPS>, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, \
+                       nch, r.chunks_per_split, xpart, nx);                                                       \
+  else                                                                                                            \
+    hipLaunchKernelGGL((x2::gemm_kernel<pl::PlaneLoader<TAPS>, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, \
+                       r.chunks_per_split, xpart, nx)
 #define STK_X2_LAUNCH_E(E)                                                                                        \
-  if (p.taps == 9) { if (S2 > 0) STK_X2_LAUNCH(E, true, 9); else STK_X2_LAUNCH(E, false, 9); }                    \
+  if (planes) { if (p.taps == 9) { STK_PL_LAUNCH(E, 9); } else { STK_PL_LAUNCH(E, 1); } }                         \
+  else if (p.taps == 9) { if (S2 > 0) STK_X2_LAUNCH(E, true, 9); else STK_X2_LAUNCH(E, false, 9); }               \
   else { if (S2 > 0) STK_X2_LAUNCH(E, true, 1); else STK_X2_LAUNCH(E, false, 1); }
     if (r.splits == 1) {
       STK_X2_LAUNCH_E(EP)
@@ -900,9 +932,11 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
     else hipLaunchKernelGGL(slab_fwd_kernel, rgrid, dim3(256), 0, s, p, r.splits, M, (int)Ng);
 #undef STK_X2_LAUNCH_E
 #undef STK_X2_LAUNCH
+#undef STK_PL_LAUNCH
     STK_CHECK_LAUNCH();
     return STK_OK;
   }
+  if (planes) return STK_EUNSUPPORTED;
   if (wp_ready) {
     q.wp = static_cast<const unsigned short*>(wp_ready);
   } else {
@@ -1141,6 +1175,79 @@ int stk_conv2d_dgrad_f32(const float* dy, const float* w, int w_layout, float* d
                          int KW, int stride, int pad, void* ws, long ws_bytes, void* stream) {
   return stk_conv2d_dgrad_wp_f32(dy, w, w_layout, dx1, C1, beta1, dx2, C2, beta2, alpha, N, H, W, Cout, OH, OW, KH, KW, stride,
                                  pad, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+/* ---- planes (conv_pl.h): activations pre-split into two fp16 planes, [split][n][c / 32][pixel][c % 32] ---- */
+long stk_planes_bytes(int N, int C, int HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  return 2 * pl::plane_bytes(N, C, HW);
+}
+
+int stk_amax_partial_f32(const float* x, long n, float* part, void* stream) {
+  if (!x || !part || n <= 0) return STK_EINVAL;
+  hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, (hipStream_t)stream, x, n, part);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+
+int stk_split_planes_f32(const float* x, int N, int C, int HW, const float* amax, int namax, void* planes, void* stream) {
+  if (!x || !amax || !planes || N <= 0 || C <= 0 || HW <= 0 || namax <= 0) return STK_EINVAL;
+  if (2 * pl::plane_bytes(N, C, HW) >= 0x7fffffffL) return STK_EUNSUPPORTED;      // 32-bit buffer offsets in the consumers
+  const long blocks = (long)N * ((C + 31) / 32) * stk_cdiv(HW, pl::SP_PIX);
+  hipLaunchKernelGGL(pl::split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, N, C, HW, amax,
+                     namax, static_cast<unsigned char*>(planes), pl::plane_bytes(N, C, HW));
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+
+/* 1 when the forward (dir 0) / data-gradient (dir 1) call of this shape can read its activation operand (x resp. dy) as
+ * planes: exactly the shapes that take the fp16 split kernel with a single-source operand. */
+int stk_conv2d_pl_ok(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
+  ConvP p = {};
+  if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, stride, pad)) return 0;
+  if (!SPLIT_FWD_DGRAD_X2 || stride != 1 || pad != KH / 2) return 0;
+  const long Ng = (long)N * p.HW;
+  if (dir == 0) {
+    if (C2 > 0 || p.Cin <= 4 || Cout <= 4) return 0;        // two sources / thin-side streaming kernels
+    return x3_plan(p, p.Cin, C1, 0, Cout, Ng).ok;
+  }
+  if (dir == 1) {
+    if (Cout <= 4 || p.Cin <= 4) return 0;
+    return x3_plan(p, Cout, Cout, 0, p.Cin, Ng).ok;
+  }
+  return 0;
+}
+
+int stk_conv2d_fwd_pl_f32(const void* xpl, const float* xamax, int C, const float* w, int w_layout, const float* bias,
+                          const float* temb, int temb_stride, const float* res, float out_div, float* y, int N, int H,
+                          int W, int Cout, int KH, int KW, const void* wp, void* ws, long ws_bytes, void* stream) {
+  if (!xpl || !xamax || !w || !y || out_div == 0.f || (w_layout != 0 && w_layout != 1) || (w_layout == 1 && KH != 1))
+    return STK_EINVAL;
+  if (!stk_conv2d_pl_ok(0, C, 0, N, H, W, Cout, KH, KW, 1, KH / 2)) return STK_EUNSUPPORTED;
+  ConvP p = {};
+  fill_common(p, N, H, W, C, 0, Cout, H, W, KH, KW, 1, KH / 2);
+  p.w = w; p.w_layout = w_layout; p.bias = bias; p.temb = temb; p.temb_stride = temb_stride; p.res = res;
+  p.inv_div = 1.f / out_div; p.use_div = out_div != 1.f; p.y = y;
+  const long Ng = (long)N * p.HW;
+  const X3Plan xr = x3_plan(p, C, C, 0, Cout, Ng);
+  if (!ws || ws_bytes < x3_ws_bytes(xr, Cout, C, p.taps)) return STK_EINVAL;
+  return launch_x3<EpFwd>(p, xr, nullptr, C, nullptr, 0, Cout, Ng, 0, ws, (hipStream_t)stream, wp, nullptr, xpl, xamax);
+}
+
+int stk_conv2d_dgrad_pl_f32(const void* dypl, const float* dyamax, const float* w, int w_layout, float* dx1, int C1,
+                            float beta1, float* dx2, int C2, float beta2, float alpha, int N, int H, int W, int Cout,
+                            int KH, int KW, const void* wp, void* ws, long ws_bytes, void* stream) {
+  if (!dypl || !dyamax || !w || (!dx1 && !dx2) || (w_layout != 0 && w_layout != 1) || (w_layout == 1 && KH != 1))
+    return STK_EINVAL;
+  if (!stk_conv2d_pl_ok(1, C1, C2, N, H, W, Cout, KH, KW, 1, KH / 2)) return STK_EUNSUPPORTED;
+  ConvP p = {};
+  fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, 1, KH / 2);
+  p.w = w; p.w_layout = w_layout; p.dx1 = dx1; p.dx2 = C2 > 0 ? dx2 : nullptr;
+  p.beta1 = beta1; p.beta2 = beta2; p.alpha = alpha;
+  const long Ng = (long)N * p.HW;
+  const X3Plan xr = x3_plan(p, Cout, Cout, 0, p.Cin, Ng);
+  if (!ws || ws_bytes < x3_ws_bytes(xr, p.Cin, Cout, p.taps)) return STK_EINVAL;
+  return launch_x3<EpDgrad>(p, xr, nullptr, Cout, nullptr, 0, p.Cin, Ng, 1, ws, (hipStream_t)stream, wp, nullptr, dypl, dyamax);
 }
 
 /* which kernel family a call with full scratch takes: 0/1 = f32-input MFMA with 64/128 tiles, 2 = bf16 three-way

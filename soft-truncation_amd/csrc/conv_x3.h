@@ -47,6 +47,7 @@ struct Src {             // the activation operand: channel-concat of two NCHW t
   const float* s1; const float* s2; int S1, S2;
   const unsigned short* wp; int Mpad; int Kc;     // prepared weights, padded row count, channels (= S1 + S2)
   int taps;                                       // 9 (3x3, pad 1) or 1 (1x1)
+  const unsigned char* pl; long pl_stride;        // pre-split activation planes (conv_pl.h) and bytes per plane, or null
 };
 
 __device__ __forceinline__ float hi_part(float v) { return __uint_as_float(__float_as_uint(v) & 0xffff0000u); }

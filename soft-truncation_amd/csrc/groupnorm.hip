@@ -581,7 +581,39 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restr
 
 }  // namespace
 
+// A-priori bound of |GroupNorm(+SiLU)(+dropout) output| from the affine parameters alone, written as a planes scale
+// record (include/stk.h "Planes"): rec[0] = bound, rec[1..255] = 0.  A group of L elements has |xhat| <= sqrt(L - 1)
+// whatever the data, |silu(u)| <= |u|, dropout multiplies by 1 / (1 - p):
+//     |y| <= (max|gamma| sqrt(L - 1) + max|beta|) / (1 - p).
+// The consumer convolution scales its split by this bound instead of a measured maximum, which removes the |x| pass over
+// every GroupNorm output; the bound is loose (sqrt(L - 1) = 64 for a 4 x 32 x 32 group against a typical |xhat| <= 5),
+// which costs the split's second term a few of its 11 spare bits and nothing else (tests/test_planes.py).
+__global__ __launch_bounds__(256) void gn_bound_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                                                       float sqrt_lm1, float keep_scale, float* __restrict__ rec) {
+  __shared__ float red[8];
+  float g = 0.f, b = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    g = fmaxf(g, fabsf(gamma[c]));
+    b = fmaxf(b, fabsf(beta[c]));
+  }
+  g = wave_max(g); b = wave_max(b);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = g; red[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  g = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  b = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+  rec[threadIdx.x] = threadIdx.x == 0 ? __fmaf_rn(g, sqrt_lm1, b) * keep_scale : 0.f;
+}
+
 extern "C" {
+
+int stk_gn_bound_f32(const float* gamma, const float* beta, int C, int G, int HW, float drop_p, float* rec, void* stream) {
+  if (!gamma || !beta || !rec || C <= 0 || G <= 0 || C % G || HW <= 0 || drop_p < 0.f || drop_p >= 1.f) return STK_EINVAL;
+  const float L = (float)((long)(C / G) * HW);
+  hipLaunchKernelGGL(gn_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gamma, beta, C, sqrtf(L - 1.f),
+                     1.f / (1.f - drop_p), rec);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
 
 int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
                    float* mean, float* rstd, int N, int HW, int G, float eps, int act, float drop_p,

@@ -50,11 +50,18 @@ class _WprepDesc(ctypes.Structure):        # StkWprepDesc of include/stk.h
 
 class Context:
   """Buffers of one forward call, kept until its backward has run."""
-  __slots__ = ('prog', 'act', 'gact', 'rt', 'released', 'seed_t', 'graphs', 'uses')
+  __slots__ = ('prog', 'act', 'gact', 'rt', 'released', 'seed_t', 'graphs', 'uses', 'pl')
 
   def __init__(self, prog):
     self.prog = prog
     self.act = _arena(prog.graph.act_size, prog.device)
+    # planes arena (+ the data-gradient scratch behind it); poisoned with 0xff = fp16 NaN under STK_POISON
+    g = prog.graph
+    self.pl = None
+    if g.pl_bytes + g.dypl_bytes > 0:
+      self.pl = torch.empty(g.pl_bytes + g.dypl_bytes, dtype=torch.uint8, device=prog.device)
+      if _POISON:
+        self.pl.fill_(0xff)
     self.gact = None
     self.rt = None
     self.released = False
@@ -241,6 +248,9 @@ class Executor:
     rt.prof = self.profiler
     if self.use_wp and prog.wp is not None and prog.wp_table is not None:
       rt.wp = prog.wp.data_ptr()
+    if c.pl is not None:
+      rt.pl = c.pl.data_ptr()
+      rt.dypl = rt.pl + prog.graph.pl_bytes
     return rt
 
   def _replay(self, c, direction, training):

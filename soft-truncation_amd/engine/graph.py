@@ -16,6 +16,7 @@ Because the plan is static, a whole forward/backward is a fixed launch sequence 
 captured into a hipGraph (engine/executor.py).
 """
 import math
+import os
 
 import numpy as np
 
@@ -29,7 +30,8 @@ def _round_up(n, a=_ALIGN):
 
 class Tensor:
   """Symbolic fp32 tensor: a shape plus an offset into one of the runtime's address spaces."""
-  __slots__ = ('shape', 'numel', 'space', 'off', 'goff', 'needs_grad', 'name', 'seen', 'external_grad')
+  __slots__ = ('shape', 'numel', 'space', 'off', 'goff', 'needs_grad', 'name', 'seen', 'external_grad',
+               'producer', 'pl_off', 'pl_rec', 'pl_maker')
 
   def __init__(self, shape, space, off, needs_grad, name):
     self.shape = tuple(int(s) for s in shape)
@@ -41,6 +43,12 @@ class Tensor:
     self.name = name
     self.seen = 0               # number of gradient writers already planned (backward order)
     self.external_grad = False  # gradient is seeded from outside (network output)
+    self.producer = None        # the op whose output this is (Graph.add)
+    # planes (include/stk.h "Planes"): byte offset of the tensor's pre-split copy in the planes arena, the (tensor,
+    # float offset) of its 256-float scale record, and the op that writes them in the forward pass
+    self.pl_off = None
+    self.pl_rec = None
+    self.pl_maker = None
 
   def __repr__(self):
     return f'T({self.name}{list(self.shape)}@{self.space}+{self.off})'
@@ -61,6 +69,8 @@ class Runtime:
     self.seed = seed
     self.seed_dev = seed_dev
     self.wp = 0           # base address of the program's prepared-weight arena (0: every conv prepares per call)
+    self.pl = 0           # base address of the context's planes arena (pre-split conv operands)
+    self.dypl = 0         # ... and of its scratch for the planes of the gradient a data-gradient call consumes
     self.prof = None      # optional engine.profile.KernelTimer: HIP events around the contraction launches
 
   def timed(self, kind, flops, fn, *args):
@@ -77,6 +87,21 @@ class Runtime:
     if t is None or not t.needs_grad or t.goff is None:
       return None
     return self.gbase[t.space] + 4 * t.goff
+
+  def planes(self, t):
+    return self.pl + t.pl_off
+
+  def rec(self, t):
+    rt, off = t.pl_rec
+    return self.v(rt) + 4 * off
+
+  def make_planes(self, t):
+    """fp32 tensor -> planes with a MEASURED scale: one |x| pass into the record, one split pass."""
+    n = t.shape[0]
+    c = t.shape[1]
+    hw = t.numel // (n * c)
+    self.lib.amax_partial_f32(self.v(t), t.numel, self.rec(t), self.stream)
+    self.lib.split_planes_f32(self.v(t), n, c, hw, self.rec(t), 256, self.planes(t), self.stream)
 
 
 class Op:
@@ -134,6 +159,13 @@ class GroupNormAct(Op):
                       rt.v(self.y), rt.v(self.mean), rt.v(self.rstd), self.N, self.HW, self.G, self.eps,
                       self.act, self._p(rt), (rt.seed + 0x9E3779B1 * self.op_id) & 0xFFFFFFFFFFFFFFFF,
                       rt.seed_dev, rt.ws, rt.stream)
+    y = self.y
+    if y.pl_maker is self:
+      # consumers take this output as planes: the scale record is the a-priori bound of the affine parameters
+      # (no pass over the data), then the split
+      C = self.C1 + self.C2
+      rt.lib.gn_bound_f32(rt.v(self.gamma), rt.v(self.beta_t), C, self.G, self.HW, self._p(rt), rt.rec(y), rt.stream)
+      rt.lib.split_planes_f32(rt.v(y), self.N, C, self.HW, rt.rec(y), 256, rt.planes(y), rt.stream)
 
   def backward(self, rt):
     rt.lib.gn_bwd_f32(rt.g(self.y), rt.v(self.x1), self.C1, rt.v(self.x2), self.C2,
@@ -214,8 +246,44 @@ class Conv(Op):
     off = self.wp_off[direction]
     return rt.wp + off if (rt.wp and off is not None) else None
 
+  # planes (include/stk.h "Planes"): decided by Graph.finalize
+  pl_fwd = False       # the forward call reads x1 as planes
+  pl_dgrad = False     # the data-gradient call reads dy as planes (made here, into the context's scratch)
+  x_rec_own = False    # x1's scale record is this layer's amax[0:256] (so the weight gradient may reuse it)
+
+  def plan_planes(self, g, lib):
+    same = self.stride == 1 and self.OH == self.H and self.OW == self.W and self.pad == self.KH // 2
+    if not same:
+      return
+    dims = (self.N, self.H, self.W, self.Cout, self.KH, self.KW, 1, self.pad)
+    t = self.x1
+    by_gn = isinstance(t.producer, GroupNormAct)
+    # 3x3: the fp32 loader re-splits every element nine times; 1x1: only worth a split pass when GroupNorm makes
+    # the planes anyway (attention's q / k / v projections share one input)
+    if self.x2 is None and (self.KH == 3 or by_gn) and int(lib.conv2d_pl_ok(0, self.C1, 0, *dims)):
+      if t.pl_off is None:
+        t.pl_off = g.pl_bytes
+        g.pl_bytes += _round_up(int(lib.planes_bytes(self.N, self.C1, self.H * self.W)), 256)
+        t.pl_rec = (self.amax, 0)
+        t.pl_maker = t.producer if by_gn else self
+        self.x_rec_own = True
+      self.pl_fwd = True
+    needs_dx = (self.x1.needs_grad and self.x1.space == 'act') or (self.x2 is not None and self.x2.needs_grad)
+    if needs_dx and self.KH == 3 and int(lib.conv2d_pl_ok(1, self.C1, self.C2, *dims)):
+      self.pl_dgrad = True
+      g.dypl_bytes = max(g.dypl_bytes, _round_up(int(lib.planes_bytes(self.N, self.Cout, self.OH * self.OW)), 256))
+
   def forward(self, rt):
     temb = rt.v(self.temb) + 4 * self.temb_col if self.temb is not None else None
+    if self.pl_fwd:
+      t = self.x1
+      if t.pl_maker is self:
+        rt.make_planes(t)
+      rt.timed(self._kind(rt.lib, 'fwd') + 'p', self.flops, rt.lib.conv2d_fwd_pl_f32,
+               rt.planes(t), rt.rec(t), self.C1, rt.v(self.w), self.w_layout, rt.v(self.bias), temb, self.temb_stride,
+               rt.v(self.res), self.out_div, rt.v(self.y), self.N, self.H, self.W, self.Cout, self.KH, self.KW,
+               self._wp(rt, 0), rt.ws, rt.ws_bytes, rt.stream)
+      return
     rt.timed(self._kind(rt.lib, 'fwd'), self.flops, rt.lib.conv2d_fwd_wp_f32,
              rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.w), self.w_layout,
              rt.v(self.bias), temb, self.temb_stride, rt.v(self.res), self.out_div,
@@ -237,8 +305,19 @@ class Conv(Op):
                         rt.ws, rt.stream)
     # data gradient first: its |dy| maxima are reused by the weight gradient (the two are independent otherwise)
     have = 1 if self._kind(lib, 'fwd').endswith('.x2') else 0
+    if self.pl_fwd and not self.x_rec_own:
+      have = 0                                   # x1's record lives with another layer: the weight gradient measures
     g1, g2 = rt.g(self.x1), rt.g(self.x2)
-    if g1 is not None or g2 is not None:
+    if self.pl_dgrad and (g1 is not None or g2 is not None):
+      rec = rt.v(self.amax) + 4 * 512            # |dy| partial maxima: reused by the weight gradient below
+      lib.amax_partial_f32(gy, self.y.numel, rec, rt.stream)
+      lib.split_planes_f32(gy, self.N, self.Cout, self.OH * self.OW, rec, 256, rt.dypl, rt.stream)
+      rt.timed(self._kind(lib, 'dgrad') + 'p', self.flops, lib.conv2d_dgrad_pl_f32,
+               rt.dypl, rec, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
+               g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
+               alpha, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self._wp(rt, 1), rt.ws, rt.ws_bytes, rt.stream)
+      have |= 2
+    elif g1 is not None or g2 is not None:
       rt.timed(self._kind(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_wp_f32,
                gy, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
@@ -580,6 +659,8 @@ class Graph:
 
   def add(self, op):
     self.ops.append(op)
+    if op.y.producer is None:
+      op.y.producer = op
     return op.y
 
   # -- convenience emitters -------------------------------------------------------------------
@@ -633,4 +714,12 @@ class Graph:
     for op in self.ops:
       if isinstance(op, Conv):
         self.wp_bytes = op.plan_wp(lib, self.wp_bytes)
+    # planes arena: pre-split copies of the activations the split convolutions read (STK_PLANES=0: none, every call
+    # takes fp32 operands -- a debugging switch)
+    self.pl_bytes = 0
+    self.dypl_bytes = 0
+    if os.environ.get('STK_PLANES', '1') != '0' and hasattr(lib, 'conv2d_pl_ok'):
+      for op in self.ops:
+        if isinstance(op, Conv):
+          op.plan_planes(self, lib)
     return self

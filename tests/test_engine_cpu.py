@@ -4,6 +4,8 @@ dependency injection -- the product never selects it) and compared with the orac
 import pytest
 
 import _model_cases as cases
+from _model_util import build_pair, tiny_config
+cases.build_pair, cases.tiny_config = build_pair, tiny_config
 
 
 @pytest.mark.parametrize('family', ['vp', 'rve', 've'])
@@ -113,3 +115,42 @@ def test_likelihood_engine_on_checker(st, ref_lib, family):
   """likelihood.py through the planned-graph engine (checker backend): exercises the engine's input-gradient path
   under torch.autograd.grad against the reference's fixtures."""
   cases.golden_likelihood_product(st, ref_lib, family)
+
+
+def test_planes_plumbing_on_checker(st, ref_lib):
+  """The 'wide' family (96 / 192 channels) is the smallest net whose convolutions qualify for the pre-split operand
+  path (include/stk.h "Planes"): GroupNorm writes bound record + planes, the 3x3 convs and attention's q / k / v
+  projections read them, data gradients split dy into the context's scratch.  Same answers as the oracle RefNet,
+  and the plan must actually contain planes."""
+  import torch
+  from importlib import import_module
+  G = import_module('soft-truncation_amd.engine.graph')
+  cases.forward_backward(st, ref_lib, 'wide', B=2)
+  cfg, cfg_cpu, sde, model, ref = cases.build_pair(st, cases.tiny_config(st, 'wide'), ref_lib)
+  x = torch.randn(2, 3, 16, 16)
+  model.eval()
+  model(x.requires_grad_(True), torch.rand(2) * 999).sum().backward()
+  progs = list(model.module.engine().programs.values())
+  convs = [op for pr in progs for op in pr.graph.ops if isinstance(op, G.Conv)]
+  assert any(op.pl_fwd and op.KH == 3 for op in convs) and any(op.pl_fwd and op.KH == 1 for op in convs)
+  assert any(op.pl_dgrad for op in convs)
+  assert all(pr.graph.pl_bytes > 0 and pr.graph.dypl_bytes > 0 for pr in progs)
+  gns = [op for pr in progs for op in pr.graph.ops if isinstance(op, G.GroupNormAct)]
+  assert any(op.y.pl_maker is op for op in gns)
+
+
+def test_planes_switch_off_gives_same_answers(st, ref_lib, monkeypatch):
+  """STK_PLANES=0 (every convolution on fp32 operands) against the default plan, on the checker: the restatement
+  decodes planes exactly, so forward values agree to the split's 2^-22."""
+  import torch
+  cfg, cfg_cpu, sde, model, ref = cases.build_pair(st, cases.tiny_config(st, 'wide'), ref_lib)
+  model.eval()
+  x, t = torch.randn(2, 3, 16, 16), torch.rand(2) * 999
+  with torch.no_grad():
+    y1 = model(x, t)
+  monkeypatch.setenv('STK_PLANES', '0')
+  model.module.engine().programs.clear()
+  with torch.no_grad():
+    y0 = model(x, t)
+  assert all(pr.graph.pl_bytes == 0 for pr in model.module.engine().programs.values())
+  assert (y1 - y0).abs().max().item() <= 2e-6 * y0.abs().max().item()

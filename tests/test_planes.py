@@ -1,0 +1,181 @@
+"""Planes (include/stk.h "Planes", csrc/conv_pl.h): the oracle's restatement of the format against numpy's IEEE
+binary16 conversion (CPU), and the HIP kernels against the oracle (GPU): the split pass BIT-exact (it is byte work:
+scale by a power of two, two round-to-nearest conversions, a fixed layout), the plane-consuming convolutions at the
+tolerance of the other convolution tests."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from _util import call, dev_of, rnd
+
+
+def _planes_np(x, amax):
+  """numpy model of the format: [split][n][c / 32][pixel][c % 32] float16 of s x."""
+  N, C, HW = x.shape
+  m = float(np.max(amax))
+  s = 1.0 if m == 0 else 2.0 ** (13 - int(np.floor(np.log2(m))))
+  Cb = (C + 31) // 32
+  xp = np.zeros((N, Cb * 32, HW), np.float32)
+  xp[:, :C] = x * np.float32(s)
+  hi = xp.astype(np.float16)
+  lo = (xp - hi.astype(np.float32)).astype(np.float16)
+  lay = lambda a: a.reshape(N, Cb, 32, HW).transpose(0, 1, 3, 2)
+  return np.stack([lay(hi), lay(lo)]), s
+
+
+def _split(lib, x, amax):
+  N, C, HW = x.shape
+  d = dev_of(lib)
+  nb = int(lib.planes_bytes(N, C, HW))
+  out = torch.full((nb,), 0xAA, dtype=torch.uint8, device=d)
+  call(lib, 'split_planes_f32', x.to(d), N, C, HW, amax.to(d), amax.numel(), out)
+  return out.cpu().numpy().view(np.float16).reshape(2, N, (C + 31) // 32, HW, 32)
+
+
+SPLIT_CASES = [(2, 32, 64), (3, 96, 256), (1, 40, 20), (2, 128, 1024), (5, 3, 7)]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES, ids=str)
+def test_oracle_planes_match_numpy_float16(ref_lib, case):
+  N, C, HW = case
+  x = rnd(N, C, HW, seed=N + C) * 3.0
+  x[0, 0, 0] = 0.0
+  x[-1, -1, -1] = 1e-9          # far below the maximum: its second term lives in fp16's subnormal range
+  amax = torch.zeros(256)
+  amax[7] = x.abs().max()
+  got = _split(ref_lib, x, amax)
+  want, s = _planes_np(x.numpy(), amax.numpy())
+  assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+  # hi + lo reproduces s x to 2^-22 relative (or 2^-25 absolute in scaled units)
+  rec = (got[0].astype(np.float64) + got[1].astype(np.float64))
+  ref = want[0].astype(np.float64) * 0 + (_planes_np(x.numpy(), amax.numpy())[0][0].astype(np.float64) * 0)
+  xs = np.zeros((N, (C + 31) // 32 * 32, HW)); xs[:, :C] = x.numpy().astype(np.float64) * s
+  xs = xs.reshape(N, -1, 32, HW).transpose(0, 1, 3, 2)
+  assert np.all(np.abs(rec - xs) <= np.maximum(np.abs(xs) * 2.0 ** -22, 2.0 ** -25))
+
+
+def test_oracle_amax_record_and_apriori_bound(ref_lib):
+  """Any record with the same maximum gives the same planes; a larger (a-priori) bound only moves the scale."""
+  x = rnd(2, 64, 48, seed=3)
+  a = torch.zeros(256); a[0] = x.abs().max()
+  b = torch.zeros(256); b[200] = x.abs().max(); b[3] = 0.5 * x.abs().max()
+  assert np.array_equal(_split(ref_lib, x, a).view(np.uint16), _split(ref_lib, x, b).view(np.uint16))
+  c = torch.zeros(256); c[0] = 16 * x.abs().max()
+  p16 = _split(ref_lib, x, c)
+  assert np.array_equal((p16[0].astype(np.float32) * 16).astype(np.float16).view(np.uint16),
+                        _split(ref_lib, x, a)[0].view(np.uint16))
+  part = torch.full((256,), -1.0)
+  call(ref_lib, 'amax_partial_f32', x, x.numel(), part)
+  assert float(part.max()) == float(x.abs().max()) and float(part.min()) >= 0
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', SPLIT_CASES + [(128, 128, 1024), (16, 256, 64)], ids=str)
+def test_split_planes_bit_exact(ref_lib, hip_lib, case):
+  N, C, HW = case
+  x = rnd(N, C, HW, seed=N + C) * 3.0
+  x[0, 0, 0] = 0.0
+  x[-1, -1, -1] = 1e-9
+  d = dev_of(hip_lib)
+  part = torch.full((256,), float('nan'), device=d)
+  call(hip_lib, 'amax_partial_f32', x.to(d), x.numel(), part)
+  part = part.cpu()
+  assert float(part.max()) == float(x.abs().max())
+  if N * C * HW > 4e6:       # the oracle's triple loop is slow: check a random subset of images
+    idx = [0, N // 2, N - 1]
+    got = _split(hip_lib, x, part)[:, idx]
+    want = _split(ref_lib, x[idx].contiguous(), part)
+  else:
+    got, want = _split(hip_lib, x, part), _split(ref_lib, x, part)
+  assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+PL_CONV_CASES = [
+  # N, C, H, W, Cout, K, layout, temb, res, div
+  (8, 128, 32, 32, 128, 3, 0, 1, 1, 1),
+  (4, 96, 16, 16, 96, 3, 0, 0, 0, 0),
+  (6, 256, 8, 8, 256, 3, 0, 1, 0, 1),       # K-split (few tiles)
+  (3, 256, 4, 4, 256, 3, 0, 0, 1, 0),
+  (4, 256, 16, 16, 256, 1, 0, 0, 1, 1),     # 1x1 Conv2d
+  (4, 256, 16, 16, 256, 1, 1, 0, 0, 0),     # NIN
+  (5, 128, 12, 20, 160, 3, 0, 0, 0, 0),     # ragged map, 160 rows
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', PL_CONV_CASES, ids=str)
+def test_conv_from_planes(ref_lib, hip_lib, case):
+  """Forward and data gradient with the activation operand given as planes, HIP vs the oracle (which decodes the
+  planes and runs its double-accumulating convolution), plus agreement with the HIP fp32-input call."""
+  N, C, H, W, Cout, K, layout, use_temb, use_res, use_div = case
+  x = rnd(N, C, H, W, seed=1)
+  w = (rnd(Cout, C, K, K, seed=3) if layout == 0 else rnd(C, Cout, seed=3)) * (1.0 / np.sqrt(C * K * K))
+  bias = rnd(Cout, seed=4)
+  temb = rnd(N, Cout, seed=5) if use_temb else None
+  res = rnd(N, Cout, H, W, seed=6) if use_res else None
+  div = float(np.float32(np.sqrt(2.))) if use_div else 1.0
+  dy = rnd(N, Cout, H, W, seed=7)
+  g1 = rnd(N, C, H, W, seed=8)
+  assert int(hip_lib.conv2d_pl_ok(0, C, 0, N, H, W, Cout, K, K, 1, K // 2)) == 1
+  assert int(ref_lib.conv2d_pl_ok(0, C, 0, N, H, W, Cout, K, K, 1, K // 2)) == 1
+  assert int(hip_lib.conv2d_pl_ok(1, C, 0, N, H, W, Cout, K, K, 1, K // 2)) == 1
+
+  def run(lib):
+    d = dev_of(lib)
+    to = lambda t: None if t is None else t.to(d)
+    shape = (C, 0, N, H, W, Cout, K, K, 1, K // 2)
+    fb = max(int(lib.conv2d_fwd_ws_bytes(*shape)), int(lib.conv2d_dgrad_ws_bytes(*shape)), 256)
+    ws = torch.zeros(fb // 4 + 64, device=d)
+    ax, ay = torch.zeros(256, device=d), torch.zeros(256, device=d)
+    xd, dyd = to(x), to(dy)
+    call(lib, 'amax_partial_f32', xd, xd.numel(), ax)
+    call(lib, 'amax_partial_f32', dyd, dyd.numel(), ay)
+    xp = torch.zeros(int(lib.planes_bytes(N, C, H * W)), dtype=torch.uint8, device=d)
+    yp = torch.zeros(int(lib.planes_bytes(N, Cout, H * W)), dtype=torch.uint8, device=d)
+    call(lib, 'split_planes_f32', xd, N, C, H * W, ax, 256, xp)
+    call(lib, 'split_planes_f32', dyd, N, Cout, H * W, ay, 256, yp)
+    y = torch.zeros(N, Cout, H, W, device=d)
+    call(lib, 'conv2d_fwd_pl_f32', xp, ax, C, to(w), layout, to(bias), to(temb), Cout if use_temb else 0, to(res), div, y,
+         N, H, W, Cout, K, K, None, ws, fb)
+    dx = to(g1.clone())
+    call(lib, 'conv2d_dgrad_pl_f32', yp, ay, to(w), layout, dx, C, 1.0, None, 0, 0.0, 0.5, N, H, W, Cout, K, K, None, ws, fb)
+    # the fp32-input calls of the same library
+    y32 = torch.zeros(N, Cout, H, W, device=d)
+    call(lib, 'conv2d_fwd_f32', xd, C, None, 0, to(w), layout, to(bias), to(temb), Cout if use_temb else 0, to(res), div,
+         y32, N, H, W, Cout, H, W, K, K, 1, K // 2, ws, fb)
+    dx32 = to(g1.clone())
+    call(lib, 'conv2d_dgrad_f32', dyd, to(w), layout, dx32, C, 1.0, None, 0, 0.0, 0.5, N, H, W, Cout, H, W, K, K, 1, K // 2,
+         ws, fb)
+    return {k: v.cpu() for k, v in dict(y=y, dx=dx, y32=y32, dx32=dx32).items()}
+
+  r, h = run(ref_lib), run(hip_lib)
+  for k in ('y', 'dx'):
+    scale = r[k].abs().max().item()
+    assert (h[k] - r[k]).abs().max().item() <= 1e-4 * scale, k
+    assert (h[k] - h[k + '32']).abs().max().item() <= 2e-5 * scale, k + ' vs the fp32-input call'
+
+
+@pytest.mark.gpu
+def test_conv_from_planes_apriori_bound(ref_lib, hip_lib):
+  """A scale record holding a loose a-priori bound (what GroupNorm writes): 64x the true maximum still gives fp32-level
+  results, because the second split term absorbs what the first loses."""
+  N, C, H, Cout = 4, 128, 16, 128
+  x = rnd(N, C, H, H, seed=1)
+  w = rnd(Cout, C, 3, 3, seed=3) / np.sqrt(C * 9.)
+  ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+  d = dev_of(hip_lib)
+  shape = (C, 0, N, H, H, Cout, 3, 3, 1, 1)
+  fb = int(hip_lib.conv2d_fwd_ws_bytes(*shape))
+  ws = torch.zeros(fb // 4 + 64, device=d)
+  for slack in (1.0, 64.0, 4096.0):
+    rec = torch.zeros(256); rec[0] = slack * x.abs().max()
+    rec = rec.to(d)
+    xp = torch.zeros(int(hip_lib.planes_bytes(N, C, H * H)), dtype=torch.uint8, device=d)
+    call(hip_lib, 'split_planes_f32', x.to(d), N, C, H * H, rec, 256, xp)
+    y = torch.zeros(N, Cout, H, H, device=d)
+    call(hip_lib, 'conv2d_fwd_pl_f32', xp, rec, C, w.to(d), 0, None, None, 0, None, 1.0, y, N, H, H, Cout, 3, 3, None, ws, fb)
+    err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 3e-6, (slack, err)

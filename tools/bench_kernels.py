@@ -40,6 +40,8 @@ def main():
   ap.add_argument('--only', default='')
   ap.add_argument('--reps', type=int, default=20)
   ap.add_argument('--batch', type=int, default=128)
+  ap.add_argument('--shapes', type=int, default=0, help='only the first N conv shapes')
+  ap.add_argument('--planes-only', action='store_true', help='conv section: time only the plane-operand calls')
   args = ap.parse_args()
   lib = st.engine.lib.load()
   d = torch.device('cuda:0')
@@ -64,6 +66,8 @@ def main():
   if 'hq' in args.only:        # the 256x256 network's layers (use with --batch 4)
     conv_shapes = [(128, 0, 256, 128, 3), (128, 0, 128, 128, 3), (128, 0, 64, 256, 3), (256, 0, 64, 256, 3),
                    (256, 0, 32, 256, 3), (256, 128, 256, 128, 3), (256, 0, 256, 128, 1)]
+  if args.shapes:
+    conv_shapes = conv_shapes[:args.shapes]
   if not args.only or 'conv' in args.only:
     for C1, C2, H, Cout, K in conv_shapes:
       if 'k1' in args.only and K != 1:
@@ -86,12 +90,26 @@ def main():
       shp = (C1, C2, N, H, H, Cout, K, K, 1, K // 2)
       fb = max(int(lib.conv2d_fwd_ws_bytes(*shp)), int(lib.conv2d_dgrad_ws_bytes(*shp)))
       fws = torch.empty(fb // 4 + 64, device=d)
-      rec('conv.fwd.f32in', shape, timeit(lambda: call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, 0, bias, None, 0, None, 1.0, y, *dims, None, 0), args.reps), flops)
-      rec('conv.dgrad.f32in', shape, timeit(lambda: call(lib, 'conv2d_dgrad_f32', dy, w, 0, dx1, C1, 0.0, dx2, C2, 0.0, 1.0, *dims, None, 0), args.reps), flops)
-      if fb:
+      if not args.planes_only:
+       rec('conv.fwd.f32in', shape, timeit(lambda: call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, 0, bias, None, 0, None, 1.0, y, *dims, None, 0), args.reps), flops)
+      if not args.planes_only:
+       rec('conv.dgrad.f32in', shape, timeit(lambda: call(lib, 'conv2d_dgrad_f32', dy, w, 0, dx1, C1, 0.0, dx2, C2, 0.0, 1.0, *dims, None, 0), args.reps), flops)
+      if fb and not args.planes_only:
         rec('conv.fwd.split', shape, timeit(lambda: call(lib, 'conv2d_fwd_f32', x1, C1, x2, C2, w, 0, bias, None, 0, None, 1.0, y, *dims, fws, fb), args.reps), flops)
         rec('conv.dgrad.split', shape, timeit(lambda: call(lib, 'conv2d_dgrad_f32', dy, w, 0, dx1, C1, 0.0, dx2, C2, 0.0, 1.0, *dims, fws, fb), args.reps), flops)
-      rec('conv.wgrad', shape, timeit(lambda: call(lib, 'conv2d_wgrad_f32', x1, C1, x2, C2, dy, dw, 0, 1.0, ws, ws.numel() * 4, *dims), args.reps), flops)
+      if fb and not C2 and int(lib.conv2d_pl_ok(0, C1, 0, N, H, H, Cout, K, K, 1, K // 2)):
+        ax, ay = torch.zeros(256, device=d), torch.zeros(256, device=d)
+        call(lib, 'amax_partial_f32', x1, x1.numel(), ax)
+        call(lib, 'amax_partial_f32', dy, dy.numel(), ay)
+        xp = torch.zeros(int(lib.planes_bytes(N, C1, H * H)), dtype=torch.uint8, device=d)
+        yp = torch.zeros(int(lib.planes_bytes(N, Cout, H * H)), dtype=torch.uint8, device=d)
+        rec('amax_partial', shape, timeit(lambda: call(lib, 'amax_partial_f32', x1, x1.numel(), ax), args.reps), nbytes=4 * x1.numel())
+        rec('split_planes', shape, timeit(lambda: call(lib, 'split_planes_f32', x1, N, C1, H * H, ax, 256, xp), args.reps), nbytes=8 * x1.numel())
+        call(lib, 'split_planes_f32', dy, N, Cout, H * H, ay, 256, yp)
+        rec('conv.fwd.planes', shape, timeit(lambda: call(lib, 'conv2d_fwd_pl_f32', xp, ax, C1, w, 0, bias, None, 0, None, 1.0, y, N, H, H, Cout, K, K, None, fws, fb), args.reps), flops)
+        rec('conv.dgrad.planes', shape, timeit(lambda: call(lib, 'conv2d_dgrad_pl_f32', yp, ay, w, 0, dx1, C1, 0.0, None, 0, 0.0, 1.0, N, H, H, Cout, K, K, None, fws, fb), args.reps), flops)
+      if not args.planes_only:
+       rec('conv.wgrad', shape, timeit(lambda: call(lib, 'conv2d_wgrad_f32', x1, C1, x2, C2, dy, dw, 0, 1.0, ws, ws.numel() * 4, *dims), args.reps), flops)
 
   if not args.only or 'gn' in args.only:
     for C, H, Nb in [(128, 32, N), (256, 16, N), (256, 8, N), (384, 32, N), (512, 16, N), (128, 256, 4), (256, 128, 4)]:
