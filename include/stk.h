@@ -196,6 +196,13 @@ int stk_conv2d_wgrad_f32(const float* x1, int C1, const float* x2, int C2, const
 /* Scale record of a GroupNorm (+SiLU) (+dropout) output from its parameters alone: rec[0] = (max|gamma| sqrt(L - 1) +
  * max|beta|) / (1 - drop_p) >= |y| for ANY input (L = (C / G) HW elements per group), rec[1..255] = 0. */
 int stk_gn_bound_f32(const float* gamma, const float* beta, int C, int G, int HW, float drop_p, float* rec, void* stream);
+/* GroupNorm forward whose output goes to plane consumers: stk_gn_fwd_f32 + stk_gn_bound_f32 (rec) +
+ * stk_split_planes_f32 (planes) in one call -- and one pass over x for the shapes stk_gn_fwd_pl_fused reports (whole
+ * groups per 32-channel block, H W in {16, 64, 256, 1024}); for those y may be NULL (no fp32 copy is written). */
+int stk_gn_fwd_pl_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
+                      void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
+                      float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream);
+int stk_gn_fwd_pl_fused(int C1, int C2, int HW, int G);
 long stk_planes_bytes(int N, int C, int HW);
 int stk_amax_partial_f32(const float* x, long n, float* part, void* stream);
 int stk_split_planes_f32(const float* x, int N, int C, int HW, const float* amax, int namax, void* planes, void* stream);
@@ -212,6 +219,10 @@ int stk_conv2d_dgrad_pl_f32(const void* dypl, const float* dyamax, const float* 
  * ws: >= N*C floats of scratch (only used when dtemb is NULL). */
 int stk_bias_grad_f32(const float* dy, int N, int C, int HW, float alpha,
                       float* dtemb, int temb_stride, float* dbias, float* ws, void* stream);
+/* The same plus a planes scale record of dy (see "Planes" above) in amax[0..256): amax[c] = max |dy[:, c, :]| for
+ * c < C <= 256, zeros behind -- the bias gradient reads every element of dy anyway.  dtemb and dbias may both be NULL. */
+int stk_bias_grad_amax_f32(const float* dy, int N, int C, int HW, float alpha,
+                           float* dtemb, int temb_stride, float* dbias, float* amax, float* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batched strided GEMM on the fp32 MFMA path:

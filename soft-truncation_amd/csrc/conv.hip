@@ -406,12 +406,71 @@ struct BWgrad {       // B(k=pixel, n=ci) = x[b, ci, oy*s + kh - pad, ox*s + kw 
 // ---- epilogues: one 16-row strip of one output column per call, loads batched ------------------------------
 struct EpFwd {        // y = (acc + bias + temb + res) * inv_div
   int b; int col_off;
+  // Tile-level staging of the per-row addends (split kernels; conv_x2.h / conv_pl.h): a 128-row tile needs 128 bias
+  // values and 128 time-embedding values per image it touches.  Fetched into registers BEFORE the main loop (their
+  // latency hides under it), parked in LDS after it, read back with ds_read_b128 -- the epilogue itself then waits
+  // for nothing but the residual loads, issued 16 at a time.  (The first version loaded bias / temb / res per group of
+  // four rows: sixteen dependent round trips per wave, ~20 us of a 150 us launch at K = 1152.)
+  static constexpr int TEMB_IMGS = 9;                 // 128-pixel tile over maps of >= 16 pixels
+  float rb; float rt[5]; int m0 = 0, b0 = 0, nimg = 0, tb = 0;
+  const float* sb = nullptr; const float* stm = nullptr;     // null: not staged (the f32-input and bf16 kernels)
+  __device__ void preload(const ConvP& p, int m0_, int n0, int tn, int M, int Nn, int tid) {
+    m0 = m0_; sb = nullptr; stm = nullptr;
+    b0 = n0 / p.OHW;
+    nimg = min(n0 + tn - 1, Nn - 1) / p.OHW - b0 + 1;
+    rb = (p.bias && tid < 128 && m0 + tid < M) ? p.bias[m0 + tid] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int idx = tid + 256 * k, img = idx >> 7, r = idx & 127;
+      rt[k] = (p.temb && nimg <= TEMB_IMGS && img < nimg && m0 + r < M) ? p.temb[(long)(b0 + img) * p.temb_stride + m0 + r] : 0.f;
+    }
+  }
+  __device__ void stage(unsigned char* lds, int tid) {      // all waves are past their last operand read when they arrive
+    __syncthreads();
+    float* s = reinterpret_cast<float*>(lds);
+    if (tid < 128) s[tid] = rb;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < TEMB_IMGS * 128) s[128 + idx] = rt[k];
+    }
+    __syncthreads();
+    sb = s; stm = s + 128;
+  }
   __device__ void init(const ConvP&, int, int) {}
   __device__ void col(const ConvP& p, int n) {
     b = n / p.OHW;
     col_off = b * p.Cout * p.OHW + (n - b * p.OHW);
+    tb = (b - b0) * 128;
   }
   __device__ void strip(const ConvP& p, int mbase, int M, bool nok, int, const floatx16& acc) {
+    if (sb && (!p.temb || nimg <= TEMB_IMGS)) {      // staged addends (wave-uniform branch)
+      const int ml = mbase - m0;
+      float rv[16]; int idx[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = mbase + strip_row(e);
+        const bool ok = nok && m < M;
+        idx[e] = ok ? col_off + m * p.OHW : -1;
+        rv[e] = (p.res && ok) ? p.res[idx[e]] : 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bb = *reinterpret_cast<const float4*>(sb + ml + 8 * g);
+        const float4 tt = *reinterpret_cast<const float4*>(stm + tb + ml + 8 * g);
+        const float bv[4] = {bb.x, bb.y, bb.z, bb.w}, tv[4] = {tt.x, tt.y, tt.z, tt.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float v = acc[4 * g + u];
+          if (p.bias) v += bv[u];
+          if (p.temb) v += tv[u];
+          if (p.res) v += rv[4 * g + u];
+          if (p.use_div) v *= p.inv_div;
+          if (idx[4 * g + u] >= 0) p.y[idx[4 * g + u]] = v;
+        }
+      }
+      return;
+    }
     // 4 rows at a time: up to 12 independent loads in flight, and only a dozen live registers on top of
     // the accumulators (a 16-row batch pushed the whole kernel to 249 VGPRs = 2 waves/SIMD).
 #pragma unroll
@@ -442,6 +501,8 @@ struct EpFwd {        // y = (acc + bias + temb + res) * inv_div
 };
 struct EpDgrad {      // dx{1,2} = beta*dx + alpha*acc, rows routed to the two sources of the concat
   int b, hw;
+  __device__ void preload(const ConvP&, int, int, int, int, int, int) {}
+  __device__ void stage(unsigned char*, int) {}
   __device__ void init(const ConvP&, int, int) {}
   __device__ void col(const ConvP& p, int n) { b = n / p.HW; hw = n - b * p.HW; }
   __device__ void strip(const ConvP& p, int mbase, int M, bool nok, int, const floatx16& acc) {
@@ -488,6 +549,8 @@ struct EpWgrad {      // partial slab of split zs as [tap][Cout][Cin] (coalesced
 // Forward / dgrad split over K (small maps): partial tile of split zs as [M][N] (lanes = pixels, contiguous)
 struct EpSlab {
   float* slab; int Nn;
+  __device__ void preload(const ConvP&, int, int, int, int, int, int) {}
+  __device__ void stage(unsigned char*, int) {}
   __device__ void init(const ConvP& p, int, int zs) { slab = p.part + (long)zs * p.part_stride; Nn = p.N * p.HW; }
   __device__ void col(const ConvP&, int) {}
   __device__ void strip(const ConvP&, int mbase, int M, bool nok, int n, const floatx16& acc) {
@@ -532,6 +595,7 @@ __global__ __launch_bounds__(256) void slab_dgrad_kernel(ConvP p, int splits, in
 #include "conv_thin.h"
 #include "conv_x2.h"
 #include "conv_pl.h"
+#include "conv_x2d.h"
 
 // dw (in the weight's own layout) += alpha * sum over splits of slab[tap][co][ci]
 // Threads walk the SLAB order four elements at a time, so the `splits` reads per element are 16-byte and coalesced
@@ -910,9 +974,23 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
     }
 #undef STK_PL_ABL
 #define STK_PL_LAUNCH(E, TAPS)                                                                                    \
-  if (pl::kernel_choice() == 1)                                                                                   \
+  if (pl::kernel_choice() == 3 || pl::kernel_choice() == 4) {                                                     \
+    /* LDS-DMA staging (conv_x2d.h); 128 x 256 tiles when that still fills the chip and a tile stays in one image */ \
+    const bool wide = pl::kernel_choice() == 3 && r.splits == 1 && p.HW % 256 == 0 && (long)tm * stk_cdiv((int)Ng, 256) >= 384; \
+    if (wide) {                                                                                                   \
+      const int tn2 = stk_cdiv((int)Ng, 256);                                                                     \
+      hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 256, E>), dim3((unsigned)(tm * tn2)), dim3(256), 0, s, p, q, M, (int)Ng, \
+                         tm, tn2, nch, r.chunks_per_split, xpart, nx);                                            \
+    } else {                                                                                                      \
+      hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 128, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch,  \
+                         r.chunks_per_split, xpart, nx);                                                          \
+    }                                                                                                             \
+  } else if (pl::kernel_choice() == 1)                                                                            \
     hipLaunchKernelGGL((pl::gemm_db_kernel<pl::PlaneLoader<TAPS>, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, \
                        nch, r.chunks_per_split, xpart, nx);                                                       \
+  else if (pl::kernel_choice() == 2)                                                                              \
+    hipLaunchKernelGGL((x2::gemm_kernel<pl::PlaneLoader<TAPS>, E, 3>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, \
+                       r.chunks_per_split, xpart, nx);                                                            \
   else                                                                                                            \
     hipLaunchKernelGGL((x2::gemm_kernel<pl::PlaneLoader<TAPS>, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, \
                        r.chunks_per_split, xpart, nx)

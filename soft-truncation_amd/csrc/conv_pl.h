@@ -172,6 +172,8 @@ __global__ __launch_bounds__(256, 2) void gemm_db_kernel(ConvP p, x3::Src q, int
   x2::WpLoader al; BL bl;
   al.init(q, m0, tid);
   bl.init(p, q, n0, tid, sx);
+  EP ep;
+  ep.preload(p, m0, n0, 128, M, Nn, tid);
 
   floatx16 acc[2][2];
 #pragma unroll
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_db_kernel(ConvP p, x3::Src q, int
 #undef STK_DB_MFMA
 #undef STK_DB_FRAGS
 
-  EP ep;
+  ep.stage(lds, tid);
   ep.init(p, 0, zs);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -257,10 +259,12 @@ __global__ __launch_bounds__(256, 2) void gemm_db_kernel(ConvP p, x3::Src q, int
   }
 }
 
-// STK_PL_KERNEL=0 selects x2::gemm_kernel (single LDS buffer, two barriers per chunk) for plane operands; default is
-// the double-buffered kernel.  A/B switch for the kernel benchmarks; results are bit-identical.
+// Kernel for plane operands, STK_PL_KERNEL (A/B switch of the kernel benchmarks; all give the same results up to the
+// accumulation order): 4 (default) = LDS-DMA staging, 128 x 128 tiles (conv_x2d.h); 3 = the same with 128 x 256 tiles
+// where they fill the chip; 1 = register staging, double-buffered LDS (above); 0 / 2 = x2::gemm_kernel's structure with
+// the plane loader (2 / 3 waves per SIMD); >= 16 = ablation builds of the double-buffered kernel.
 inline int kernel_choice() {
-  static const int v = [] { const char* e = getenv("STK_PL_KERNEL"); return e ? atoi(e) : 1; }();
+  static const int v = [] { const char* e = getenv("STK_PL_KERNEL"); return e ? atoi(e) : 4; }();
   return v;
 }
 

@@ -218,8 +218,8 @@ struct ActLoader {
 
 // ---- the kernel: out tile 128 x 128, 4 waves of 64 x 64, chunks of 32 k; 12 MFMAs per 16-k step and wave -------------
 // Grid (XCD-remapped): one flat dimension of tiles x K-splits.  xpart: `nxpart` (256 / 512) partial |x| maxima.
-template <class BL, class EP>
-__global__ __launch_bounds__(256) void gemm_kernel(ConvP p, x3::Src q, int M, int Nn, int tiles_m, int tiles_n,
+template <class BL, class EP, int WPS = 2>       // WPS: waves per SIMD the register allocation must admit
+__global__ __launch_bounds__(256, WPS) void gemm_kernel(ConvP p, x3::Src q, int M, int Nn, int tiles_m, int tiles_n,
                                                    int nchunks_total, int chunks_per_split, const float* __restrict__ xpart,
                                                    int nxpart) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
@@ -241,6 +241,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(ConvP p, x3::Src q, int M, in
   WpLoader al; BL bl;
   al.init(q, m0, tid);
   bl.init(p, q, n0, tid, sx);
+  EP ep;
+  ep.preload(p, m0, n0, 128, M, Nn, tid);
 
   floatx16 acc[2][2];
 #pragma unroll
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ConvP p, x3::Src q, int M, in
 #undef STK_X2_MFMA
 #undef STK_X2_FRAGS
 
-  EP ep;
+  ep.stage(lds, tid);
   ep.init(p, 0, zs);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {

@@ -1,0 +1,177 @@
+// conv_x2d.h -- the fp16 two-way-split convolution (conv_x2.h) with BOTH operands staged by LDS-DMA
+// (`buffer_load_dwordx4 ... lds`), for gfx950.  Included by conv.hip inside its anonymous namespace, after conv_pl.h.
+//
+// Why.  With plane operands (conv_pl.h) the staging of x2::gemm_kernel is pure copying, yet the kernel stayed at 0.31
+// of the 3-MFMA ceiling.  Ablations on the 128 -> 128 3x3 layer at 32x32, batch 128 (profiles/r02_conv_ablation.txt):
+//     full kernel 148.9 us | without the ds_write_b128 of the staging 120.6 | MFMAs + barriers only 115.7.
+// A ds_write_b128 moves 5 source VGPRs to the LDS at 2 cycles per dword and wave (MI355X_MICROARCH.md, LDS): the 8
+// stores per thread and chunk keep the LDS busy for ~830 of the 1536 cycles the two resident workgroups' MFMAs of a
+// chunk take, on top of ~510 cycles of operand reads.  LDS-DMA writes the LDS from the memory pipe instead -- no
+// staging registers, no store instructions -- and the freed registers buy a 128 x 256 tile (wave tile 64 x 128:
+// one weight tile now feeds twice the MFMAs, 0.5 instead of 0.67 operand reads per MFMA, and the 32x32 layers of
+// batch 128 become ONE round of 512 workgroups instead of two with their prologue / epilogue bursts).
+//
+// LDS image of an operand tile: [split][row][64 bytes = 32 k], NO padding (a DMA instruction writes wave-uniform base
+// + 16 lane: 16 rows x 64 bytes), bank conflicts removed by an XOR swizzle of the 16-byte slots inside a row,
+//     slot(row, seg) = seg ^ ((row >> 2) & 3),
+// applied on the SOURCE address of the DMA and on the address of the operand read (cdna_hip_programming.md, rule 21):
+// any 32 consecutive rows read with one `seg` then cover every bank group exactly once per ds_read_b128 lane group.
+#pragma once
+
+namespace x2d {
+
+using x3::KC;
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int TN>
+struct Geo {
+  static constexpr int A_PLANE = 128 * 64, A_BYTES = 2 * A_PLANE;
+  static constexpr int B_PLANE = TN * 64, B_BYTES = 2 * B_PLANE;
+  static constexpr int LDS = A_BYTES + B_BYTES;                 // 32 KB (TN = 128) / 48 KB (TN = 256)
+  static constexpr int NJ = TN / 64;                            // 32-pixel MFMA column blocks per wave (2 waves along N)
+  static constexpr int BBLK = TN / 64;                          // 16-row DMA blocks of B per wave and plane
+};
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* dst, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, (int)voff, (int)soff, 0, 0);
+}
+
+// (Tried and dropped: a static wave priority per workgroup generation, s_setprio by (blockIdx >> 8) & 1, to break
+// the lockstep of the two workgroups of a CU -- 132 -> 142 us on the 128 -> 128 layer.)
+template <int TAPS, int TN, class EP>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M, int Nn, int tiles_m, int tiles_n,
+                                                      int nchunks_total, int chunks_per_split,
+                                                      const float* __restrict__ xpart, int nxpart) {
+  using G = Geo<TN>;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS];
+  unsigned char* As = lds;
+  unsigned char* Bs = lds + G::A_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float sx = x2::pow2_scale_of(x2::block_amax(xpart, nxpart, reinterpret_cast<float*>(lds)));
+  const float sw = x2::weight_scale(q.wp);
+  const float unscale = 1.f / (sw * sx);
+  const int ntiles = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = id % ntiles, zs = id / ntiles;
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int m0 = tm * 128, n0 = tn * TN;
+  const int c_begin = zs * chunks_per_split;
+  const int c_last = min(nchunks_total, c_begin + chunks_per_split) - 1;
+
+  // ---- DMA sources.  A lane of a DMA instruction owns (row = 16-row block base + lane / 4, slot = lane % 4) and
+  // fetches segment slot ^ f(row); every block base is a multiple of 16, so f(row) = (lane >> 4) & 3 for all of them.
+  const unsigned seg_src = (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
+  // A: prepared weights, [split][k / 32][tap][row (Mpad)][32] fp16 behind the header; wave w stages rows 32 w .. 32 w + 31
+  const unsigned a_plane2 = (unsigned)q.taps * q.Mpad * q.Kc * 2u;
+  const unsigned a_chunk2 = (unsigned)q.Mpad * KC * 2u;
+  const __amdgpu_buffer_rsrc_t a_rs = x3::make_rsrc(reinterpret_cast<const unsigned char*>(q.wp) + x2::HEADER, 2L * a_plane2);
+  const unsigned a_voff = (unsigned)(m0 + 32 * wid + (lane >> 2)) * 64u + seg_src;
+  // B: planes [split][n][cb][pixel][32]; wave w stages rows (TN / 4) w .. + TN / 4 - 1 in blocks of 16
+  const __amdgpu_buffer_rsrc_t b_rs = x3::make_rsrc(q.pl, 2L * q.pl_stride);
+  const unsigned b_ps = (unsigned)q.pl_stride;
+  unsigned b_base[G::BBLK], b_mask[G::BBLK];
+  {
+    const int Cb = q.Kc >> 5;
+#pragma unroll
+    for (int jb = 0; jb < G::BBLK; ++jb) {
+      const int n = n0 + (TN / 4) * wid + 16 * jb + (lane >> 2);
+      b_mask[jb] = 0; b_base[jb] = 0;
+      if (n < Nn) {
+        const int b = n / p.HW, hw = n - b * p.HW;
+        const int y = hw / p.W, x = hw - y * p.W;
+        if (TAPS == 1) b_mask[jb] = 1u;
+#pragma unroll
+        for (int t = 0; t < (TAPS == 9 ? 9 : 0); ++t) {
+          const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) b_mask[jb] |= 1u << t;
+        }
+        b_base[jb] = ((unsigned)(b * Cb) * p.HW + hw) * 64u + seg_src;
+      }
+    }
+  }
+  auto stage = [&](int c) {
+    const int cc = TAPS == 9 ? c / 9 : c, tap = c - cc * TAPS;           // scalar
+    const unsigned a_soff = (unsigned)c * a_chunk2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        dma16(a_rs, As + s * G::A_PLANE + (32 * wid + 16 * h) * 64, a_voff + h * 1024u, a_soff + s * a_plane2);
+    const int shift = TAPS == 9 ? ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * 64 : 0;
+    const unsigned b_soff = (unsigned)cc * (unsigned)p.HW * 64u;
+#pragma unroll
+    for (int jb = 0; jb < G::BBLK; ++jb) {
+      const unsigned dead = (((b_mask[jb] >> tap) & 1u) ^ 1u) << 31;      // halo / out-of-range rows: DMA of zeros
+      const unsigned vo = (b_base[jb] + (unsigned)shift) | dead;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        dma16(b_rs, Bs + s * G::B_PLANE + ((TN / 4) * wid + 16 * jb) * 64, vo, b_soff + s * b_ps);
+    }
+  };
+
+  EP ep;
+  ep.preload(p, m0, n0, TN, M, Nn, tid);
+
+  floatx16 acc[2][G::NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < G::NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * (TN / 2);
+  const int fk = lane >> 5, fc = lane & 31;
+  const int fsw = (fc >> 2) & 3;                                          // f(row) of the operand rows this lane reads
+  const unsigned char* a_rd = As + (wm0 + fc) * 64;
+  const unsigned char* b_rd = Bs + (wn0 + fc) * 64;
+  const int ko0 = ((0 + fk) ^ fsw) * 16, ko1 = ((2 + fk) ^ fsw) * 16;     // slot of k segment (2 kk + fk)
+
+#define STK_D_FRAGS(KO)                                                                                   \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
+      a[i][s] = *reinterpret_cast<const halfx8*>(a_rd + s * G::A_PLANE + i * 32 * 64 + (KO));              \
+    _Pragma("unroll") for (int j = 0; j < G::NJ; ++j)                                                       \
+      b[j][s] = *reinterpret_cast<const halfx8*>(b_rd + s * G::B_PLANE + j * 32 * 64 + (KO));              \
+  }
+  // three products per tile, the two cross terms first (fixed accumulation order)
+  constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};
+#define STK_D_MFMAS                                                                                        \
+  _Pragma("unroll") for (int pr = 0; pr < 3; ++pr) _Pragma("unroll") for (int i = 0; i < 2; ++i)             \
+    _Pragma("unroll") for (int j = 0; j < G::NJ; ++j) {                                                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][SA[pr]], b[j][SB[pr]], acc[i][j], 0, 0, 0);   \
+    }
+
+  halfx8 a[2][2], b[G::NJ][2];
+  stage(c_begin);
+  for (int c = c_begin; c <= c_last; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk c has landed ...
+    __syncthreads();                                   // ... and so has everybody else's
+    STK_D_FRAGS(ko0)
+    STK_D_MFMAS
+    STK_D_FRAGS(ko1)
+    __syncthreads();                                   // nobody reads the tile any more (the barrier waits lgkmcnt(0))
+    if (c < c_last) stage(c + 1);                      // chunk c + 1 streams in under the second half's MFMAs
+    STK_D_MFMAS
+  }
+#undef STK_D_MFMAS
+#undef STK_D_FRAGS
+
+  ep.stage(lds, tid);
+  ep.init(p, 0, zs);
+#pragma unroll
+  for (int j = 0; j < G::NJ; ++j) {
+    const int n = n0 + wn0 + j * 32 + fc;
+    const bool nok = n < Nn;
+    ep.col(p, nok ? n : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] *= unscale;
+      ep.strip(p, m0 + wm0 + i * 32 + 4 * fk, M, nok, nok ? n : 0, acc[i][j]);
+    }
+  }
+}
+
+}  // namespace x2d

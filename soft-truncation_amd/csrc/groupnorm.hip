@@ -604,6 +604,141 @@ __global__ __launch_bounds__(256) void gn_bound_kernel(const float* __restrict__
   rec[threadIdx.x] = threadIdx.x == 0 ? __fmaf_rn(g, sqrt_lm1, b) * keep_scale : 0.f;
 }
 
+// ---- forward writing planes --------------------------------------------------------------------------------------
+// GroupNorm (+SiLU) (+dropout) whose output goes to the split convolutions as planes (include/stk.h "Planes"):
+// [split][n][c / 32][pixel][c % 32] fp16.  One workgroup per (sample, 32-channel block) -- a whole number of groups when
+// 32 % (C / G) == 0 -- and a thread per (pixel, 8-channel piece): its 8 loads are channel-strided but 16 lanes x 4 B =
+// 64 B contiguous along pixels, and its two 16-byte stores (hi, lo) land lane-contiguously, 1 KB per wave and plane.
+// The block (32 x HW <= 32768 elements) stays in registers between the statistics and the normalisation, so x is read
+// once; the fp32 NCHW copy of y is optional (the weight gradient and non-split consumers read it; a no-grad pass whose
+// consumers all take planes skips it).  The planes' scale comes from the a-priori bound of gn_bound_kernel, computed
+// here from gamma / beta by every workgroup (C <= 1024 values) -- no pass over y, no dependence between workgroups.
+template <int PASSES>
+__global__ __launch_bounds__(1024) void gn_fwd_pl_kernel(GnArgs a, float* __restrict__ y, unsigned char* __restrict__ planes,
+                                                         long plane_stride, float* __restrict__ rec,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         float eps, float sqrt_lm1) {
+  __shared__ float red[16 * 4 * 4];       // [wave][q][lo sum, lo sumsq, hi sum, hi sumsq]
+  __shared__ float gst[8 * 2];            // [group in block][mean, rstd]
+  __shared__ float bnd[32];
+  const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+  const int C = a.C1 + a.C2, Cb = C >> 5;
+  const int n = blockIdx.x / Cb, cb = blockIdx.x - n * Cb;
+  const int c0 = cb * 32;
+  const float* src = c0 < a.C1 ? a.x1 + ((long)n * a.C1 + c0) * a.HW : a.x2 + ((long)n * a.C2 + (c0 - a.C1)) * a.HW;
+  const int q = tid & 3;                  // 8-channel piece (constant per thread: T % 4 == 0)
+  const int gb = 32 / a.cpg;              // groups in this block
+  const int g_lo = (8 * q) / a.cpg, g_hi = (8 * q + 4) / a.cpg;
+  // shifted sums (shift = first element of the group), as in gn_fwd_flat_kernel
+  const float sh_lo = src[(long)(g_lo * a.cpg) * a.HW], sh_hi = src[(long)(g_hi * a.cpg) * a.HW];
+
+  // scale of the planes: |y| <= (max|gamma| sqrt(L - 1) + max|beta|) / (1 - p)
+  float gm = 0.f, bm = 0.f;
+  for (int c = tid; c < C; c += T) { gm = fmaxf(gm, fabsf(a.gamma[c])); bm = fmaxf(bm, fabsf(a.beta[c])); }
+  gm = wave_max(gm); bm = wave_max(bm);
+  if (lane == 0) { bnd[wave] = gm; bnd[16 + wave] = bm; }
+
+  float v[PASSES][8];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < PASSES; ++k) {
+    const int px = (tid + T * k) >> 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[k][j] = src[(long)(8 * q + j) * a.HW + px];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d0 = v[k][j] - sh_lo, d1 = v[k][4 + j] - sh_hi;
+      s[0] += d0; s[1] += d0 * d0; s[2] += d1; s[3] += d1 * d1;
+    }
+  }
+  // lanes with equal q (lane bits 0..1) -> xor-shuffle over lane bits 2..5
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] += __shfl_xor(s[i], o, 64);
+  if (lane < 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[(wave * 4 + lane) * 4 + i] = s[i];
+  }
+  __syncthreads();
+  if (tid < gb) {
+    // pieces of group `tid`, in a fixed order: (q', half) with (8 q' + 4 half) / cpg == tid, over all waves
+    float s0 = 0.f, s1 = 0.f;
+    for (int qq = 0; qq < 4; ++qq)
+      for (int h = 0; h < 2; ++h)
+        if ((8 * qq + 4 * h) / a.cpg == tid)
+          for (int w = 0; w < nw; ++w) { s0 += red[(w * 4 + qq) * 4 + 2 * h]; s1 += red[(w * 4 + qq) * 4 + 2 * h + 1]; }
+    const float inv_l = 1.f / ((float)a.cpg * (float)a.HW);
+    const float shift = src[(long)(tid * a.cpg) * a.HW];
+    const float md = s0 * inv_l;
+    const float var = fmaxf(s1 * inv_l - md * md, 0.f);
+    const float mean = shift + md, rstd = 1.f / sqrtf(var + eps);
+    gst[2 * tid] = mean; gst[2 * tid + 1] = rstd;
+    const int g = (c0 / a.cpg) + tid;
+    mean_out[n * a.G + g] = mean;
+    rstd_out[n * a.G + g] = rstd;
+  }
+  __syncthreads();
+  float gmax = 0.f, bmax = 0.f;
+  for (int w = 0; w < nw; ++w) { gmax = fmaxf(gmax, bnd[w]); bmax = fmaxf(bmax, bnd[16 + w]); }
+  const float bound = __fmaf_rn(gmax, sqrt_lm1, bmax) * a.keep_scale;
+  if (blockIdx.x == 0)
+    for (int i = tid; i < 256; i += T) rec[i] = i == 0 ? bound : 0.f;
+  // the power of two that puts the bound in [2^13, 2^14) (x2::pow2_scale_of in conv_x2.h)
+  float sc = 1.f;
+  {
+    const int be = (int)((__float_as_uint(bound) >> 23) & 0xffu);
+    if (be != 0) sc = __uint_as_float((unsigned)min(max(127 + 13 - (be - 127), 1), 254) << 23);
+  }
+  const float m_lo = gst[2 * g_lo], r_lo = gst[2 * g_lo + 1], m_hi = gst[2 * g_hi], r_hi = gst[2 * g_hi + 1];
+  float ga[8], be8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ga[j] = a.gamma[c0 + 8 * q + j]; be8[j] = a.beta[c0 + 8 * q + j]; }
+  unsigned long long seed = a.seed;
+  if (a.drop_p > 0.f && a.seed_dev) seed += *a.seed_dev;
+  float* yo = y ? y + ((long)n * C + c0) * a.HW : nullptr;
+  unsigned char* po = planes + ((long)n * Cb + cb) * a.HW * 64 + q * 16;
+#pragma unroll
+  for (int k = 0; k < PASSES; ++k) {
+    const int px = (tid + T * k) >> 2;
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float mean = j < 4 ? m_lo : m_hi, rstd = j < 4 ? r_lo : r_hi;
+      const float u = ga[j] * ((v[k][j] - mean) * rstd) + be8[j];
+      float r = a.act ? silu_f(u) : u;
+      if (a.drop_p > 0.f) {
+        const unsigned long long flat = ((unsigned long long)n * C + (c0 + 8 * q + j)) * a.HW + px;
+        r = (stk_uniform(seed, flat) >= a.drop_p) ? r * a.keep_scale : 0.f;
+      }
+      t[j] = r;
+      if (yo) yo[(long)(8 * q + j) * a.HW + px] = r;
+    }
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v0 = sc * t[2 * j], v1 = sc * t[2 * j + 1];
+      const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+      const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      hi[j] = __builtin_bit_cast(unsigned, h2{h0, h1});
+      lo[j] = __builtin_bit_cast(unsigned, h2{l0, l1});
+    }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<u4*>(po + (long)px * 64) = u4{hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<u4*>(po + plane_stride + (long)px * 64) = u4{lo[0], lo[1], lo[2], lo[3]};
+  }
+}
+
+// shapes the fused kernel takes: whole groups per 32-channel block, both sources in whole blocks, the block in registers
+static inline bool gn_pl_fused_ok(int C1, int C2, int HW, int G) {
+  const int C = C1 + C2;
+  if (C % 32 || C1 % 32 || C % G) return false;
+  const int cpg = C / G;
+  if (cpg > 32 || 32 % cpg || cpg < 4) return false;        // a thread's 4-channel halves must not straddle groups
+  return HW == 16 || HW == 64 || HW == 256 || HW == 1024;
+}
+
 extern "C" {
 
 int stk_gn_bound_f32(const float* gamma, const float* beta, int C, int G, int HW, float drop_p, float* rec, void* stream) {
@@ -656,6 +791,44 @@ int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float
   STK_CHECK_LAUNCH();
   return STK_OK;
 }
+
+/* = stk_gn_fwd_f32 (y may be NULL when no consumer reads the fp32 copy) + stk_gn_bound_f32 (rec) +
+ * stk_split_planes_f32 (planes), in one pass over x where the shape allows (gn_pl_fused_ok), else as those three. */
+int stk_gn_fwd_pl_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
+                      void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
+                      float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream) {
+  const int C = C1 + C2;
+  if (!x1 || !gamma || !beta || !planes || !rec || !mean || !rstd || N <= 0 || HW <= 0 || G <= 0 || C1 <= 0 || C2 < 0 ||
+      C % G || (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f)
+    return STK_EINVAL;
+  const long plane_stride = (long)N * ((C + 31) / 32) * HW * 64;
+  if (2 * plane_stride >= 0x7fffffffL) return STK_EUNSUPPORTED;
+  if (gn_pl_fused_ok(C1, C2, HW, G)) {
+    GnArgs a;
+    a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
+    a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p);
+    a.seed = seed; a.seed_dev = seed_dev;
+    const int items = HW * 4, T = items < 1024 ? items : 1024, passes = items / T;
+    const float sq = sqrtf((float)((long)a.cpg * HW) - 1.f);
+    const dim3 grid((unsigned)(N * (C / 32)));
+#define STK_GN_PL(P)                                                                                               \
+  hipLaunchKernelGGL((gn_fwd_pl_kernel<P>), grid, dim3(T), 0, (hipStream_t)stream, a, y, static_cast<unsigned char*>(planes), \
+                     plane_stride, rec, mean, rstd, eps, sq)
+    if (passes == 1) STK_GN_PL(1); else if (passes == 2) STK_GN_PL(2); else STK_GN_PL(4);
+#undef STK_GN_PL
+    STK_CHECK_LAUNCH();
+    return STK_OK;
+  }
+  if (!y) return STK_EINVAL;          // the unfused route goes through the fp32 copy
+  int rc = stk_gn_fwd_f32(x1, C1, x2, C2, gamma, beta, y, mean, rstd, N, HW, G, eps, act, drop_p, seed, seed_dev, ws, stream);
+  if (rc) return rc;
+  rc = stk_gn_bound_f32(gamma, beta, C, G, HW, drop_p, rec, stream);
+  if (rc) return rc;
+  return stk_split_planes_f32(y, N, C, HW, rec, 256, planes, stream);
+}
+
+/* 1 if stk_gn_fwd_pl_f32 takes this shape in one pass (and therefore accepts y = NULL) */
+int stk_gn_fwd_pl_fused(int C1, int C2, int HW, int G) { return gn_pl_fused_ok(C1, C2, HW, G) ? 1 : 0; }
 
 int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, int C2, const float* gamma,
                    const float* beta, const float* mean, const float* rstd, float* dx1, float dx1_beta, float* dx2,

@@ -104,17 +104,37 @@ __device__ __forceinline__ float row_sum(const float* __restrict__ p, int HW, in
   }
   return s;
 }
+// AMAX: also track max |dy| of the channel (the sums need every element anyway) and leave it in amax[c] -- a planes scale
+// record of the gradient tensor (include/stk.h "Planes") with one entry per channel, zero-filled up to 256 entries, so
+// the data-gradient call that follows needs no |dy| pass of its own.
+template <bool AMAX>
+__device__ __forceinline__ float row_sum_max(const float* __restrict__ p, int HW, int lane, bool vec, float& m) {
+  float s = 0.f;
+  if (vec) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    for (int i = lane; i < (HW >> 2); i += 64) {
+      const float4 v = p4[i];
+      s += (v.x + v.y) + (v.z + v.w);
+      if (AMAX) m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  } else {
+    for (int i = lane; i < HW; i += 64) { s += p[i]; if (AMAX) m = fmaxf(m, fabsf(p[i])); }
+  }
+  return s;
+}
+template <bool AMAX>
 __global__ __launch_bounds__(1024) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ rows,
                                                          int rows_stride, float* __restrict__ dbias, int N, int C,
-                                                         int HW, float alpha) {
+                                                         int HW, float alpha, float* __restrict__ amax) {
   __shared__ float red[16];
+  __shared__ float redm[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = blockIdx.x;
   const bool vec = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
-  float tot = 0.f;
+  float tot = 0.f, mx = 0.f;
   for (int n = wv; n < N; n += 32) {
     const int n2 = n + 16;
-    float s0 = row_sum(dy + ((long)n * C + c) * HW, HW, lane, vec);
-    float s1 = n2 < N ? row_sum(dy + ((long)n2 * C + c) * HW, HW, lane, vec) : 0.f;
+    float s0 = row_sum_max<AMAX>(dy + ((long)n * C + c) * HW, HW, lane, vec, mx);
+    float s1 = n2 < N ? row_sum_max<AMAX>(dy + ((long)n2 * C + c) * HW, HW, lane, vec, mx) : 0.f;
     s0 = alpha * wave_sum(s0);
     s1 = alpha * wave_sum(s1);
     if (rows && lane == 0) {
@@ -124,13 +144,21 @@ __global__ __launch_bounds__(1024) void bias_grad_kernel(const float* __restrict
     tot += s0;
     if (n2 < N) tot += s1;
   }
-  if (lane == 0) red[wv] = tot;
+  if (AMAX) mx = wave_max(mx);
+  if (lane == 0) { red[wv] = tot; if (AMAX) redm[wv] = mx; }
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q];
-    dbias[c] += t;
+    if (dbias) dbias[c] += t;
+    if (AMAX) {
+      float m = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) m = fmaxf(m, redm[q]);
+      amax[c] = m;
+      for (int i = c + C; i < 256; i += C) amax[i] = 0.f;
+    }
   }
 }
 // dbias[c] += sum_n src[n*stride + c].  32 channels per 256-thread block: thread (c = t%32, part = t/32)
@@ -284,12 +312,30 @@ int stk_softmax_bwd_f32(const float* y, const float* dy, float* dx, long rows, i
   return STK_OK;
 }
 
+/* stk_bias_grad_f32 that also leaves a planes scale record of dy in amax[0..256): per-channel max |dy| (C <= 256 entries,
+ * zeros behind them).  One pass over dy for maps below 64 x 64; larger maps take the two calls it stands for. */
+int stk_bias_grad_amax_f32(const float* dy, int N, int C, int HW, float alpha, float* dtemb, int temb_stride, float* dbias,
+                           float* amax, float* ws, void* stream) {
+  if (!dy || !amax || N <= 0 || C <= 0 || C > 256 || HW <= 0 || (!dtemb && !dbias && !ws)) return STK_EINVAL;
+  if (HW < 4096) {
+    hipLaunchKernelGGL(bias_grad_kernel<true>, dim3((unsigned)C), dim3(1024), 0, S(stream), dy, dtemb, temb_stride, dbias, N,
+                       C, HW, alpha, amax);
+    STK_CHECK_LAUNCH();
+    return STK_OK;
+  }
+  if (dtemb || dbias) {
+    const int rc = stk_bias_grad_f32(dy, N, C, HW, alpha, dtemb, temb_stride, dbias, ws, stream);
+    if (rc) return rc;
+  }
+  return stk_amax_partial_f32(dy, (long)N * C * HW, amax, stream);
+}
+
 int stk_bias_grad_f32(const float* dy, int N, int C, int HW, float alpha, float* dtemb, int temb_stride, float* dbias,
                       float* ws, void* stream) {
   if (!dy || N <= 0 || C <= 0 || HW <= 0 || (!dtemb && !ws) || (!dtemb && !dbias)) return STK_EINVAL;
   if (dbias && HW < 4096) {
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)C), dim3(1024), 0, S(stream), dy, dtemb, temb_stride, dbias, N, C, HW,
-                       alpha);
+    hipLaunchKernelGGL(bias_grad_kernel<false>, dim3((unsigned)C), dim3(1024), 0, S(stream), dy, dtemb, temb_stride, dbias, N,
+                       C, HW, alpha, (float*)nullptr);
     STK_CHECK_LAUNCH();
     return STK_OK;
   }

@@ -64,11 +64,84 @@ def allreduce_flat_(flat_grad, n, bucket_mb=64.0, average=True, group=None):
   return len(ranges)
 
 
+class OverlappedExchange:
+  """Gradient all-reduce overlapped with the backward pass of the LAST micro-batch of a step.
+
+  The engine's backward is a fixed launch sequence over one flat gradient buffer (engine/executor.py).  Armed on an
+  executor, it cuts that sequence where buckets of the buffer become final -- from the top of the buffer down, which
+  is the order the backward finishes them -- and calls :meth:`ready` between the cuts; `ready` starts the bucket's
+  asynchronous all-reduce, which RCCL runs on its own stream behind the launches made so far while the next segment
+  computes.  :meth:`finish` (from ``sync_gradients``) reduces whatever was not covered, waits once, and averages.
+  Replaces the reference's ``torch.nn.DataParallel`` gather (models/utils.py:94) -- with the same sums: a bucket is
+  only handed over after its last writer, so the result equals the exchange-after-backward path bit for bit."""
+
+  def __init__(self, executor, bucket_mb=64.0, group=None):
+    self.ex, self.group = executor, group
+    self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
+    self.handles, self.covered, self.flat = [], [], None
+
+  def arm(self):
+    self.flat = self.ex.ensure_flat()
+    self.handles, self.covered = [], []
+    self.ex.grad_bucket_elems = self.bucket_elems
+    self.ex.grad_hook = self.ready
+    return self
+
+  def ready(self, lo, hi):
+    if hi > lo:
+      self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+      self.covered.append((lo, hi))
+
+  def finish(self, average=True):
+    """Reduce the ranges no segment handed over (a backward that never ran, unused parameters), wait, average."""
+    self.ex.grad_hook = None
+    flat, n = self.flat, self.flat.n_train
+    pos = 0
+    for lo, hi in sorted(self.covered):
+      if lo > pos:
+        self.ready(pos, lo)
+      pos = max(pos, hi)
+    if pos < n:
+      self.ready(pos, n)
+    for h in self.handles:
+      h.wait()
+    if average:
+      flat.grad[:n].div_(dist.get_world_size(self.group))
+    nb = len(self.handles)
+    self.handles, self.covered = [], []
+    return nb
+
+
+_armed = {}      # id(FlatParams) -> OverlappedExchange armed for the current step
+
+
+def _default_bucket_mb():
+  import os
+  return float(os.environ.get('STK_DDP_BUCKET_MB', '64'))
+
+
+def arm_overlap(model, bucket_mb=None):
+  """Called by the training step right before the backward of its last micro-batch (losses.get_step_fn): from then on
+  finished gradient buckets are all-reduced while the backward is still running.  No-op in a single process and for
+  models that are not on the engine."""
+  if not is_distributed():
+    return None
+  net = getattr(model, 'module', model)
+  engine = getattr(net, 'engine', None)
+  if engine is None:
+    return None
+  ex = engine()
+  x = OverlappedExchange(ex, _default_bucket_mb() if bucket_mb is None else bucket_mb).arm()
+  _armed[id(x.flat)] = x
+  return x
+
+
 def sync_gradients(optimizer, params=None, bucket_mb=64.0):
   """Average gradients across ranks before clipping (no-op in a single process).
 
-  Flat-backed parameters (the score network) go through ``allreduce_flat_``; any other
-  parameter list is flattened into one temporary bucket."""
+  Flat-backed parameters (the score network) go through ``allreduce_flat_`` -- or, when the step armed an
+  :class:`OverlappedExchange`, only wait for the buckets that are already in flight; any other parameter list is
+  flattened into one temporary bucket."""
   if not is_distributed():
     return
   flat = getattr(optimizer, '_flat', None)
@@ -78,7 +151,11 @@ def sync_gradients(optimizer, params=None, bucket_mb=64.0):
     except RuntimeError:
       flat = None
   if flat is not None:
-    allreduce_flat_(flat.grad, flat.n_train, bucket_mb=bucket_mb)
+    armed = _armed.pop(id(flat), None)
+    if armed is not None:
+      armed.finish()
+    else:
+      allreduce_flat_(flat.grad, flat.n_train, bucket_mb=bucket_mb)
     return
   if params is None:
     params = [p for g in optimizer.param_groups for p in g['params']]

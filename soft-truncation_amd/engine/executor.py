@@ -89,6 +89,51 @@ class Program:
     self.wp_counts = (0, 0)      # entries: forward only, forward + data gradient
     self.wp_items = 0
     self.wp_frozen = 0           # entries valid under Executor.frozen_weights()
+    self._segments = {}          # bucket_elems -> backward segments for the overlapped gradient exchange
+
+  def backward_segments(self, n_train, bucket_elems):
+    """Cut the backward launch sequence where buckets of the flat gradient buffer become final.
+
+    Returns [(op_end, [(lo, hi), ...]), ...]: after the first `op_end` ops of the backward order have run, the listed
+    ranges of the flat gradient buffer (float offsets) will not be written again in this backward.  Buckets are formed
+    from the TOP of the buffer down: the layout is module order (engine/flat.py), the backward visits the modules in
+    reverse, so high offsets finish first; the stacked time-embedding projections at the bottom finish last."""
+    key = int(bucket_elems)
+    segs = self._segments.get(key)
+    if segs is not None:
+      return segs
+    from .graph import Tensor
+    ops = list(reversed(self.graph.ops))
+    last = {}                                   # flat offset of a parameter -> index of its last writer
+    size = {}
+    for i, op in enumerate(ops):
+      for v in vars(op).values():
+        if isinstance(v, Tensor) and v.space == 'param' and v.goff is not None:
+          last[v.goff] = i
+          size[v.goff] = v.numel
+    # walk the parameters from the top of the buffer down, closing a bucket every `bucket_elems`
+    offs = sorted(last, reverse=True)
+    buckets, hi, ready = [], n_train, -1
+    for k, off in enumerate(offs):
+      ready = max(ready, last[off])
+      if hi - off >= key or k == len(offs) - 1:
+        lo = 0 if k == len(offs) - 1 else off
+        buckets.append((lo, hi, ready))
+        hi = lo
+    if not offs:
+      buckets = [(0, n_train, -1)]
+    # a bucket is ready once its own AND all earlier (higher) buckets' writers ran: keep the cut points monotone
+    segs, run = [], -1
+    for lo, hi, ready in buckets:
+      run = max(run, ready)
+      if segs and segs[-1][0] == run + 1:
+        segs[-1][1].append((lo, hi))
+      else:
+        segs.append((run + 1, [(lo, hi)]))
+    if segs[-1][0] != len(ops):                 # ops after the last parameter writer (input-gradient tail)
+      segs.append((len(ops), []))
+    self._segments[key] = segs
+    return segs
 
   def build_wp(self, lib, param_base):
     g = self.graph
@@ -162,6 +207,10 @@ class Executor:
     # forward; a debugging switch, results are bit-identical
     self.use_wp = os.environ.get('STK_WP', '1') != '0'
     self._frozen = 0
+    # gradient exchange overlapped with the backward (engine/ddp.py): when set, run_backward cuts its launch sequence
+    # into segments and calls grad_hook(lo, hi) as soon as a bucket [lo, hi) of the flat gradient buffer is final
+    self.grad_hook = None
+    self.grad_bucket_elems = 16 << 20
 
   # -- parameters ---------------------------------------------------------------------------------
   def set_backend(self, backend):
@@ -253,9 +302,10 @@ class Executor:
       rt.dypl = rt.pl + prog.graph.pl_bytes
     return rt
 
-  def _replay(self, c, direction, training):
-    """Replay (capturing on first use) the hipGraph of one direction of this context."""
-    key = (direction, training)
+  def _replay(self, c, direction, training, span=None):
+    """Replay (capturing on first use) the hipGraph of one direction of this context; `span` = (begin, end) restricts a
+    backward graph to that slice of the backward op order (segments of the overlapped gradient exchange)."""
+    key = (direction, training) if span is None else (direction, training, span)
     g = c.graphs.get(key)
     if g is None:
       ops = c.prog.graph.ops
@@ -269,8 +319,11 @@ class Executor:
           if direction == 'fwd':
             for op in ops:
               op.forward(rt)
-          else:
+          elif span is None:
             for op in reversed(ops):
+              op.backward(rt)
+          else:
+            for op in list(reversed(ops))[span[0]:span[1]]:
               op.backward(rt)
       except Exception as e:   # capture is an optimisation: report, disable, run eagerly
         warnings.warn(f'hipGraph capture failed ({e!r}); continuing with eager launches')
@@ -323,7 +376,34 @@ class Executor:
     o = g.output
     c.gact[o.goff:o.goff + o.numel].view(o.shape).copy_(gout)
     done = False
-    if self._graphs_on() and rt.seed_dev is not None:
+    hook = self.grad_hook
+    if hook is not None:
+      # overlapped exchange: segment by segment, handing finished buckets to the hook (which starts their all-reduce
+      # on the communicator's stream, ordered behind the launches made so far)
+      segs = prog.backward_segments(flat.n_train, self.grad_bucket_elems)
+      graphs = self._graphs_on() and rt.seed_dev is not None
+      if not graphs:
+        rt.gbase['act'] = c.gact.data_ptr()
+        rt.gbase['param'] = flat.grad.data_ptr()
+        rt.stream = stk_lib.stream_ptr(flat.device)
+        rt.prof = self.profiler
+      order = list(reversed(g.ops))
+      begin = 0
+      for end, ranges in segs:
+        if end > begin:
+          if not (graphs and self._replay(c, 'bwd', rt.training, (begin, end))):
+            if graphs:            # capture failed half way: finish eagerly with a consistent runtime
+              graphs = False
+              rt.gbase['act'] = c.gact.data_ptr()
+              rt.gbase['param'] = flat.grad.data_ptr()
+              rt.stream = stk_lib.stream_ptr(flat.device)
+            for op in order[begin:end]:
+              op.backward(rt)
+        begin = end
+        for lo, hi in ranges:
+          hook(lo, hi)
+      done = True
+    elif self._graphs_on() and rt.seed_dev is not None:
       done = self._replay(c, 'bwd', rt.training)
     if not done:
       rt.gbase['act'] = c.gact.data_ptr()

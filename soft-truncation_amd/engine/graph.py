@@ -155,17 +155,18 @@ class GroupNormAct(Op):
     return self.drop_p if rt.training else 0.0
 
   def forward(self, rt):
-    rt.lib.gn_fwd_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
-                      rt.v(self.y), rt.v(self.mean), rt.v(self.rstd), self.N, self.HW, self.G, self.eps,
-                      self.act, self._p(rt), (rt.seed + 0x9E3779B1 * self.op_id) & 0xFFFFFFFFFFFFFFFF,
-                      rt.seed_dev, rt.ws, rt.stream)
+    seed = (rt.seed + 0x9E3779B1 * self.op_id) & 0xFFFFFFFFFFFFFFFF
     y = self.y
     if y.pl_maker is self:
-      # consumers take this output as planes: the scale record is the a-priori bound of the affine parameters
-      # (no pass over the data), then the split
-      C = self.C1 + self.C2
-      rt.lib.gn_bound_f32(rt.v(self.gamma), rt.v(self.beta_t), C, self.G, self.HW, self._p(rt), rt.rec(y), rt.stream)
-      rt.lib.split_planes_f32(rt.v(y), self.N, C, self.HW, rt.rec(y), 256, rt.planes(y), rt.stream)
+      # consumers take this output as planes (include/stk.h "Planes"): normalise, bound record and split in one call
+      # (one pass over x for the shapes the library fuses); the scale is the a-priori bound of the affine parameters
+      rt.lib.gn_fwd_pl_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
+                           rt.v(y), rt.planes(y), rt.rec(y), rt.v(self.mean), rt.v(self.rstd), self.N, self.HW, self.G,
+                           self.eps, self.act, self._p(rt), seed, rt.seed_dev, rt.ws, rt.stream)
+      return
+    rt.lib.gn_fwd_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
+                      rt.v(self.y), rt.v(self.mean), rt.v(self.rstd), self.N, self.HW, self.G, self.eps,
+                      self.act, self._p(rt), seed, rt.seed_dev, rt.ws, rt.stream)
 
   def backward(self, rt):
     rt.lib.gn_bwd_f32(rt.g(self.y), rt.v(self.x1), self.C1, rt.v(self.x2), self.C2,
@@ -300,17 +301,26 @@ class Conv(Op):
     if self.temb is not None and self.temb.needs_grad:
       dtemb = rt.g(self.temb) + 4 * self.temb_col
     gb = rt.g(self.bias)
-    if dtemb is not None or gb is not None:
+    g1, g2 = rt.g(self.x1), rt.g(self.x2)
+    pl_dgrad = self.pl_dgrad and (g1 is not None or g2 is not None)
+    dy_rec = rt.v(self.amax) + 4 * 512           # |dy| scale record: planes of dy, reused by the weight gradient
+    rec_done = False
+    if pl_dgrad and self.Cout <= 256 and (dtemb is not None or gb is not None):
+      # the bias gradient reads all of dy: it leaves the per-channel |dy| maxima behind as the scale record
+      lib.bias_grad_amax_f32(gy, self.N, self.Cout, self.OH * self.OW, alpha, dtemb, self.temb_stride, gb, dy_rec,
+                             rt.ws, rt.stream)
+      rec_done = True
+    elif dtemb is not None or gb is not None:
       lib.bias_grad_f32(gy, self.N, self.Cout, self.OH * self.OW, alpha, dtemb, self.temb_stride, gb,
                         rt.ws, rt.stream)
     # data gradient first: its |dy| maxima are reused by the weight gradient (the two are independent otherwise)
     have = 1 if self._kind(lib, 'fwd').endswith('.x2') else 0
     if self.pl_fwd and not self.x_rec_own:
       have = 0                                   # x1's record lives with another layer: the weight gradient measures
-    g1, g2 = rt.g(self.x1), rt.g(self.x2)
-    if self.pl_dgrad and (g1 is not None or g2 is not None):
-      rec = rt.v(self.amax) + 4 * 512            # |dy| partial maxima: reused by the weight gradient below
-      lib.amax_partial_f32(gy, self.y.numel, rec, rt.stream)
+    if pl_dgrad:
+      rec = dy_rec
+      if not rec_done:
+        lib.amax_partial_f32(gy, self.y.numel, rec, rt.stream)
       lib.split_planes_f32(gy, self.N, self.Cout, self.OH * self.OW, rec, 256, rt.dypl, rt.stream)
       rt.timed(self._kind(lib, 'dgrad') + 'p', self.flops, lib.conv2d_dgrad_pl_f32,
                rt.dypl, rec, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),

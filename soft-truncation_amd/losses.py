@@ -15,6 +15,8 @@ The soft-truncation loss itself (time sampling, perturbation, weighting) is per-
 math plus a few element-wise passes over the [B,3,H,W] batch; it is written with the same torch
 expression order as the reference so results are bit-identical on identical inputs.
 """
+import os
+
 import numpy as np
 import torch
 import torch.optim as optim
@@ -169,6 +171,10 @@ def _pick_loss_fn(config, sde, train):
   raise ValueError(f"Discrete training for {sde.__class__.__name__} is not recommended.")
 
 
+# STK_DDP_OVERLAP=0: exchange the gradients after the backward (one bucketed all-reduce) instead of during it
+OVERLAP_EXCHANGE = os.environ.get('STK_DDP_OVERLAP', '1') != '0'
+
+
 def get_step_fn(config, sde, train, optimize_fn=None):
   """One training step: ``step_fn(state, batch) -> losses`` on the CPU (losses.py:218-325).
 
@@ -206,6 +212,9 @@ def get_step_fn(config, sde, train, optimize_fn=None):
       t_min = sde.get_t_min(config)
       for k in range(parts):
         losses = micro_losses(model, batch[per * k: per * (k + 1)], t_min)
+        if k == parts - 1 and OVERLAP_EXCHANGE:
+          # multi-GPU: buckets of the flat gradient buffer are all-reduced as the last backward finishes them
+          ddp.arm_overlap(model)
         torch.mean(losses).backward(retain_graph=True)
         losses_[out_per * k: out_per * (k + 1)] = losses.cpu().detach()
       optimize_fn(optimizer, model.parameters(), step=state['step'])

@@ -88,8 +88,22 @@ def worker(rank, world, port, outdir):
   nb = st.engine.ddp.allreduce_flat_(buf, 1000, bucket_mb=0.001, average=True)     # ~262-element buckets
   assert nb == 4
   assert torch.allclose(buf, torch.arange(1000, dtype=torch.float32) * 1.5)
-  # 2) two training steps on this rank's shard
+  # 2) two training steps on this rank's shard, gradients exchanged DURING the last backward (small buckets so that the
+  #    tiny model has several), then the same with the exchange after the backward: bit-identical
+  os.environ['STK_DDP_BUCKET_MB'] = '0.05'
+  calls = []
+  real = dist.all_reduce
+  dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), real(*a, **k))[1]
+  assert st.losses.OVERLAP_EXCHANGE
   losses, params, shadow = run_steps(st, lib, rank, world, steps=2, global_batch=4)
-  torch.save({'losses': losses, 'params': params, 'shadow': shadow}, os.path.join(outdir, f'rank{rank}.pt'))
+  n_overlapped = len(calls)
+  st.losses.OVERLAP_EXCHANGE = False
+  del calls[:]
+  losses_b, params_b, shadow_b = run_steps(st, lib, rank, world, steps=2, global_batch=4)
+  dist.all_reduce = real
+  assert n_overlapped >= 2 * 3, n_overlapped            # >= 3 buckets per step went out from inside the backward
+  assert torch.equal(params, params_b) and torch.equal(shadow, shadow_b) and torch.equal(losses, losses_b)
+  torch.save({'losses': losses, 'params': params, 'shadow': shadow, 'buckets': n_overlapped},
+             os.path.join(outdir, f'rank{rank}.pt'))
   dist.barrier()
   dist.destroy_process_group()

@@ -50,3 +50,32 @@ def test_two_ranks_match_single_process(st, ref_lib, tmp_path):
   lr = 2e-4
   assert (got[0]['params'] - params).abs().max().item() <= 0.05 * lr * 2
   assert (got[0]['shadow'] - shadow).abs().max().item() <= 0.05 * lr * 2
+
+
+def test_backward_segments_cover_the_gradient_buffer(st, ref_lib):
+  """Program.backward_segments: the buckets partition [0, n_train), come top-down, and a bucket is only released after
+  the last op that writes into it."""
+  import torch
+  from _model_util import build_pair, tiny_config
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, 'vp'), ref_lib)
+  x = torch.randn(2, 3, 16, 16)
+  model(x, torch.rand(2) * 999).sum().backward()
+  ex = model.module.engine()
+  prog = next(iter(ex.programs.values()))
+  n = ex.flat.n_train
+  segs = prog.backward_segments(n, 20000)
+  ranges = [r for _, rs in segs for r in rs]
+  assert len(ranges) >= 3
+  assert ranges[0][1] == n and ranges[-1][0] == 0
+  assert all(a[0] == b[1] for a, b in zip(ranges, ranges[1:]))          # contiguous, descending
+  ends = [e for e, _ in segs]
+  assert ends == sorted(ends) and ends[-1] == len(prog.graph.ops)
+  # no op after a bucket's release point touches a parameter inside it
+  from importlib import import_module
+  Tensor = import_module('soft-truncation_amd.engine.graph').Tensor
+  order = list(reversed(prog.graph.ops))
+  for end, rs in segs:
+    for op in order[end:]:
+      for v in vars(op).values():
+        if isinstance(v, Tensor) and v.space == 'param' and v.goff is not None:
+          assert not any(lo <= v.goff < hi for lo, hi in rs), (type(op).__name__, v.goff, rs)

@@ -99,8 +99,8 @@ PL_CONV_CASES = [
   (4, 96, 16, 16, 96, 3, 0, 0, 0, 0),
   (6, 256, 8, 8, 256, 3, 0, 1, 0, 1),       # K-split (few tiles)
   (3, 256, 4, 4, 256, 3, 0, 0, 1, 0),
-  (4, 256, 16, 16, 256, 1, 0, 0, 1, 1),     # 1x1 Conv2d
-  (4, 256, 16, 16, 256, 1, 1, 0, 0, 0),     # NIN
+  (96, 256, 16, 16, 256, 1, 0, 0, 1, 1),    # 1x1 Conv2d (needs >= 192 tiles: a 1x1 layer has too few chunks to split K)
+  (96, 256, 16, 16, 256, 1, 1, 0, 0, 0),    # NIN
   (5, 128, 12, 20, 160, 3, 0, 0, 0, 0),     # ragged map, 160 rows
 ]
 
@@ -179,3 +179,85 @@ def test_conv_from_planes_apriori_bound(ref_lib, hip_lib):
     call(hip_lib, 'conv2d_fwd_pl_f32', xp, rec, C, w.to(d), 0, None, None, 0, None, 1.0, y, N, H, H, Cout, 3, 3, None, ws, fb)
     err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert err <= 3e-6, (slack, err)
+
+
+GN_PL_CASES = [
+  # N, C1, C2, HW, G, act, drop
+  (4, 128, 0, 1024, 32, 1, 0.0),      # fused: 4 channels per group, 4 passes
+  (3, 256, 0, 256, 32, 1, 0.1),       # fused: 8 per group, dropout
+  (5, 256, 0, 64, 32, 0, 0.0),        # fused, no activation (attention's GroupNorm)
+  (6, 128, 128, 16, 32, 1, 0.0),      # fused, two sources, 4x4 maps
+  (2, 256, 256, 256, 32, 1, 0.0),     # fused: 16 per group, two sources
+  (2, 256, 128, 64, 32, 1, 0.0),      # 12 per group: the unfused route (bound + split after the fp32 kernel)
+  (2, 96, 0, 256, 24, 1, 0.0),        # the 'wide' test family
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', GN_PL_CASES, ids=str)
+def test_gn_forward_to_planes(ref_lib, hip_lib, case):
+  """stk_gn_fwd_pl_f32 on the HIP library against the oracle's composition (GroupNorm restatement, bound, split):
+  the scale record bit for bit, mean / rstd / y at the GroupNorm tolerance, and the planes decoded back (hi + lo) / s
+  against y -- they must carry y to 2^-22."""
+  N, C1, C2, HW, G, act, drop = case
+  C = C1 + C2
+  x1 = rnd(N, C1, HW, seed=1) * 2 + 0.3
+  x2 = rnd(N, C2, HW, seed=2) if C2 else None
+  gamma, beta = rnd(C, seed=3) * 0.5 + 1.0, rnd(C, seed=4) * 0.2
+  out = {}
+  for name, lib in (('ref', ref_lib), ('hip', hip_lib)):
+    d = dev_of(lib)
+    to = lambda t: None if t is None else t.to(d)
+    y = torch.zeros(N, C, HW, device=d)
+    mean, rstd = torch.zeros(N * G, device=d), torch.zeros(N * G, device=d)
+    rec = torch.full((256,), -1.0, device=d)
+    pl = torch.full((int(lib.planes_bytes(N, C, HW)),), 0xAA, dtype=torch.uint8, device=d)
+    ws = torch.zeros(int(lib.gn_ws_bytes(N, C, HW, G)) // 4 + 64, device=d)
+    call(lib, 'gn_fwd_pl_f32', to(x1), C1, to(x2), C2, to(gamma), to(beta), y, pl, rec, mean, rstd, N, HW, G, 1e-6, act,
+         drop, 1234, None, ws)
+    out[name] = dict(y=y.cpu(), mean=mean.cpu(), rstd=rstd.cpu(), rec=rec.cpu(),
+                     pl=pl.cpu().numpy().view(np.float16).reshape(2, N, (C + 31) // 32, HW, 32))
+    if name == 'hip' and int(lib.gn_fwd_pl_fused(C1, C2, HW, G)):
+      # y = NULL: the planes must not change
+      pl2 = torch.full_like(pl, 0x55)
+      call(lib, 'gn_fwd_pl_f32', to(x1), C1, to(x2), C2, to(gamma), to(beta), None, pl2, rec, mean, rstd, N, HW, G, 1e-6, act,
+           drop, 1234, None, ws)
+      assert torch.equal(pl2, pl)
+  r, h = out['ref'], out['hip']
+  assert torch.equal(r['rec'], h['rec']) and float(r['rec'][0]) >= float(r['y'].abs().max())
+  for k in ('y', 'mean', 'rstd'):
+    assert (h[k] - r[k]).abs().max().item() <= 1e-5 * max(r[k].abs().max().item(), 1.0), k
+  m = float(h['rec'].max())
+  s = 2.0 ** (13 - int(np.floor(np.log2(m))))
+  dec = (h['pl'][0].astype(np.float64) + h['pl'][1].astype(np.float64)) / s          # [N, Cb, HW, 32]
+  dec = dec.transpose(0, 1, 3, 2).reshape(N, -1, HW)[:, :C]
+  yy = h['y'].double().numpy()
+  assert np.abs(dec - yy).max() <= max(2.0 ** -22 * np.abs(yy).max(), 2.0 ** -25 / s)
+  assert np.all(h['pl'].reshape(2, N, -1, HW, 32).transpose(0, 1, 2, 4, 3).reshape(2, N, -1, HW)[:, :, C:] == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(8, 128, 1024), (5, 256, 64), (3, 96, 256), (2, 64, 4096)], ids=str)
+def test_bias_grad_with_scale_record(ref_lib, hip_lib, case):
+  """stk_bias_grad_amax_f32: the bias / time-embedding gradients of stk_bias_grad_f32 plus the per-channel |dy| maxima
+  as a scale record (bit-exact: a maximum has no rounding)."""
+  N, C, HW = case
+  dy = rnd(N, C, HW, seed=5) * torch.logspace(-3, 1, N)[:, None, None]
+  res = {}
+  for name, lib in (('ref', ref_lib), ('hip', hip_lib)):
+    d = dev_of(lib)
+    db, dt = torch.ones(C, device=d), torch.zeros(N, C + 8, device=d)
+    rec = torch.full((256,), float('nan'), device=d)
+    ws = torch.zeros(N * C + 64, device=d)
+    call(lib, 'bias_grad_amax_f32', dy.to(d), N, C, HW, 0.5, dt, C + 8, db, rec, ws)
+    rec2 = torch.full((256,), float('nan'), device=d)
+    call(lib, 'bias_grad_amax_f32', dy.to(d), N, C, HW, 0.5, None, 0, None, rec2, ws)       # record only
+    res[name] = (db.cpu(), dt.cpu(), rec.cpu(), rec2.cpu())
+  (rdb, rdt, rrec, _), (hdb, hdt, hrec, hrec2) = res['ref'], res['hip']
+  assert float(hrec.max()) == float(dy.abs().max()) == float(rrec.max())
+  assert not torch.isnan(hrec).any() and float(hrec.min()) >= 0
+  assert float(hrec2.max()) == float(hrec.max())
+  if HW < 4096:
+    assert torch.equal(hrec, rrec)
+  assert (hdb - rdb).abs().max().item() <= 1e-5 * rdb.abs().max().item()
+  assert (hdt - rdt).abs().max().item() <= 1e-5 * rdt.abs().max().item()
