@@ -214,6 +214,14 @@ int stk_conv2d_dgrad_pl_f32(const void* dypl, const float* dyamax, const float* 
                             float beta1, float* dx2, int C2, float beta2, float alpha, int N, int H, int W, int Cout,
                             int KH, int KW, const void* wp, void* ws, long ws_bytes, void* stream);
 
+/* 3x3 / stride 1 / pad 1 weight gradient (w_layout 0) with BOTH operands as planes: dw += alpha * sum dy * x, the planes
+ * being the ones the layer's forward (x) and data-gradient (dy) calls read.  H = W a power of two >= 8, channel counts
+ * multiples of 32 (stk_conv2d_wgrad_pl_ok); ws: stk_conv2d_wgrad_pl_ws_bytes bytes for the K-split slabs. */
+int stk_conv2d_wgrad_pl_ok(int N, int H, int W, int Cin, int Cout);
+long stk_conv2d_wgrad_pl_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int stk_conv2d_wgrad_pl_f32(const void* xpl, const float* xrec, const void* dypl, const float* dyrec, float* dw,
+                            float alpha, float* ws, long ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
+
 /* dtemb[n*temb_stride + c] = alpha * sum_hw dy[n,c,:]  (written; may be NULL);
  * dbias[c] += alpha * sum_{n,hw} dy[n,c,:]              (accumulated; may be NULL).
  * ws: >= N*C floats of scratch (only used when dtemb is NULL). */

@@ -596,6 +596,7 @@ __global__ __launch_bounds__(256) void slab_dgrad_kernel(ConvP p, int splits, in
 #include "conv_x2.h"
 #include "conv_pl.h"
 #include "conv_x2d.h"
+#include "conv_x2w.h"
 
 // dw (in the weight's own layout) += alpha * sum over splits of slab[tap][co][ci]
 // Threads walk the SLAB order four elements at a time, so the `splits` reads per element are 16-byte and coalesced
@@ -1326,6 +1327,40 @@ int stk_conv2d_dgrad_pl_f32(const void* dypl, const float* dyamax, const float* 
   const X3Plan xr = x3_plan(p, Cout, Cout, 0, p.Cin, Ng);
   if (!ws || ws_bytes < x3_ws_bytes(xr, p.Cin, Cout, p.taps)) return STK_EINVAL;
   return launch_x3<EpDgrad>(p, xr, nullptr, Cout, nullptr, 0, p.Cin, Ng, 1, ws, (hipStream_t)stream, wp, nullptr, dypl, dyamax);
+}
+
+/* 3x3 / stride 1 / pad 1 weight gradient with x and dy given as planes (conv_x2w.h) */
+int stk_conv2d_wgrad_pl_ok(int N, int H, int W, int Cin, int Cout) { return x2w::plan(N, H, W, Cin, Cout).ok; }
+
+long stk_conv2d_wgrad_pl_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+  const x2w::Plan q = x2w::plan(N, H, W, Cin, Cout);
+  return q.ok ? (long)q.splits * q.slab * 4 + 256 : 0;
+}
+
+int stk_conv2d_wgrad_pl_f32(const void* xpl, const float* xrec, const void* dypl, const float* dyrec, float* dw,
+                            float alpha, float* ws, long ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream) {
+  if (!xpl || !xrec || !dypl || !dyrec || !dw || !ws) return STK_EINVAL;
+  const x2w::Plan q = x2w::plan(N, H, W, Cin, Cout);
+  if (!q.ok) return STK_EUNSUPPORTED;
+  if (ws_bytes < (long)q.splits * q.slab * 4) return STK_EINVAL;
+  x2w::Args a = {};
+  a.dypl = static_cast<const unsigned char*>(dypl); a.dyrec = dyrec; a.dy_ps = pl::plane_bytes(N, Cout, H * W);
+  a.xpl = static_cast<const unsigned char*>(xpl); a.xrec = xrec; a.x_ps = pl::plane_bytes(N, Cin, H * W);
+  if (2 * a.dy_ps >= 0x7fffffffL || 2 * a.x_ps >= 0x7fffffffL) return STK_EUNSUPPORTED;
+  a.part = ws; a.part_stride = q.slab;
+  a.N = N; a.H = H; a.W = W; a.HW = H * W; a.Cin = Cin; a.Cout = Cout; a.Cob = Cout / 32; a.Cib = Cin / 32;
+  a.tiles_co = stk_cdiv(Cout, 128); a.tiles_ci = Cin / 32;
+  a.nchunks_total = (int)((long)N * H * W / 32); a.chunks_per_split = q.chunks_per_split;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)(a.tiles_co * a.tiles_ci * q.splits));
+  if (W >= 32) hipLaunchKernelGGL((x2w::wgrad_kernel<32>), grid, dim3(256), 0, s, a);
+  else if (W == 16) hipLaunchKernelGGL((x2w::wgrad_kernel<16>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((x2w::wgrad_kernel<8>), grid, dim3(256), 0, s, a);
+  STK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((q.slab + 3) / 4)), dim3(256), 0, s, ws, dw, q.slab, q.splits,
+                     q.slab, alpha, 0, Cout, Cin, 9);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
 }
 
 /* which kernel family a call with full scratch takes: 0/1 = f32-input MFMA with 64/128 tiles, 2 = bf16 three-way

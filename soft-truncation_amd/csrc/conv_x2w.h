@@ -1,0 +1,211 @@
+// conv_x2w.h -- 3x3 / stride 1 / pad 1 weight gradient on the fp16 two-way split with BOTH operands read as planes
+// (conv_pl.h), staged by LDS-DMA and fed to the MFMAs through the LDS transpose read, for gfx950.
+// Included by conv.hip inside its anonymous namespace, after conv_x2d.h.
+//
+//   dW[co, ci, kh, kw] = sum over pixels p of  dy[co, p] * x[ci, p + (kh - 1) W + (kw - 1)]        (zero outside the map)
+//
+// i.e. nine GEMMs D = A B with M = co, N = ci and K = PIXELS.  Planes are [pixel][32 channels]: the contraction index is
+// the slow one for both operands, exactly the case `ds_read_b64_tr_b16` exists for -- a 16-lane group reads a
+// [4 pixels][16 channels] block and every lane receives 4 consecutive PIXELS of its channel (semantics pinned by
+// tools/_probe/tr.hip on the hardware).  What that buys over x2::wgrad3_kernel (fp32 NCHW operands, split on the fly,
+// one kernel row per workgroup, three shifted windows of x written to LDS per chunk):
+//   * a tap shift is a shift by whole 64-byte LDS rows, so ONE staged halo tile of x (the chunk's pixels, one row above
+//     and below, one column left and right) serves all nine taps: 14 KB of x + 16 KB of dy per 32-pixel chunk and
+//     216 MFMAs per workgroup, against 46 KB per 144;
+//   * no conversion and no ds_write at all: both tiles arrive by `buffer_load_dwordx4 ... lds`, halo pixels outside the
+//     map as zeros from the buffer range check; the two LDS buffers alternate, one barrier per chunk;
+//   * the planes are the ones the forward (x) and the data gradient (dy) already use -- no fp32 copy of either tensor
+//     is read, so GroupNorm need not write one for its 3x3 consumers.
+// Workgroup = 128 output channels (wave w owns 32-block w) x 32 input channels x 9 taps, over a slab of the pixels;
+// partial slabs [tap][Cout][Cin] are summed by splitk_reduce_kernel in a fixed order, as for the other weight gradients.
+#pragma once
+
+namespace x2w {
+
+typedef short s4 __attribute__((__vector_size__(8)));
+typedef __attribute__((address_space(3))) s4 lds_s4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int A_BLK = 32 * 64;              // one 32-channel block of dy for a chunk: 32 pixels x 64 bytes
+constexpr int A_PLANE = 4 * A_BLK;          // 8192
+constexpr int B_INSTR = 7;                  // DMA instructions (16 pixels each) per plane of the x halo tile
+constexpr int B_PLANE = B_INSTR * 16 * 64;  // 7168 (112 pixel slots; <= 102 used)
+constexpr int BUF = 2 * A_PLANE + 2 * B_PLANE;   // 30720
+constexpr int LDS = 2 * BUF;                     // 61440: two workgroups per CU
+
+struct Args {
+  const unsigned char* dypl; const float* dyrec; long dy_ps;     // planes of dy [N, Cout, H, W], scale record, bytes per plane
+  const unsigned char* xpl; const float* xrec; long x_ps;        // planes of x  [N, Cin,  H, W]
+  float* part; long part_stride;                                 // slabs [split][tap][Cout][Cin]
+  int N, H, W, HW, Cin, Cout, Cob, Cib;                          // Cob / Cib: 32-channel blocks
+  int tiles_co, tiles_ci, nchunks_total, chunks_per_split;
+};
+
+__device__ __forceinline__ halfx8 cat(s4 lo, s4 hi) {
+  typedef short s8 __attribute__((__vector_size__(16)));
+  const s8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(halfx8, v);
+}
+
+// COLS = min(W, 32): pixels of a chunk per map row (a chunk is 32 consecutive pixels = 32 / COLS whole rows, or a
+// 32-pixel piece of one row when W > 32)
+template <int COLS>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(Args a) {
+  constexpr int ROWS = 32 / COLS, TP = COLS + 2, TR = ROWS + 2;
+  static_assert(TR * TP <= B_INSTR * 16, "halo tile exceeds the staged slots");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float sa = x2::pow2_scale_of(x2::block_amax(a.dyrec, x2::NPART, reinterpret_cast<float*>(lds)));
+  const float sb = x2::pow2_scale_of(x2::block_amax(a.xrec, x2::NPART, reinterpret_cast<float*>(lds)));
+  const float unscale = 1.f / (sa * sb);
+  const int ntiles = a.tiles_co * a.tiles_ci;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = id % ntiles, zs = id / ntiles;
+  const int tco = tile % a.tiles_co, tci = tile / a.tiles_co;
+  const int co_blk = tco * 4 + wid;                                     // this wave's 32 output channels
+  const bool co_live = co_blk < a.Cob;
+  const int c_begin = zs * a.chunks_per_split;
+  const int c_last = min(a.nchunks_total, c_begin + a.chunks_per_split) - 1;
+
+  // ---- DMA sources ----------------------------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t a_rs = x3::make_rsrc(a.dypl, 2L * a.dy_ps);
+  const __amdgpu_buffer_rsrc_t b_rs = x3::make_rsrc(a.xpl, 2L * a.x_ps);
+  const unsigned piece = (unsigned)(lane & 3) * 16u;
+  // dy: wave w stages block co_blk: (half, plane) -> 16 pixels x 64 bytes, contiguous in the planes
+  const unsigned a_voff = (co_live ? 0u : 0x80000000u) | ((unsigned)(lane >> 2) * 64u + piece);
+  // x halo tile: slot s = 16 j + lane / 4 holds tile pixel (ty, tx) = (s / TP, s % TP) = map pixel (y0 - 1 + ty, x0 - 1 + tx);
+  // wave w issues instructions j = w and w + 4
+  int b_rel[2], b_ty[2], b_tx[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = wid + 4 * u, s = 16 * j + (lane >> 2);
+    b_ty[u] = s / TP; b_tx[u] = s - b_ty[u] * TP;
+    if (j >= B_INSTR || s >= TR * TP) b_ty[u] = -1000000;               // never inside the map
+    b_rel[u] = ((b_ty[u] - 1) * a.W + (b_tx[u] - 1)) * 64 + (int)piece;
+  }
+  auto stage = [&](int c, unsigned char* buf) {
+    const int p0 = c * 32;                                               // first pixel of the chunk, over N * HW
+    const int b = p0 / a.HW, hw0 = p0 - b * a.HW;
+    const int y0 = hw0 / a.W, x0 = hw0 - y0 * a.W;
+    const unsigned a_soff = ((unsigned)(b * a.Cob + co_blk) * (unsigned)a.HW + (unsigned)hw0) * 64u;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(buf + s * A_PLANE + wid * A_BLK + h * 1024), 16,
+                                                 (int)(a_voff + h * 1024u), (int)(a_soff + s * (unsigned)a.dy_ps), 0, 0);
+    const int b_chunk = ((b * a.Cib + tci) * a.HW + hw0) * 64;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (wid + 4 * u >= B_INSTR) continue;                              // wave-uniform
+      const int yy = y0 + b_ty[u] - 1, xx = x0 + b_tx[u] - 1;
+      const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+      const unsigned vo = ok ? (unsigned)(b_chunk + b_rel[u]) : 0x80000000u;     // outside the map: DMA of zeros
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(buf + 2 * A_PLANE + s * B_PLANE + (wid + 4 * u) * 1024), 16,
+                                                 (int)vo, (int)(s * (unsigned)a.x_ps), 0, 0);
+    }
+  };
+
+  floatx16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  // ---- transpose-read addresses: lane (m = lane % 16, g = lane / 16) supplies the 8 bytes at pixel k0 + m / 4, channels
+  // r0 + 4 (m % 4) .. + 3 and receives pixels k0 .. k0 + 3 of channel r0 + m:  r0 = 16 (g & 1), k0 = 8 (g >> 1) + 4 h + 16 kk
+  const int m = lane & 15, g = lane >> 4;
+  const int ch_off = (16 * (g & 1) + 4 * (m & 3)) * 2;
+  int a_off[2][2], b_off[2][2];                                          // [kk][h]
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = 16 * kk + 8 * (g >> 1) + 4 * h + (m >> 2);           // pixel of the chunk this lane addresses
+      a_off[kk][h] = wid * A_BLK + k * 64 + ch_off;
+      const int krow = k / COLS, kcol = k - krow * COLS;
+      b_off[kk][h] = 2 * A_PLANE + ((krow + 1) * TP + kcol + 1) * 64 + ch_off;      // tap (0, 0) of that pixel in the halo tile
+    }
+  constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};                    // cross terms first (fixed accumulation order)
+
+  auto compute = [&](const unsigned char* buf) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      halfx8 af[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        af[s] = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * A_PLANE + a_off[kk][0])),
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * A_PLANE + a_off[kk][1])));
+#pragma unroll
+      for (int t3 = 0; t3 < 3; ++t3) {                                   // one kernel row at a time: 3 taps, 9 MFMAs
+        halfx8 bf[3][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int shift = ((t3 - 1) * TP + (t - 1)) * 64;              // compile-time: an immediate offset
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            bf[t][s] = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * B_PLANE + b_off[kk][0] + shift)),
+                           __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * B_PLANE + b_off[kk][1] + shift)));
+        }
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            acc[3 * t3 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[SA[pr]], bf[t][SB[pr]], acc[3 * t3 + t], 0, 0, 0);
+      }
+    }
+  };
+
+  stage(c_begin, lds);
+  int cur = 0;
+  for (int c = c_begin; c <= c_last; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of chunk c has landed ...
+    __syncthreads();                                   // ... everybody's has, and nobody reads the other buffer any more
+    if (c < c_last) stage(c + 1, lds + (cur ^ 1) * BUF);
+    compute(lds + cur * BUF);
+    cur ^= 1;
+  }
+
+  // partial slab of split zs as [tap][Cout][Cin] (lanes = ci, contiguous); splitk_reduce_kernel re-lays it out
+  float* slab = a.part + (long)zs * a.part_stride;
+  const int fk = lane >> 5, fc = lane & 31;
+  const int ci = tci * 32 + fc;
+  if (co_live && ci < a.Cin) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co_blk * 32 + 4 * fk + igemm::strip_row(e);
+        if (co < a.Cout) slab[((long)t * a.Cout + co) * a.Cin + ci] = unscale * acc[t][e];
+      }
+  }
+}
+
+// H = W a power of two >= 8 (a chunk of 32 pixels is whole rows or a piece of one row, never across images), channel
+// counts in whole 32-blocks (planes), enough work to fill the chip
+struct Plan { int ok; int splits; int chunks_per_split; long slab; };
+inline Plan plan(int N, int H, int W, int Cin, int Cout) {
+  Plan r = {0, 1, 0, 0};
+  if (H != W || W < 8 || (W & (W - 1)) || Cin % 32 || Cout % 32 || Cin < 32 || Cout < 32) return r;
+  const long px = (long)N * H * W;
+  if (px % 32 || px / 32 > 0x7fffffffL / 64) return r;
+  const int nch = (int)(px / 32);
+  const long tiles = (long)stk_cdiv(Cout, 128) * (Cin / 32);
+  // two workgroups per CU; >= 8 chunks per workgroup; and a cap on the slab traffic (every split writes, and the
+  // reduce reads, 9 Cout Cin floats): STK_WGRAD_SLAB_MB, default 64
+  static const long cap_mb = [] { const char* e = getenv("STK_WGRAD_SLAB_MB"); return e ? atol(e) : 64L; }();
+  long splits = stk_cdiv(512, tiles);
+  if (splits > nch / 8) splits = nch / 8;
+  const long cap = (cap_mb << 20) / (9L * Cout * Cin * 4);
+  if (splits > cap) splits = cap;
+  if (splits < 1) splits = 1;
+  r.chunks_per_split = stk_cdiv(nch, splits);
+  r.splits = stk_cdiv(nch, r.chunks_per_split);
+  r.slab = 9L * Cout * Cin;
+  r.ok = nch >= 8;
+  return r;
+}
+
+}  // namespace x2w

@@ -288,13 +288,14 @@ class Executor:
   def _graphs_on(self):
     return self.use_graphs and self.lib.is_device and self.profiler is None
 
-  def _runtime(self, c, training, seed, seed_dev=None):
+  def _runtime(self, c, training, seed, seed_dev=None, with_backward=True):
     prog, flat = c.prog, self.flat
     rt = Runtime(self.lib, stk_lib.stream_ptr(flat.device), c.act.data_ptr(),
                  c.gact.data_ptr() if c.gact is not None else 0,
                  flat.data.data_ptr(), flat.grad.data_ptr(), prog.const.data_ptr(),
                  prog.ws.data_ptr(), prog.graph.ws_bytes, training, seed, seed_dev)
     rt.prof = self.profiler
+    rt.with_backward = with_backward
     if self.use_wp and prog.wp is not None and prog.wp_table is not None:
       rt.wp = prog.wp.data_ptr()
     if c.pl is not None:
@@ -302,10 +303,10 @@ class Executor:
       rt.dypl = rt.pl + prog.graph.pl_bytes
     return rt
 
-  def _replay(self, c, direction, training, span=None):
+  def _replay(self, c, direction, training, span=None, with_backward=True):
     """Replay (capturing on first use) the hipGraph of one direction of this context; `span` = (begin, end) restricts a
     backward graph to that slice of the backward op order (segments of the overlapped gradient exchange)."""
-    key = (direction, training) if span is None else (direction, training, span)
+    key = (direction, training, with_backward) if span is None else (direction, training, span)
     g = c.graphs.get(key)
     if g is None:
       ops = c.prog.graph.ops
@@ -315,7 +316,7 @@ class Executor:
         # thread_local: calls made by OTHER threads while this one captures (e.g. the RCCL watchdog of a
         # multi-GPU run polling its events) must not invalidate the capture
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
-          rt = self._runtime(c, training, 0, c.seed_t.data_ptr())   # stream = the capture stream
+          rt = self._runtime(c, training, 0, c.seed_t.data_ptr(), with_backward)   # stream = the capture stream
           if direction == 'fwd':
             for op in ops:
               op.forward(rt)
@@ -356,11 +357,11 @@ class Executor:
       if c.gact is None and torch.is_grad_enabled():
         c.gact = _arena(g.gact_size, prog.device)
       c.seed_t.fill_(seed)
-      done = self._replay(c, 'fwd', training)
+      done = self._replay(c, 'fwd', training, with_backward=with_backward)
       if done:
-        c.rt = self._runtime(c, training, 0, c.seed_t.data_ptr())
+        c.rt = self._runtime(c, training, 0, c.seed_t.data_ptr(), with_backward)
     if not done:
-      rt = self._runtime(c, training, seed)
+      rt = self._runtime(c, training, seed, None, with_backward)
       for op in g.ops:
         op.forward(rt)
       c.rt = rt

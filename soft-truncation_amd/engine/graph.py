@@ -31,7 +31,7 @@ def _round_up(n, a=_ALIGN):
 class Tensor:
   """Symbolic fp32 tensor: a shape plus an offset into one of the runtime's address spaces."""
   __slots__ = ('shape', 'numel', 'space', 'off', 'goff', 'needs_grad', 'name', 'seen', 'external_grad',
-               'producer', 'pl_off', 'pl_rec', 'pl_maker')
+               'producer', 'pl_off', 'pl_rec', 'pl_maker', 'f32_fwd', 'f32_bwd')
 
   def __init__(self, shape, space, off, needs_grad, name):
     self.shape = tuple(int(s) for s in shape)
@@ -49,6 +49,10 @@ class Tensor:
     self.pl_off = None
     self.pl_rec = None
     self.pl_maker = None
+    # does anybody read the fp32 copy of this tensor in the forward pass / in a backward pass?  (Graph.finalize; a
+    # GroupNorm whose consumers all take planes skips writing it)
+    self.f32_fwd = True
+    self.f32_bwd = True
 
   def __repr__(self):
     return f'T({self.name}{list(self.shape)}@{self.space}+{self.off})'
@@ -69,6 +73,7 @@ class Runtime:
     self.seed = seed
     self.seed_dev = seed_dev
     self.wp = 0           # base address of the program's prepared-weight arena (0: every conv prepares per call)
+    self.with_backward = True   # False: a no-grad evaluation (nothing is kept for a backward pass)
     self.pl = 0           # base address of the context's planes arena (pre-split conv operands)
     self.dypl = 0         # ... and of its scratch for the planes of the gradient a data-gradient call consumes
     self.prof = None      # optional engine.profile.KernelTimer: HIP events around the contraction launches
@@ -150,6 +155,7 @@ class GroupNormAct(Op):
     self.rstd = g.new((N * groups,), needs_grad=False, name=name + '.rstd')
     self.inputs = (x1, x2)
     self.op_id = g.next_id()
+    self.fused = False        # the library's one-pass GroupNorm -> planes kernel takes this shape (Graph.finalize)
 
   def _p(self, rt):
     return self.drop_p if rt.training else 0.0
@@ -159,9 +165,11 @@ class GroupNormAct(Op):
     y = self.y
     if y.pl_maker is self:
       # consumers take this output as planes (include/stk.h "Planes"): normalise, bound record and split in one call
-      # (one pass over x for the shapes the library fuses); the scale is the a-priori bound of the affine parameters
+      # (one pass over x for the shapes the library fuses); the scale is the a-priori bound of the affine parameters.
+      # The fp32 copy is written only if somebody reads it (the fused shapes accept y = NULL).
+      need_f32 = y.f32_fwd or (rt.with_backward and y.f32_bwd) or not self.fused
       rt.lib.gn_fwd_pl_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
-                           rt.v(y), rt.planes(y), rt.rec(y), rt.v(self.mean), rt.v(self.rstd), self.N, self.HW, self.G,
+                           rt.v(y) if need_f32 else None, rt.planes(y), rt.rec(y), rt.v(self.mean), rt.v(self.rstd), self.N, self.HW, self.G,
                            self.eps, self.act, self._p(rt), seed, rt.seed_dev, rt.ws, rt.stream)
       return
     rt.lib.gn_fwd_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
@@ -250,6 +258,7 @@ class Conv(Op):
   # planes (include/stk.h "Planes"): decided by Graph.finalize
   pl_fwd = False       # the forward call reads x1 as planes
   pl_dgrad = False     # the data-gradient call reads dy as planes (made here, into the context's scratch)
+  pl_wgrad = False     # the weight-gradient call reads x1 AND dy as planes (3x3 layers whose forward does)
   x_rec_own = False    # x1's scale record is this layer's amax[0:256] (so the weight gradient may reuse it)
 
   def plan_planes(self, g, lib):
@@ -272,6 +281,11 @@ class Conv(Op):
     needs_dx = (self.x1.needs_grad and self.x1.space == 'act') or (self.x2 is not None and self.x2.needs_grad)
     if needs_dx and self.KH == 3 and int(lib.conv2d_pl_ok(1, self.C1, self.C2, *dims)):
       self.pl_dgrad = True
+    if (self.pl_fwd and self.KH == 3 and self.w_layout == 0 and self.w.needs_grad and
+        os.environ.get('STK_PLANES_WGRAD', '1') != '0' and hasattr(lib, 'conv2d_wgrad_pl_ok') and
+        int(lib.conv2d_wgrad_pl_ok(self.N, self.H, self.W, self.C1, self.Cout))):
+      self.pl_wgrad = True
+    if self.pl_dgrad or self.pl_wgrad:
       g.dypl_bytes = max(g.dypl_bytes, _round_up(int(lib.planes_bytes(self.N, self.Cout, self.OH * self.OW)), 256))
 
   def forward(self, rt):
@@ -302,10 +316,12 @@ class Conv(Op):
       dtemb = rt.g(self.temb) + 4 * self.temb_col
     gb = rt.g(self.bias)
     g1, g2 = rt.g(self.x1), rt.g(self.x2)
+    gw = rt.g(self.w)
     pl_dgrad = self.pl_dgrad and (g1 is not None or g2 is not None)
+    pl_wgrad = self.pl_wgrad and gw is not None
     dy_rec = rt.v(self.amax) + 4 * 512           # |dy| scale record: planes of dy, reused by the weight gradient
     rec_done = False
-    if pl_dgrad and self.Cout <= 256 and (dtemb is not None or gb is not None):
+    if (pl_dgrad or pl_wgrad) and self.Cout <= 256 and (dtemb is not None or gb is not None):
       # the bias gradient reads all of dy: it leaves the per-channel |dy| maxima behind as the scale record
       lib.bias_grad_amax_f32(gy, self.N, self.Cout, self.OH * self.OW, alpha, dtemb, self.temb_stride, gb, dy_rec,
                              rt.ws, rt.stream)
@@ -317,11 +333,13 @@ class Conv(Op):
     have = 1 if self._kind(lib, 'fwd').endswith('.x2') else 0
     if self.pl_fwd and not self.x_rec_own:
       have = 0                                   # x1's record lives with another layer: the weight gradient measures
-    if pl_dgrad:
+    if pl_dgrad or pl_wgrad:
       rec = dy_rec
       if not rec_done:
         lib.amax_partial_f32(gy, self.y.numel, rec, rt.stream)
       lib.split_planes_f32(gy, self.N, self.Cout, self.OH * self.OW, rec, 256, rt.dypl, rt.stream)
+      have |= 2
+    if pl_dgrad:
       rt.timed(self._kind(lib, 'dgrad') + 'p', self.flops, lib.conv2d_dgrad_pl_f32,
                rt.dypl, rec, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
@@ -334,16 +352,21 @@ class Conv(Op):
                alpha, *self._dims(), self._wp(rt, 1), rt.v(self.amax), rt.ws, rt.ws_bytes, rt.stream)
       if self._kind(lib, 'dgrad').endswith('.x2'):
         have |= 2
-    gw = rt.g(self.w)
-    if gw is not None:
+    if pl_wgrad:
+      rt.timed(self._kind(lib, 'wgrad') + 'p', self.flops, lib.conv2d_wgrad_pl_f32,
+               rt.planes(self.x1), rt.rec(self.x1), rt.dypl, dy_rec, gw, alpha, rt.ws, rt.ws_bytes,
+               self.N, self.H, self.W, self.C1, self.Cout, rt.stream)
+    elif gw is not None:
       rt.timed(self._kind(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_amax_f32,
                rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, gy, gw, self.w_layout, alpha,
                rt.ws, rt.ws_bytes, *self._dims(), rt.v(self.amax), have, rt.stream)
 
   def ws_bytes(self, lib):
     shape = (self.C1, self.C2, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self.stride, self.pad)
-    return max(int(lib.conv2d_wgrad_ws_bytes(self.C1, self.C2, self.N, self.Cout, self.OH, self.OW,
-                                             self.KH, self.KW)),
+    pw = int(lib.conv2d_wgrad_pl_ws_bytes(self.N, self.H, self.W, self.C1, self.Cout)) \
+        if (self.C2 == 0 and self.KH == 3 and hasattr(lib, 'conv2d_wgrad_pl_ws_bytes')) else 0
+    return max(pw, int(lib.conv2d_wgrad_ws_bytes(self.C1, self.C2, self.N, self.Cout, self.OH, self.OW,
+                                                 self.KH, self.KW)),
                int(lib.conv2d_fwd_ws_bytes(*shape)), int(lib.conv2d_dgrad_ws_bytes(*shape)),
                4 * self.N * self.Cout)
 
@@ -732,4 +755,27 @@ class Graph:
       for op in self.ops:
         if isinstance(op, Conv):
           op.plan_planes(self, lib)
+      self._plan_f32_copies(lib)
     return self
+
+  def _plan_f32_copies(self, lib):
+    """For every GroupNorm output that is made as planes: who still reads its fp32 NCHW copy?  A convolution whose
+    forward takes planes does not; its weight gradient does unless it takes planes too.  Anything else does."""
+    readers = {}
+    for op in self.ops:
+      for v in vars(op).values():
+        if isinstance(v, Tensor) and v.space == 'act' and v.producer is not op:
+          readers.setdefault(id(v), []).append(op)
+    for op in self.ops:
+      if not isinstance(op, GroupNormAct) or op.y.pl_maker is not op:
+        continue
+      op.fused = bool(int(lib.gn_fwd_pl_fused(op.C1, op.C2, op.HW, op.G))) if hasattr(lib, 'gn_fwd_pl_fused') else False
+      y = op.y
+      fwd = bwd = y is self.output
+      for r in readers.get(id(y), []):
+        as_x1 = isinstance(r, Conv) and r.x1 is y and r.x2 is not y and r.res is not y and r.temb is not y
+        if not (as_x1 and r.pl_fwd):
+          fwd = True
+        if not as_x1 or (r.w.needs_grad and not r.pl_wgrad) or not r.pl_fwd:
+          bwd = True
+      y.f32_fwd, y.f32_bwd = fwd, bwd

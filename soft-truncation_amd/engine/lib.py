@@ -54,6 +54,9 @@ SIGNATURES = {
   'stk_conv2d_pl_ok': [I, I, I, I, I, I, I, I, I, I, I],
   'stk_conv2d_fwd_pl_f32': [P, P, I, P, I, P, P, I, P, F, P, I, I, I, I, I, I, P, P, L, S],
   'stk_conv2d_dgrad_pl_f32': [P, P, P, I, P, I, F, P, I, F, F, I, I, I, I, I, I, P, P, L, S],
+  'stk_conv2d_wgrad_pl_ok': [I, I, I, I, I],
+  'stk_conv2d_wgrad_pl_ws_bytes': [I, I, I, I, I],
+  'stk_conv2d_wgrad_pl_f32': [P, P, P, P, P, F, P, L, I, I, I, I, I, S],
   'stk_bias_grad_f32': [P, I, I, I, F, P, I, P, P, S],
   'stk_bias_grad_amax_f32': [P, I, I, I, F, P, I, P, P, P, S],
   'stk_gemm_f32': [P, L, L, L, P, L, L, L, P, L, L, L, P, I, I, I, I, I, F, F, S],
@@ -80,8 +83,8 @@ SIGNATURES = {
 }
 _RESTYPE = {'stk_strerror': c_char_p, 'stk_backend': c_char_p, 'stk_conv2d_wgrad_ws_bytes': c_long,
             'stk_conv2d_fwd_ws_bytes': c_long, 'stk_conv2d_dgrad_ws_bytes': c_long, 'stk_gn_ws_bytes': c_long,
-            'stk_conv2d_wp_bytes': c_long, 'stk_conv2d_wp_desc': c_long, 'stk_planes_bytes': c_long}
-_NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant', 'stk_conv2d_pl_ok', 'stk_gn_fwd_pl_fused'}
+            'stk_conv2d_wp_bytes': c_long, 'stk_conv2d_wp_desc': c_long, 'stk_planes_bytes': c_long, 'stk_conv2d_wgrad_pl_ws_bytes': c_long}
+_NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant', 'stk_conv2d_pl_ok', 'stk_gn_fwd_pl_fused', 'stk_conv2d_wgrad_pl_ok'}
 
 
 class StkMissingError(RuntimeError):

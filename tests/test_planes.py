@@ -261,3 +261,48 @@ def test_bias_grad_with_scale_record(ref_lib, hip_lib, case):
     assert torch.equal(hrec, rrec)
   assert (hdb - rdb).abs().max().item() <= 1e-5 * rdb.abs().max().item()
   assert (hdt - rdt).abs().max().item() <= 1e-5 * rdt.abs().max().item()
+
+
+WGRAD_PL_CASES = [
+  # N, Cin, Cout, H
+  (8, 128, 128, 32),      # COLS = 32, one row per chunk
+  (4, 64, 96, 16),        # COLS = 16, Cout not a multiple of 128 (dead waves)
+  (8, 256, 160, 8),       # COLS = 8, two co tiles, the second one ragged
+  (2, 32, 32, 64),        # W > 32: a chunk is half a row
+  (3, 96, 128, 16),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', WGRAD_PL_CASES, ids=str)
+def test_wgrad_from_planes(ref_lib, hip_lib, case):
+  """3x3 weight gradient with x and dy as planes (LDS-DMA + transpose reads) against the oracle, accumulating into a
+  non-zero dw with alpha != 1, and against the HIP fp32-operand weight gradient."""
+  N, Cin, Cout, H = case
+  x = rnd(N, Cin, H, H, seed=1)
+  dy = rnd(N, Cout, H, H, seed=2) * torch.logspace(-2, 0, N)[:, None, None, None]
+  dw0 = rnd(Cout, Cin, 3, 3, seed=3)
+  assert int(hip_lib.conv2d_wgrad_pl_ok(N, H, H, Cin, Cout)) == 1 and int(ref_lib.conv2d_wgrad_pl_ok(N, H, H, Cin, Cout)) == 1
+
+  def run(lib):
+    d = dev_of(lib)
+    xd, dyd = x.to(d), dy.to(d)
+    ax, ay = torch.zeros(256, device=d), torch.zeros(256, device=d)
+    call(lib, 'amax_partial_f32', xd, xd.numel(), ax)
+    call(lib, 'amax_partial_f32', dyd, dyd.numel(), ay)
+    xp = torch.zeros(int(lib.planes_bytes(N, Cin, H * H)), dtype=torch.uint8, device=d)
+    yp = torch.zeros(int(lib.planes_bytes(N, Cout, H * H)), dtype=torch.uint8, device=d)
+    call(lib, 'split_planes_f32', xd, N, Cin, H * H, ax, 256, xp)
+    call(lib, 'split_planes_f32', dyd, N, Cout, H * H, ay, 256, yp)
+    nb = max(int(lib.conv2d_wgrad_pl_ws_bytes(N, H, H, Cin, Cout)), int(lib.conv2d_wgrad_ws_bytes(Cin, 0, N, Cout, H, H, 3, 3)))
+    ws = torch.full((nb // 4 + 64,), float('nan'), device=d)
+    dw = dw0.clone().to(d)
+    call(lib, 'conv2d_wgrad_pl_f32', xp, ax, yp, ay, dw, 0.5, ws, nb, N, H, H, Cin, Cout)
+    dw32 = dw0.clone().to(d)
+    call(lib, 'conv2d_wgrad_f32', xd, Cin, None, 0, dyd, dw32, 0, 0.5, ws, nb, N, H, H, Cout, H, H, 3, 3, 1, 1)
+    return dw.cpu(), dw32.cpu()
+
+  (r, _), (h, h32) = run(ref_lib), run(hip_lib)
+  scale = (r - dw0).abs().max().item()
+  assert (h - r).abs().max().item() <= 1e-4 * scale
+  assert (h - h32).abs().max().item() <= 2e-5 * scale

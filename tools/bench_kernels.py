@@ -108,6 +108,10 @@ def main():
         call(lib, 'split_planes_f32', dy, N, Cout, H * H, ay, 256, yp)
         rec('conv.fwd.planes', shape, timeit(lambda: call(lib, 'conv2d_fwd_pl_f32', xp, ax, C1, w, 0, bias, None, 0, None, 1.0, y, N, H, H, Cout, K, K, None, fws, fb), args.reps), flops)
         rec('conv.dgrad.planes', shape, timeit(lambda: call(lib, 'conv2d_dgrad_pl_f32', yp, ay, w, 0, dx1, C1, 0.0, None, 0, 0.0, 1.0, N, H, H, Cout, K, K, None, fws, fb), args.reps), flops)
+        if K == 3 and int(lib.conv2d_wgrad_pl_ok(N, H, H, C1, Cout)):
+          nbp = int(lib.conv2d_wgrad_pl_ws_bytes(N, H, H, C1, Cout))
+          wsp = torch.empty(nbp // 4 + 64, device=d)
+          rec('conv.wgrad.planes', shape, timeit(lambda: call(lib, 'conv2d_wgrad_pl_f32', xp, ax, yp, ay, dw, 1.0, wsp, nbp, N, H, H, C1, Cout), args.reps), flops)
       if not args.planes_only:
        rec('conv.wgrad', shape, timeit(lambda: call(lib, 'conv2d_wgrad_f32', x1, C1, x2, C2, dy, dw, 0, 1.0, ws, ws.numel() * 4, *dims), args.reps), flops)
 
