@@ -9,13 +9,20 @@ on one synthetic batch already resident in HBM.  Workload at N = 1 (BASELINE.jso
 DDPM++ (VP) CIFAR-10 32x32, per-GPU batch 128, fp32.  Scaling is weak: the per-GPU batch is fixed and
 the global batch is 128 N.  Rank 0 prints ONE JSON line.
 
+`python bench.py --gpus N` outside a launcher starts the N ranks itself (torch.distributed.run on 127.0.0.1).
+
 Extra objects in that line:
-  roofline      the dominant kernel (by total time inside the timed region), timed with HIP events on the
-                launch stream: achieved = algorithmic FLOPs per launch / average launch duration, against
-                the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).  `kernels` lists the other
-                contraction kernels the same way.
-  cpu_baseline  the oracle's PyTorch-CPU restatement of the same training step (RefNet + torch Adam) timed
-                on this box's host cores on a bounded sample (rank 0, N = 1 only).
+  roofline      the dominant contraction kernel (by total time), timed with HIP events on the launch stream:
+                achieved = algorithmic FLOPs per launch / average launch duration, against the ceiling of the
+                matrix pipe for the arithmetic that kernel runs: 2500 / 3 = 833 TFLOP/s fp32-equivalent for the
+                fp16 two-way-split kernels (three fp16 MFMAs per fp32 product; labels .x2 / .x2p), 2500 / 6 for
+                the bf16 three-way-split ones (.x3), 157.3 for the f32-input MFMA kernels (MI355X_MICROARCH.md).
+                `kernels` lists the other contraction kernels the same way; `traffic` comes from the newest
+                committed PMC summary (profiles/rNN_traffic.json).
+  parity_probe  the benched build checks itself: per-sample soft-truncation losses of one batch-8 step on the HIP
+                engine against the oracle RefNet on identical weights and noise (N = 1 only).
+  cpu_baseline  the oracle's PyTorch-CPU restatement of the same training step (RefNet + torch Adam + EMA) and of
+                one PC-sampler iteration, timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -44,8 +51,12 @@ PEAK_X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 # rocprofv3 symbol of the kernel behind a profiler label (for the committed PMC summary, see traffic_of)
 KERNEL_SYMBOL = {
   'conv3x3.wgrad.x2': 'x2::wgrad3_kernel<false>',
-  'conv3x3.fwd.x2': 'x2::gemm_kernel<x2::ActLoader<false, 9>, EpFwd>',
-  'conv3x3.dgrad.x2': 'x2::gemm_kernel<x2::ActLoader<false, 9>, EpDgrad>',
+  'conv3x3.fwd.x2': 'x2::gemm_kernel<x2::ActLoader<false, 9>, EpFwd, 2>',
+  'conv3x3.dgrad.x2': 'x2::gemm_kernel<x2::ActLoader<false, 9>, EpDgrad, 2>',
+  # plane operands (round 2): LDS-DMA staged forward / data gradient, transpose-read weight gradient
+  'conv3x3.fwd.x2p': 'x2d::gemm_kernel<9, 128, EpFwd>',
+  'conv3x3.dgrad.x2p': 'x2d::gemm_kernel<9, 128, EpDgrad>',
+  'conv3x3.wgrad.x2p': 'x2w::wgrad_kernel<32>',
 }
 
 
@@ -66,7 +77,7 @@ def traffic_of(kind):
 
 
 def kernel_peak(kind):
-  if kind.endswith('.x2'):
+  if kind.endswith('.x2') or kind.endswith('.x2p'):
     return PEAK_X2_TFLOPS
   return PEAK_X3_TFLOPS if kind.endswith('.x3') else PEAK_F32_MFMA_TFLOPS
 TRAIN_FLOPS_PER_IMG = {'cifar10_ddpmpp_nll_st': 65.072e9, 'imagenet32_ddpmpp_st': 65.072e9,
@@ -97,6 +108,7 @@ def parse():
   ap.add_argument('--batch', type=int, default=0, help='per-GPU batch override')
   ap.add_argument('--fir', action='store_true', help='same net with model.fir=True (FIR resampling through upfirdn2d); SURVEY 8(d)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-parity-probe', action='store_true')
   ap.add_argument('--no-kernel-timer', action='store_true')
   ap.add_argument('--prof-steps', type=int, default=3)
   ap.add_argument('--cpu-batch', type=int, default=8)
@@ -130,10 +142,83 @@ def cpu_baseline(st, cfg_name, batch, steps, fir=False):
     step_fn(state, x)
     times.append(time.perf_counter() - t0)
   med = float(np.median(times[1:]))
-  return {'value': batch / med, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-          'sample': f'{cfg_name} full-size model, batch {batch}, median of {steps} training steps after 1 warm-up '
-                    f'(oracle/ref_torch.RefNet + torch.optim.Adam + EMA, PyTorch CPU fp32)',
-          'sec_per_step': med}
+  out = {'value': batch / med, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+         'sample': f'{cfg_name} full-size model, batch {batch}, median of {steps} training steps after 1 warm-up '
+                   f'(oracle/ref_torch.RefNet + torch.optim.Adam + EMA, PyTorch CPU fp32)',
+         'sec_per_step': med}
+  # BASELINE.json configs[0] also names "1 PC sample step": one corrector + predictor iteration of the config's sampler
+  # registry (euler_maruyama + none, the CPU-runnable pair), batch `batch`, median of `steps`
+  try:
+    ref.eval()
+    xs = torch.randn(batch, cfg.data.num_channels, cfg.data.image_size, cfg.data.image_size)
+    vec_t = torch.ones(batch) * 0.5
+    pc = []
+    with torch.no_grad():
+      for i in range(steps + 1):
+        t0 = time.perf_counter()
+        xc, _ = st.sampling.shared_corrector_update_fn(xs, vec_t, sde, ref, st.sampling.NoneCorrector, True, 0.16, 1, cfg)
+        st.sampling.shared_predictor_update_fn(xc, vec_t, sde, ref, st.sampling.EulerMaruyamaPredictor, False, True, cfg)
+        pc.append(time.perf_counter() - t0)
+    out['pc_iteration'] = {'sec': float(np.median(pc[1:])), 'batch': batch, 'image_evals_per_s': batch / float(np.median(pc[1:])),
+                           'sample': 'euler_maruyama predictor + none corrector, one iteration'}
+  except Exception as e:
+    out['pc_iteration'] = {'error': repr(e)[:200]}
+  # a larger batch for a like-for-like images/s (BASELINE.md section 4 (ii) asks for 128: 128 images at ~1.5 images/s
+  # would be ~90 s per step, beyond the bounded sample; batch 32, one step after the warm state above)
+  try:
+    ref.train()
+    big = 32
+    xb = st.datasets.synthetic_batch(cfg, big, generator=torch.Generator().manual_seed(1))
+    t0 = time.perf_counter()
+    step_fn(state, xb)
+    dt = time.perf_counter() - t0
+    out['batch32'] = {'value': big / dt, 'unit': 'images/s', 'sec_per_step': dt, 'steps': 1}
+  except Exception as e:
+    out['batch32'] = {'error': repr(e)[:200]}
+  return out
+
+
+def parity_probe(st, cfg_name, device):
+  """The benched build checks itself (a build whose data gradients were computed from zero-filled weight
+  blocks benchmarked fine): one batch-8 evaluation of the soft-truncation loss on the HIP engine and on the oracle
+  RefNet with identical weights, batch, t_min and noise; per-sample losses and the network's parameter gradients
+  (sum of squares) must agree.  Weights: the reference's own initialisation (seed 0)."""
+  import copy
+  import ref_torch
+  from _model_util import patched_rng
+  cfg = st.configs.get_config(cfg_name)
+  cfg.model.dropout = 0.0                   # torch's CPU and the device draw different dropout masks
+  cfg.device = device
+  cfg_cpu = copy.deepcopy(cfg)
+  cfg_cpu.device = torch.device('cpu')
+  sde = st.sde_lib.get_sde(cfg, None)
+  torch.manual_seed(0)
+  net = st.models.ncsnpp.NCSNpp(cfg, sde).to(device)
+  model = st.models.utils.DataParallel(net)
+  net.engine().ensure_flat()
+  sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+  ref = st.models.utils.DataParallel(ref_torch.RefNet(cfg_cpu, sd))
+  batch = st.datasets.synthetic_batch(cfg_cpu, 8, generator=torch.Generator().manual_seed(7))
+  out = {}
+  res = []
+  for m, c, b in ((model, cfg, batch.to(device)), (ref, cfg_cpu, batch)):
+    loss_fn = st.losses.get_sde_loss_fn(c, sde, train=True)
+    m.train()
+    m.zero_grad()
+    np.random.seed(3)
+    with patched_rng(11):
+      losses = loss_fn(m, b, importance_sampling=c.training.importance_sampling)
+    torch.mean(losses).backward()
+    gsq = sum(float((p.grad.double() ** 2).sum()) for p in m.parameters() if p.grad is not None)
+    res.append((losses.detach().cpu().double(), gsq))
+  (lp, gp), (lr, gr) = res
+  out['loss_hip'] = [float(v) for v in lp]
+  out['loss_ref'] = [float(v) for v in lr]
+  out['loss_max_rel_err'] = float((lp - lr).abs().max() / lr.abs().max())
+  out['grad_norm_rel_err'] = abs(gp ** 0.5 - gr ** 0.5) / max(gr ** 0.5, 1e-30)
+  out['tolerance'] = 1e-3
+  out['ok'] = bool(out['loss_max_rel_err'] <= 1e-3 and out['grad_norm_rel_err'] <= 1e-3)
+  return out
 
 
 def sampler_rate(st, cfg, sde, score_model, batch, steps, device):
@@ -336,7 +421,7 @@ def main():
                            'frac': a['tflops'] / kernel_peak(dom), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
                            'traffic_source': traffic_src, 'kernel': dom,
                            'peak_note': ('bf16 MFMA dense peak / 6 products per fp32 product' if dom.endswith('.x3')
-                                         else 'fp16 MFMA dense peak / 3 products per fp32 product' if dom.endswith('.x2')
+                                         else 'fp16 MFMA dense peak / 3 products per fp32 product' if kernel_peak(dom) == PEAK_X2_TFLOPS
                                          else 'f32-input MFMA peak'),
                            'avg_us': a['avg_us'], 'launches': a['count'], 'flops_per_launch': a['flops_per_launch'],
                            'share_of_step': (a['total_ms'] / max(args.prof_steps, 1)) / (1e3 * elapsed / args.steps),
@@ -359,6 +444,13 @@ def main():
         out['sampler'] = {'error': repr(e)[:200]}
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(st, cfg_name, args.cpu_batch, args.cpu_steps, args.fir)
+    if world == 1 and not args.no_parity_probe:
+      try:
+        del state, optimizer, ema, score_model       # free the benched replica's arenas before building the probe's
+        torch.cuda.empty_cache()
+        out['parity_probe'] = parity_probe(st, cfg_name, device)
+      except Exception as e:
+        out['parity_probe'] = {'error': repr(e)[:300]}
     print(json.dumps(out), flush=True)
   if world > 1:
     dist.destroy_process_group()

@@ -1,4 +1,4 @@
 mkdir -p gpurun_out
-python -m pytest tests/test_planes.py -m gpu -q -k "wgrad" 2>&1 | tail -8
-python tools/bench_kernels.py --only conv --shapes 8 2>&1 | grep -E "wgrad"
-for mb in 32 128; do echo "== STK_WGRAD_SLAB_MB=$mb"; STK_WGRAD_SLAB_MB=$mb python tools/bench_kernels.py --only conv --planes-only --shapes 3 2>&1 | grep -E "wgrad.planes"; done
+python -m pytest tests/test_gpu_kernels.py tests/test_gpu_ops.py -m gpu -q -x -k "upfirdn or resampl or op" > gpurun_out/r02_tests_d.log 2>&1; grep -E "passed|failed" gpurun_out/r02_tests_d.log; grep -E "^E " gpurun_out/r02_tests_d.log | head -5
+python tools/bench_kernels.py --only misc 2>&1 | grep -E "upfirdn"
+python tools/bench_kernels.py --only gn 2>&1 | grep -E "gn_"
