@@ -374,12 +374,20 @@ class Conv(Op):
 class Linear(Op):
   """y[B,out] = x[B,in] @ W[out,in]^T + b  -- nn.Linear (models/ncsnpp.py:97-102, layerspp.py:240)."""
 
+  KSLICE = 256       # data gradient of a wide layer: K (= fout) is cut into slices of this many columns ...
+  KSPLIT_MIN = 2048  # ... when the layer is at least this wide
+
   def __init__(self, g, x, w, bias, name='linear'):
     self.x, self.w, self.bias = x, w, bias
     self.B, self.fin = x.shape
     self.fout = w.shape[0]
     self.y = g.new((self.B, self.fout), name=name)
     self.inputs = (x,)
+    # dX = dY W has M x N = B x fin outputs (a handful of tiles) and K = fout: for the stacked time-embedding projections
+    # (46 Dense_0 layers, fout = 9984) one workgroup per tile would walk all of K alone.  Split K into slices computed as
+    # one batched GEMM into slabs, summed in slice order by a second GEMM with a row of ones (deterministic).
+    self.ksplit = self.fout // self.KSLICE if (self.fout >= self.KSPLIT_MIN and self.fout % self.KSLICE == 0 and x.needs_grad) else 0
+    self.ones = g.const(np.ones(self.ksplit, dtype=np.float32)) if self.ksplit else None
 
   def forward(self, rt):
     B, fin, fout = self.B, self.fin, self.fout
@@ -391,7 +399,13 @@ class Linear(Op):
     gy = rt.g(self.y)
     lib = rt.lib
     gx = rt.g(self.x)
-    if gx is not None:   # dX[b][k] = sum_n dY[b][n] W[n][k]
+    if gx is not None and self.ksplit:
+      S, ks = self.ksplit, self.KSLICE
+      lib.gemm_f32(gy, fout, 1, ks, rt.v(self.w), fin, 1, ks * fin, rt.ws, fin, 1, B * fin, None, 0,
+                   B, fin, ks, S, 1.0, 0.0, rt.stream)
+      lib.gemm_f32(rt.v(self.ones), S, 1, 0, rt.ws, B * fin, 1, 0, gx, B * fin, 1, 0, None, 0,
+                   1, B * fin, S, 1, 1.0, self.b(self.x), rt.stream)
+    elif gx is not None:   # dX[b][k] = sum_n dY[b][n] W[n][k]
       lib.gemm_f32(gy, fout, 1, 0, rt.v(self.w), fin, 1, 0, gx, fin, 1, 0, None, 0,
                    B, fin, fout, 1, 1.0, self.b(self.x), rt.stream)
     gw = rt.g(self.w)
@@ -403,7 +417,7 @@ class Linear(Op):
       lib.bias_grad_f32(gy, B, fout, 1, 1.0, None, 0, gb, rt.ws, rt.stream)
 
   def ws_bytes(self, lib):
-    return 4 * self.B * self.fout
+    return max(4 * self.B * self.fout, 4 * self.ksplit * self.B * self.fin)
 
 
 class SiLU(Op):

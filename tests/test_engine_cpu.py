@@ -154,3 +154,19 @@ def test_planes_switch_off_gives_same_answers(st, ref_lib, monkeypatch):
     y0 = model(x, t)
   assert all(pr.graph.pl_bytes == 0 for pr in model.module.engine().programs.values())
   assert (y1 - y0).abs().max().item() <= 2e-6 * y0.abs().max().item()
+
+
+def test_linear_data_gradient_k_split(st, ref_lib, monkeypatch):
+  """The stacked time-embedding projection (46 Dense_0 layers, fout = 9984 at full size) computes its data gradient as a
+  batched GEMM over K slices plus a ones-row GEMM that sums the slabs in slice order (engine/graph.py Linear).  Forced on
+  for the tiny net here (slices of 16 columns); the full-size GPU parity tests run it at its real size."""
+  from importlib import import_module
+  G = import_module('soft-truncation_amd.engine.graph')
+  monkeypatch.setattr(G.Linear, 'KSLICE', 16)
+  monkeypatch.setattr(G.Linear, 'KSPLIT_MIN', 32)
+  cases.forward_backward(st, ref_lib, 'vp')
+  cfg, cfg_cpu, sde, model, ref = cases.build_pair(st, cases.tiny_config(st, 'vp'), ref_lib)
+  import torch
+  model(torch.randn(2, 3, 16, 16), torch.rand(2) * 999).sum().backward()
+  lins = [op for pr in model.module.engine().programs.values() for op in pr.graph.ops if isinstance(op, G.Linear)]
+  assert any(op.ksplit > 1 for op in lins)
