@@ -20,6 +20,7 @@
  *   stk_conv2d_*             nn.Conv2d / NIN call sites, models/layerspp.py:273-282, models/layers.py:100-124,546-555
  *   stk_gemm_f32             NIN / Linear / attention einsums, models/layerspp.py:95-99, models/ncsnpp.py:288-292
  *   stk_softmax_*            F.softmax in AttnBlockpp, models/layerspp.py:97
+ *   stk_attention_*          the einsum / softmax / einsum core of AttnBlockpp, models/layerspp.py:95-99
  *   stk_resample_naive_f32   naive_upsample_2d / naive_downsample_2d, models/up_or_down_sampling.py:59-69
  *   stk_*embedding_f32       layers.get_timestep_embedding (models/layers.py:515-529), GaussianFourierProjection (models/layerspp.py:52-54)
  *   stk_perturb_f32 / stk_sm_loss_*   losses.py:116-132
@@ -248,6 +249,25 @@ int stk_gemm_f32(const float* A, long sam, long sak, long sab,
 int stk_softmax_fwd_f32(const float* x, float* y, long rows, int cols, float scale, void* stream);
 int stk_softmax_bwd_f32(const float* y, const float* dy, float* dx, long rows, int cols,
                         float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused attention core of AttnBlockpp (models/layerspp.py:95-99): the two einsums and the softmax between them,
+ *   o[b,c,t] = sum_t' softmax_t'( scale * sum_c' q[b,c',t] k[b,c',t'] ) v[b,c,t'],      scale = C^-0.5,
+ * on q, k, v, o [B, C, T] (NCHW with T = H*W), forward and backward, with no [B, T, T] matrix in memory.
+ *   lse   [B, T]   out (forward) / in (backward): log sum_t' exp(scale * s[t, t'])
+ *   rec   4 x 256 floats owned by the caller: the scale records (partial |x| maxima, see "Planes") of q, k, v written
+ *         by the forward and of d_o written by the backward; the backward reads the forward's three
+ *   delta [B, T]   scratch of the backward: sum_t' p[t, t'] dp[t, t']
+ *   dq / dk / dv = beta * dq / dk / dv + gradient  (beta == 0: not read)
+ * stk_attention_ok: 1 if the fused kernels take the shape (C % 32 == 0, 32 <= C <= 256, T % 4 == 0, T <= 256); other
+ * shapes return STK_EUNSUPPORTED and go through stk_gemm_f32 / stk_softmax_*.
+ * ------------------------------------------------------------------------------------------ */
+int stk_attention_ok(int B, int C, int T);
+int stk_attention_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, float* rec,
+                          int B, int C, int T, float scale, void* stream);
+int stk_attention_bwd_f32(const float* q, const float* k, const float* v, const float* d_o, const float* lse, float* rec,
+                          float* delta, float* dq, float beta_q, float* dk, float beta_k, float* dv, float beta_v,
+                          int B, int C, int T, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Element-wise and small helpers.

@@ -244,7 +244,7 @@ class Executor:
     key = (B, H, W, need_xgrad)
     prog = self.programs.get(key)
     if prog is None:
-      g = Graph(self.flat)
+      g = Graph(self.flat, self.lib)
       out = self.model._emit(g, B, H, W, need_xgrad)
       g.finalize(out, self.lib)
       prog = self.programs[key] = Program(g, self.flat.device)

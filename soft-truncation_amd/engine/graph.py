@@ -576,22 +576,39 @@ class AddDiv(Op):
 
 class AttentionCore(Op):
   """o = softmax(q^T k / sqrt(C)) applied to v -- the two einsums and the softmax of AttnBlockpp
-  (models/layerspp.py:95-99), q/k/v/o all [B,C,H,W], single head of dimension C."""
+  (models/layerspp.py:95-99), q/k/v/o all [B,C,H,W], single head of dimension C.
+
+  Shapes the library's fused kernels take (stk_attention_ok: every shipped config) run as one launch per direction pair
+  with no [B,T,T] matrix in memory; the rest as batched GEMMs around stk_softmax_*.  STK_ATTN_FUSED=0 forces the latter."""
 
   def __init__(self, g, q, k, v, name='attn'):
     self.q, self.k, self.vv = q, k, v
     B, C, H, W = q.shape
     self.B, self.C, self.T = B, C, H * W
     self.scale = float(int(C) ** (-0.5))
-    self.s = g.new((B, self.T, self.T), needs_grad=False, name=name + '.s')
-    self.p = g.new((B, self.T, self.T), needs_grad=False, name=name + '.p')
+    lib = g.lib
+    self.fused = bool(lib is not None and os.environ.get('STK_ATTN_FUSED', '1') != '0' and hasattr(lib, 'attention_ok') and
+                      int(lib.attention_ok(B, C, self.T)))
+    if self.fused:
+      self.lse = g.new((B, self.T), needs_grad=False, name=name + '.lse')
+      self.delta = g.new((B, self.T), needs_grad=False, name=name + '.delta')
+      self.rec = g.new((1024,), needs_grad=False, name=name + '.rec')      # scale records of q, k, v, do
+    else:
+      self.s = g.new((B, self.T, self.T), needs_grad=False, name=name + '.s')
+      self.p = g.new((B, self.T, self.T), needs_grad=False, name=name + '.p')
     self.o = g.new(q.shape, name=name + '.o')
     self.y = self.o
     self.inputs = (q, k, v)
+    # algorithmic FLOPs: forward 2 GEMMs, backward 4 (+ 3 recomputed by the fused kernels, not counted)
+    self.flops = 2.0 * 2.0 * B * self.T * self.T * C
 
   def forward(self, rt):
     B, C, T = self.B, self.C, self.T
     lib = rt.lib
+    if self.fused:
+      rt.timed('attention.fwd.x2', self.flops, lib.attention_fwd_f32, rt.v(self.q), rt.v(self.k), rt.v(self.vv), rt.v(self.o),
+               rt.v(self.lse), rt.v(self.rec), B, C, T, self.scale, rt.stream)
+      return
     # S[b][t][t'] = sum_c Q[b][c][t] K[b][c][t']
     lib.gemm_f32(rt.v(self.q), 1, T, C * T, rt.v(self.k), T, 1, C * T, rt.v(self.s), T, 1, T * T,
                  None, 0, T, T, C, B, 1.0, 0.0, rt.stream)
@@ -604,6 +621,20 @@ class AttentionCore(Op):
     B, C, T = self.B, self.C, self.T
     lib = rt.lib
     go = rt.g(self.o)
+    if self.fused:
+      gq, gk, gv = rt.g(self.q), rt.g(self.k), rt.g(self.vv)
+      if gq is None and gk is None and gv is None:
+        return
+      # the kernels write all three gradients; one that nobody asked for goes to the workspace
+      n4 = 4 * self.q.numel
+      spare = [rt.ws + i * n4 for i in range(3)]
+      rt.timed('attention.bwd.x2', 2.0 * self.flops, lib.attention_bwd_f32, rt.v(self.q), rt.v(self.k), rt.v(self.vv), go,
+               rt.v(self.lse), rt.v(self.rec), rt.v(self.delta),
+               gq if gq is not None else spare[0], self.b(self.q) if gq is not None else 0.0,
+               gk if gk is not None else spare[1], self.b(self.k) if gk is not None else 0.0,
+               gv if gv is not None else spare[2], self.b(self.vv) if gv is not None else 0.0,
+               B, C, T, self.scale, rt.stream)
+      return
     dp = rt.v(self.s)   # S is dead after the forward softmax: reuse it for dP, then dS
     # dP[b][t][t'] = sum_c dO[b][c][t] V[b][c][t']
     lib.gemm_f32(go, 1, T, C * T, rt.v(self.vv), T, 1, C * T, dp, T, 1, T * T,
@@ -621,6 +652,9 @@ class AttentionCore(Op):
     if gk is not None:  # dK[b][c][t'] = sum_t Q[b][c][t] dS[b][t][t']
       lib.gemm_f32(rt.v(self.q), T, 1, C * T, dp, T, 1, T * T, gk, T, 1, C * T,
                    None, 0, C, T, T, B, 1.0, self.b(self.k), rt.stream)
+
+  def ws_bytes(self, lib):
+    return 3 * 4 * self.q.numel if self.fused else 0
 
 
 class RowScale(Op):
@@ -657,8 +691,9 @@ class RowScale(Op):
 class Graph:
   """Builder: allocates symbolic tensors, records ops, then plans gradient buffers."""
 
-  def __init__(self, flat):
+  def __init__(self, flat, lib=None):
     self.flat = flat                  # engine.flat.FlatParams (parameter -> flat offset)
+    self.lib = lib                    # the backend the plan is made for (ops may ask it which kernels take a shape)
     self.ops = []
     self.tensors = []
     self.act_size = 0

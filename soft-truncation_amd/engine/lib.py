@@ -62,6 +62,9 @@ SIGNATURES = {
   'stk_gemm_f32': [P, L, L, L, P, L, L, L, P, L, L, L, P, I, I, I, I, I, F, F, S],
   'stk_softmax_fwd_f32': [P, P, L, I, F, S],
   'stk_softmax_bwd_f32': [P, P, P, L, I, F, S],
+  'stk_attention_ok': [I, I, I],
+  'stk_attention_fwd_f32': [P, P, P, P, P, P, I, I, I, F, S],
+  'stk_attention_bwd_f32': [P, P, P, P, P, P, P, P, F, P, F, P, F, I, I, I, F, S],
   'stk_silu_fwd_f32': [P, P, L, S],
   'stk_silu_bwd_f32': [P, P, P, F, L, S],
   'stk_axpby_f32': [P, F, P, F, P, L, S],
@@ -84,7 +87,7 @@ SIGNATURES = {
 _RESTYPE = {'stk_strerror': c_char_p, 'stk_backend': c_char_p, 'stk_conv2d_wgrad_ws_bytes': c_long,
             'stk_conv2d_fwd_ws_bytes': c_long, 'stk_conv2d_dgrad_ws_bytes': c_long, 'stk_gn_ws_bytes': c_long,
             'stk_conv2d_wp_bytes': c_long, 'stk_conv2d_wp_desc': c_long, 'stk_planes_bytes': c_long, 'stk_conv2d_wgrad_pl_ws_bytes': c_long}
-_NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant', 'stk_conv2d_pl_ok', 'stk_gn_fwd_pl_fused', 'stk_conv2d_wgrad_pl_ok'}
+_NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant', 'stk_conv2d_pl_ok', 'stk_gn_fwd_pl_fused', 'stk_conv2d_wgrad_pl_ok', 'stk_attention_ok'}
 
 
 class StkMissingError(RuntimeError):

@@ -588,6 +588,58 @@ def test_softmax(ref_lib, hip_lib, rows, cols):
   compare(both(ref_lib, hip_lib, fn), 1e-5, 'softmax')
 
 
+# fused attention core (csrc/attention.hip) against the oracle's double-precision restatement of
+# models/layerspp.py:95-99 and of its autograd.  Shapes: the 16x16 blocks of every shipped config (C = 256, T = 256),
+# the mid-block of CelebA-64 (T = 64) and of CIFAR-10 / CelebA-HQ (T = 16), the `wide` test family (C = 192 / 96),
+# a T that is neither a tile nor a block multiple, and the smallest C.
+ATTN_CASES = [
+  # (B, C, T, beta, magnitudes of q, k, v, do)
+  (3, 256, 256, 0.0, (1., 1., 1., 1.)),
+  (2, 256, 64, 0.0, (1., 1., 1., 1.)),
+  (3, 256, 16, 1.0, (1., 1., 1., 1.)),
+  (2, 192, 256, 0.5, (1., 1., 1., 1.)),
+  (2, 96, 64, 0.0, (1., 1., 1., 1.)),
+  (2, 64, 200, 0.0, (1., 1., 1., 1.)),
+  (2, 32, 132, 1.0, (1., 1., 1., 1.)),
+  (2, 128, 256, 0.0, (3e3, 2e-3, 5e-4, 1e-6)),        # operands far apart in magnitude: every tensor has its own scale
+  (2, 256, 256, 0.0, (0.02, 30., 1e4, 1e3)),          # peaked softmax rows
+]
+
+
+@pytest.mark.parametrize('case', ATTN_CASES, ids=lambda c: f'B{c[0]}C{c[1]}T{c[2]}b{c[3]}m{c[4][0]:g}')
+def test_attention(ref_lib, hip_lib, case):
+  B, C, T, beta, (mq, mk, mv, mdo) = case
+  assert hip_lib.attention_ok(B, C, T) == 1
+  q, k, v, do = rnd(B, C, T, seed=1) * mq, rnd(B, C, T, seed=2) * mk, rnd(B, C, T, seed=3) * mv, rnd(B, C, T, seed=4) * mdo
+  g0 = [rnd(B, C, T, seed=5 + i) * m * 0.1 for i, m in enumerate((mk, mq, mdo))]       # accumulated into when beta != 0
+  scale = float(C) ** -0.5
+
+  def fn(lib, to):
+    o, lse, rec, delta = to(torch.zeros(B, C, T)), to(torch.zeros(B, T)), to(torch.zeros(1024)), to(torch.zeros(B, T))
+    call(lib, 'attention_fwd_f32', to(q), to(k), to(v), o, lse, rec, B, C, T, scale)
+    dq, dk, dv = (to(g.clone()) for g in g0)
+    call(lib, 'attention_bwd_f32', to(q), to(k), to(v), to(do), lse, rec, delta, dq, beta, dk, beta, dv, beta, B, C, T, scale)
+    return {'o': o, 'lse': lse, 'delta': delta, 'dq': dq, 'dk': dk, 'dv': dv}
+
+  outs = both(ref_lib, hip_lib, fn)
+  ref, got = outs
+  for name in ('o', 'dq', 'dk', 'dv'):
+    close(got[name], ref[name], rtol=1e-4, what=f'attention:{name}')
+  close(got['lse'], ref['lse'], rtol=1e-5, atol=1e-5, what='attention:lse')
+  close(got['delta'], ref['delta'], rtol=1e-4, what='attention:delta')
+
+
+def test_attention_unsupported_shapes_are_refused(hip_lib):
+  """Shapes outside the fused kernels' range return STK_EUNSUPPORTED (the engine plans them as GEMMs + softmax)."""
+  assert hip_lib.attention_ok(2, 48, 64) == 0 and hip_lib.attention_ok(2, 512, 64) == 0
+  assert hip_lib.attention_ok(2, 64, 1024) == 0 and hip_lib.attention_ok(2, 64, 30) == 0
+  x = torch.zeros(2 * 48 * 64, device='cuda')
+  r = torch.zeros(1024, device='cuda')
+  rc = hip_lib.attention_fwd_f32.raw(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), r.data_ptr(), r.data_ptr(),
+                                     2, 48, 64, 0.1, 0)
+  assert rc != 0
+
+
 # ---------------------------------------------------------------------------------------------------
 # optimizer side
 # ---------------------------------------------------------------------------------------------------

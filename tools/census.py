@@ -25,7 +25,7 @@ def main():
   H = cfg.data.image_size
   flat = import_module('soft-truncation_amd.engine.flat').FlatParams(list(net.parameters()), torch.device('cpu'),
                                                                      groups=net._flat_groups())
-  g = graph_mod.Graph(flat)
+  g = graph_mod.Graph(flat, lib)
   out = net._emit(g, B, H, H, False)
   g.finalize(out, lib)
   rows = collections.OrderedDict()
