@@ -33,6 +33,9 @@
 // back from the accumulators as [n][m]: plain `ds_read_b128` fragments from padded rows (80 / 528-byte pitch).  Both
 // phases are software-pipelined: global fp32 loads of chunk c + 2 in flight, chunk c + 1 being split and written to the
 // other LDS buffer, MFMAs on chunk c, one barrier per chunk.
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -45,6 +48,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef short s4 __attribute__((__vector_size__(8)));
 typedef __attribute__((address_space(3))) s4 lds_s4;
 
+#ifndef ATTN_EXPERIMENT
+#define ATTN_EXPERIMENT 0          // development: 1 = phase A without MFMAs, 2 = without staging, 3 = without fragment reads
+#endif
 constexpr int NPART = 256;          // partial |x| maxima per tensor (a "scale record", include/stk.h)
 constexpr int MODE_FWD = 0, MODE_DQ = 1, MODE_DKV = 2;
 
@@ -114,22 +120,25 @@ struct Args {
   float* lse;             // [B, T]  FWD: written; DQ / DKV: read
   float* delta;           // [B, T]  DQ: written; DKV: read
   int B, C, T; float scale;
+  long long* dbg;         // development aid: cycle stamps of workgroup 0 / wave 0 at the phase boundaries (NULL: off)
 };
 
 template <int MODE, int TK>
 struct Geo {
+  static constexpr int NW = TK / 32;                      // waves: one 32-row block of D per wave (8 for TK = 256, 4 for 128)
+  static constexpr int NT = 64 * NW;
   static constexpr int NG = MODE == MODE_FWD ? 1 : 2;     // GEMMs of phase A
   static constexpr int CK = 32 / NG;                      // channels per phase A chunk
   static constexpr int KS = CK / 16;                      // MFMA k steps per chunk
-  static constexpr int MBW = TK / 128;                    // 32-row blocks of D per wave
-  static constexpr int XBLK = TK / 32;
   static constexpr int XP = TK * CK * 2;                  // bytes per plane of an X chunk tile [m block][c][32]
   static constexpr int YP = 64 * CK * 2;
   static constexpr int GSZ = 2 * XP + 2 * YP;             // one GEMM's tiles: X hi, X lo, Y hi, Y lo
   static constexpr int STAGE = NG * GSZ;                  // 40960 (TK = 256) / 24576 (TK = 128)
-  static constexpr int XI = XBLK * (CK / 8) / 4;          // 16-byte loads per thread, chunk and X operand
-  static constexpr int YI = 2 * (CK / 8) / 4;             //                                 ... and Y operand (0 -> see YI1)
-  static constexpr int YI1 = YI > 0 ? YI : 1;
+  static constexpr int XI = CK / 8;                       // 16-byte pieces per thread, chunk and X operand (its wave's 32-block)
+  static constexpr int YT = NG * 2 * (CK / 8) / NW;       // ... of the Y operands together (1 with 8 waves, 2 with 4)
+  static constexpr int NPA = NG * XI + YT;                // pieces per thread and chunk
+  static constexpr int CBW = 8 / NW;                      // phase B: 32-channel blocks of the output per wave
+  static constexpr int AI = 32 / NW;                      // phase B: pieces per thread and 32-position block of A
   static constexpr int APITCH = 80;                       // phase B: A block [256 c][32 k] fp16, padded rows
   static constexpr int AP = 256 * APITCH;
   static constexpr int ASTAGE = 2 * AP;                   // 40960
@@ -139,29 +148,49 @@ struct Geo {
   static constexpr int LDS = REGION0 + 2 * BP;
 };
 
-template <int MODE, int TK>
-__global__ __launch_bounds__(256, 1) void attn_kernel(Args a) {
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// FULL: C == 256 and T == TK (every 16 x 16 attention block of the shipped configs).  Both loops are then unrolled into
+// straight-line code -- not for the branches: with the chunk loop rolled, hipcc's s_waitcnt insertion merges the counter
+// states of the loop's paths and makes every iteration wait for the loads it has just issued (vmcnt(9) ... vmcnt(0)
+// behind a fresh 10-load fetch: 3000 cycles per chunk instead of 800) -- and the m < T masks disappear.
+//
+// Waves.  TK / 32 waves, two per SIMD for T = 256: a wave alone on its SIMD exposes every latency of its in-order
+// stream (fragment reads, LDS store hand-off, barrier) and hides at most ~5 issue slots behind an MFMA; measured with
+// four waves, a chunk took 2400 cycles of which the MFMAs are 768.  With a partner wave on the SIMD the two streams
+// fill each other's gaps.
+template <int MODE, int TK, bool FULL>
+__global__ __launch_bounds__(TK * 2, TK / 128) void attn_kernel(Args a) {   // NT threads, NW / 4 waves per SIMD
   using G = Geo<MODE, TK>;
-  constexpr int NG = G::NG, CK = G::CK, KS = G::KS, MBW = G::MBW, XBLK = G::XBLK;
-  static_assert(G::YI >= 1 || MODE != MODE_FWD, "geometry");
+  constexpr int NG = G::NG, CK = G::CK, KS = G::KS, NW = G::NW, NT = G::NT;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS];
-  __shared__ float red[2][4][64];                 // cross-wave column statistics
+  __shared__ float red[2][NW][64];                // cross-wave column statistics
   __shared__ float rowstat[2][TK];                // DKV: lse[m], delta[m]
-  __shared__ float sred[8];
+  __shared__ float sred[NW];
   unsigned char* const bm = lds + G::REGION0;     // probabilities / score gradients for phase B
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntile = (a.T + 63) >> 6;
+  const int ntile = FULL ? TK / 64 : (a.T + 63) >> 6;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int b = id / ntile, n0 = (id - b * ntile) * 64;
-  const int T = a.T, C = a.C;
+  const int T = FULL ? TK : a.T, C = FULL ? 256 : a.C;
+  int stamp_i = 0;
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[stamp_i] = (long long)__builtin_amdgcn_s_memtime();
+    ++stamp_i;
+  };
+  stamp();
 
   // ---- scales of the tensor operands: maxima of their 256-entry records -------------------------------------------------
   float sx[2] = {1.f, 1.f}, sy[2] = {1.f, 1.f}, sa[2] = {1.f, 1.f};
   {
     float m[6];
-    m[0] = a.rx[0][tid]; m[1] = a.ry[0][tid]; m[2] = a.ra[0][tid];
-    m[3] = NG == 2 ? a.rx[1][tid] : 0.f; m[4] = NG == 2 ? a.ry[1][tid] : 0.f; m[5] = MODE == MODE_DKV ? a.ra[1][tid] : 0.f;
+    const int ri = tid & 255;
+    m[0] = a.rx[0][ri]; m[1] = a.ry[0][ri]; m[2] = a.ra[0][ri];
+    m[3] = NG == 2 ? a.rx[1][ri] : 0.f; m[4] = NG == 2 ? a.ry[1][ri] : 0.f; m[5] = MODE == MODE_DKV ? a.ra[1][ri] : 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) m[i] = wave_max(m[i]);
     float* r6 = reinterpret_cast<float*>(lds);
@@ -171,78 +200,107 @@ __global__ __launch_bounds__(256, 1) void attn_kernel(Args a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 6; ++i) m[i] = fmaxf(fmaxf(r6[i], r6[6 + i]), fmaxf(r6[12 + i], r6[18 + i]));
+    for (int i = 0; i < 6; ++i) m[i] = fmaxf(fmaxf(r6[i], r6[6 + i]), fmaxf(r6[12 + i], r6[18 + i]));   // waves 0..3 hold all 256
     __syncthreads();
     sx[0] = pow2_scale_of(m[0]); sy[0] = pow2_scale_of(m[1]); sa[0] = pow2_scale_of(m[2]);
     sx[1] = pow2_scale_of(m[3]); sy[1] = pow2_scale_of(m[4]); sa[1] = pow2_scale_of(m[5]);
   }
   if (MODE == MODE_DKV) {
-    for (int m = tid; m < TK; m += 256) {
+    for (int m = tid; m < TK; m += NT) {
       rowstat[0][m] = m < T ? a.lse[(long)b * T + m] : INFINITY;       // exp(s - inf) = 0 for the padding rows
       rowstat[1][m] = m < T ? a.delta[(long)b * T + m] : 0.f;
     }
   }
 
-  // ---- phase A: D_g[m, n] = sum_c X_g[c, m] Y_g[c, n] --------------------------------------------------------------------
+  stamp();
+  // ---- phase A: D_g[m, n] = sum_c X_g[c, m] Y_g[c, n];  wave w owns rows m = 32 w .. 32 w + 31 -------------------------
   const long tensor_bytes = (long)a.B * C * T * 4;
   const int l8 = lane >> 3, l7 = lane & 7;
   __amdgpu_buffer_rsrc_t xrs[NG], yrs[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) { xrs[g] = make_rsrc(a.x[g], tensor_bytes); yrs[g] = make_rsrc(a.y[g], tensor_bytes); }
-  // a 16-byte load covers 4 positions of one channel; a wave instruction 8 channels x 32 positions (one 32-block)
-  unsigned xvo[G::XI], xdst[G::XI], yvo[G::YI1], ydst[G::YI1];
+  // A 16-byte load covers 4 positions of one channel; a wave instruction 8 channels x 32 positions (one 32-block).
+  // X tiles: wave w stages 32-block w (the rows it multiplies), channel groups j = 0 .. CK / 8 - 1.
+  // Y tiles (2 blocks x CK / 8 groups x NG operands = NW YT instructions): flat index f = wid + NW j.
+  unsigned xvo[G::XI], xdst[G::XI], yvo[G::YT], ydst[G::YT];
+  int yg[G::YT];
 #pragma unroll
   for (int j = 0; j < G::XI; ++j) {
-    const int i = wid + 4 * j, mblk = i % XBLK, c = (i / XBLK) * 8 + l8, m = mblk * 32 + 4 * l7;
+    const int c = j * 8 + l8, m = wid * 32 + 4 * l7;
     xvo[j] = (unsigned)(c * T + m) * 4u | (m < T ? 0u : 0x80000000u);          // bit 31: out of range -> zeros
-    xdst[j] = (unsigned)((mblk * CK + c) * 64 + 8 * l7);
+    xdst[j] = (unsigned)((wid * CK + c) * 64 + 8 * l7);
   }
-  // Y tiles: 2 blocks x CK / 8 instructions; with CK = 16 that is one instruction per wave, with CK = 32 two
 #pragma unroll
-  for (int j = 0; j < G::YI1; ++j) {
-    const int i = wid + 4 * j, nblk = i & 1, c = (i >> 1) * 8 + l8, n = nblk * 32 + 4 * l7;
+  for (int j = 0; j < G::YT; ++j) {
+    const int f = wid + NW * j, per = 2 * (CK / 8), g = f / per, r = f % per;
+    const int nblk = r & 1, c = (r >> 1) * 8 + l8, n = nblk * 32 + 4 * l7;
+    yg[j] = g;                                                                  // wave-uniform
     yvo[j] = (unsigned)(c * T + n0 + n) * 4u | (n0 + n < T ? 0u : 0x80000000u);
-    ydst[j] = (unsigned)((nblk * CK + c) * 64 + 8 * l7);
+    ydst[j] = (unsigned)(g * G::GSZ + 2 * G::XP + (nblk * CK + c) * 64 + 8 * l7);
   }
-  u32x4 xr[NG][G::XI], yr[NG][G::YI1];
-  auto fetch = [&](int chunk) __attribute__((always_inline)) {
+  // Two register sets: the loads of chunk c + 2 are issued at the top of iteration c while chunk c + 1 (the other set)
+  // is being split and written to LDS between the MFMAs of chunk c.
+  constexpr int NPA = G::NPA;
+  u32x4 ra[2][NPA];
+  auto fetch = [&](auto SET, int chunk) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
     const unsigned soff = (unsigned)((b * C + chunk * CK) * T) * 4u;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int j = 0; j < G::XI; ++j)
-        xr[g][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs[g], (int)xvo[j], (int)soff, 0));
+        ra[S][g * G::XI + j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs[g], (int)xvo[j], (int)soff, 0));
 #pragma unroll
-      for (int j = 0; j < G::YI1; ++j)
-        yr[g][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs[g], (int)yvo[j], (int)soff, 0));
-    }
+    for (int j = 0; j < G::YT; ++j)
+      ra[S][NG * G::XI + j] = __builtin_bit_cast(
+          u32x4, __builtin_amdgcn_raw_buffer_load_b128(NG == 2 && yg[j] ? yrs[NG - 1] : yrs[0], (int)yvo[j], (int)soff, 0));
   };
-  auto put = [&](unsigned char* hi_plane, int plane_bytes, unsigned dst, u32x4 r, float s) __attribute__((always_inline)) {
-    const float v[4] = {s * __uint_as_float(r[0]), s * __uint_as_float(r[1]), s * __uint_as_float(r[2]), s * __uint_as_float(r[3])};
-    u32x2 hi, lo;
-    split4(v, hi, lo);
-    *reinterpret_cast<u32x2*>(hi_plane + dst) = hi;
+  // A piece goes to LDS in two halves (so that they can be placed between MFMAs): scale + hi terms, then lo terms + stores
+  // (instruction selection is pinned by inline asm: left to itself the compiler packs the multiplies into v_pk_mul_f32
+  // and evaluates the lo terms as v_cvt_f32_f16 + v_pk_add_f32 + s_nop, 12+ issue slots per piece instead of 10, and
+  // packed fp32 VALU beside MFMAs costs extra -- MI355X_MICROARCH.md, price of a filler)
+  struct Half { float v[4]; u32x2 hi; };
+  auto half_a = [&](Half& h, u32x4 r, float s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm("v_mul_f32 %0, %1, %2" : "=v"(h.v[i]) : "v"(s), "v"(__uint_as_float(r[i])));
+    h.hi = u32x2{pack_h2(h.v[0], h.v[1]), pack_h2(h.v[2], h.v[3])};
+  };
+  auto half_b = [&](const Half& h, unsigned char* hi_plane, int plane_bytes, unsigned dst) __attribute__((always_inline)) {
+    u32x2 lo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned d;                                  // lo = fp16(v - hi): one v_fma_mix per element, (-1) * hi + v
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h.hi[i]), "v"(h.v[2 * i]));
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(h.hi[i]), "v"(h.v[2 * i + 1]));
+      lo[i] = d;
+    }
+    *reinterpret_cast<u32x2*>(hi_plane + dst) = h.hi;
     *reinterpret_cast<u32x2*>(hi_plane + plane_bytes + dst) = lo;
   };
-  auto stage = [&](unsigned char* buf) __attribute__((always_inline)) {
+  // piece q of a chunk: the X pieces of GEMM 0, of GEMM 1, then the Y pieces
+  auto piece_a = [&](auto SET, int q, Half& h) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    float s;
+    if (q < NG * G::XI) s = sx[q / G::XI];
+    else s = (NG == 2 && yg[q - NG * G::XI]) ? sy[NG - 1] : sy[0];
+    half_a(h, ra[S][q], s);
+  };
+  auto piece_b = [&](int q, const Half& h, unsigned char* buf) __attribute__((always_inline)) {
+    if (q < NG * G::XI) half_b(h, buf + (q / G::XI) * G::GSZ, G::XP, xdst[q % G::XI]);
+    else half_b(h, buf, G::YP, ydst[q - NG * G::XI]);
+  };
+  auto stage = [&](auto SET, unsigned char* buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-#pragma unroll
-      for (int j = 0; j < G::XI; ++j) put(buf + g * G::GSZ, G::XP, xdst[j], xr[g][j], sx[g]);
-#pragma unroll
-      for (int j = 0; j < G::YI1; ++j) put(buf + g * G::GSZ + 2 * G::XP, G::YP, ydst[j], yr[g][j], sy[g]);
-    }
+    for (int q = 0; q < NPA; ++q) { Half h; piece_a(SET, q, h); piece_b(q, h, buf); }
   };
 
-  floatx16 acc[NG][MBW][2];
+  floatx16 acc[NG][2];
 #pragma unroll
   for (int g = 0; g < NG; ++g)
 #pragma unroll
-    for (int mb = 0; mb < MBW; ++mb)
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[g][mb][nb][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[g][nb][e] = 0.f;
 
   // transpose-read addresses: lane (mm = lane % 16, g4 = lane / 16) supplies the 8 bytes at channel k0 + mm / 4,
   // positions r0 + 4 (mm % 4) .. + 3 and receives channels k0 .. k0 + 3 of position r0 + mm:  r0 = 16 (g4 & 1),
@@ -254,151 +312,211 @@ __global__ __launch_bounds__(256, 1) void attn_kernel(Args a) {
                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p + tr0 + 4 * 64)));
   };
   constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};        // cross terms first (fixed accumulation order)
-  auto mma_a = [&](const unsigned char* buf) __attribute__((always_inline)) {
+  // One chunk: NMA MFMAs in (k step, GEMM) groups of 6, with the 2 NPA half pieces of the NEXT chunk's staging placed
+  // between them (the scheduler left to itself runs all the staging first and the MFMAs back to back after it).
+  constexpr int GS = 6, NMA = KS * NG * GS;
+  constexpr int PRE_A = (2 * NPA) / 5, REST_A = 2 * NPA - PRE_A;
+  auto chunk_a = [&](auto PAR, auto MORE, bool fetch2, int c) __attribute__((always_inline)) {
+    constexpr int P = decltype(PAR)::value;
+    constexpr bool more = decltype(MORE)::value;               // a next chunk exists: stage it between the MFMAs
+    using SetNext = std::integral_constant<int, 1 - P>;
+    const unsigned char* cur = lds + P * G::STAGE;
+    unsigned char* nxt = lds + (1 - P) * G::STAGE;
+    if (fetch2) fetch(PAR, c + 2);                            // set P was consumed when chunk c was staged
+    halfx8 xa[KS][NG][2], yb[KS][NG][2][2];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        halfx8 xa[MBW][2], yb[2][2];
+      for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-#pragma unroll
-          for (int mb = 0; mb < MBW; ++mb)
-            xa[mb][p] = tr8(buf + g * G::GSZ + p * G::XP + ((wid * MBW + mb) * CK + kk * 16) * 64);
+          xa[kk][g][p] = tr8(cur + g * G::GSZ + p * G::XP + (wid * CK + kk * 16) * 64);
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
-            yb[nb][p] = tr8(buf + g * G::GSZ + 2 * G::XP + p * G::YP + (nb * CK + kk * 16) * 64);
+            yb[kk][g][nb][p] = tr8(cur + g * G::GSZ + 2 * G::XP + p * G::YP + (nb * CK + kk * 16) * 64);
         }
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-          for (int mb = 0; mb < MBW; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-              acc[g][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[mb][SA[pr]], yb[nb][SB[pr]], acc[g][mb][nb], 0, 0, 0);
+    Half h;
+    int hp = 0;                                                 // half pieces done (compile-time after unrolling)
+    auto half_piece = [&]() __attribute__((always_inline)) {
+      if (more) {
+        if ((hp & 1) == 0) piece_a(SetNext{}, hp >> 1, h); else piece_b(hp >> 1, h, nxt);
       }
+      ++hp;
+    };
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < PRE_A; ++i) half_piece();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NMA; ++i) {
+      const int gi = i / GS, kk = gi / NG, g = gi % NG, r = i % GS, pr = r / 2, nb = r % 2;
+      acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk][g][SA[pr]], yb[kk][g][nb][SB[pr]], acc[g][nb], 0, 0, 0);
+      if (((i + 1) * REST_A) / NMA > (i * REST_A) / NMA) half_piece();
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
 
   const int nchunk = C / CK;
-  fetch(0);
-  stage(lds);
-  if (nchunk > 1) fetch(1);
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  fetch(P0{}, 0);
+  if (nchunk > 1) fetch(P1{}, 1);
+  stage(P0{}, lds);
   __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    unsigned char* cur = lds + (c & 1) * G::STAGE;
-    if (c + 1 < nchunk) stage(lds + ((c + 1) & 1) * G::STAGE);
-    if (c + 2 < nchunk) fetch(c + 2);
-    mma_a(cur);
-    __syncthreads();
+  if constexpr (FULL) {
+    constexpr int NCH = 256 / CK;
+    static_for<NCH>([&](auto ci) __attribute__((always_inline)) {
+      constexpr int c = decltype(ci)::value;
+      chunk_a(std::integral_constant<int, (c & 1)>{}, std::bool_constant<(c + 1 < NCH)>{}, c + 2 < NCH, c);
+      __syncthreads();
+    });
+  } else {
+    for (int c = 0; c < nchunk; c += 2) {
+      if (c + 1 < nchunk) chunk_a(P0{}, std::true_type{}, c + 2 < nchunk, c); else chunk_a(P0{}, std::false_type{}, false, c);
+      __syncthreads();
+      if (c + 1 < nchunk) {
+        if (c + 2 < nchunk) chunk_a(P1{}, std::true_type{}, c + 3 < nchunk, c + 1); else chunk_a(P1{}, std::false_type{}, false, c + 1);
+        __syncthreads();
+      }
+    }
   }
 
-  // ---- phase B plumbing ----------------------------------------------------------------------------------------------
+  stamp();
+  // ---- phase B plumbing: out[c, n] = sum_k A[c, k] bm[n, k];  wave w owns channel blocks CBW w .. CBW w + CBW - 1 ------
+  constexpr int CBW = G::CBW, AI = G::AI;
   __amdgpu_buffer_rsrc_t ars = make_rsrc(a.a[0], tensor_bytes);
-  const int KB = (T + 31) >> 5;                               // 32-position blocks of the contraction
-  const int cw = C >> 5;                                       // live 32-channel blocks
-  unsigned avo[8], adst[8];
+  const int KB = FULL ? TK / 32 : (T + 31) >> 5;              // 32-position blocks of the contraction
+  unsigned avo[AI], adst[AI];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = (wid + 4 * j) * 8 + l8;
+  for (int j = 0; j < AI; ++j) {
+    const int c = (wid + NW * j) * 8 + l8;
     avo[j] = (unsigned)(c * T + 4 * l7) * 4u | (c < C ? 0u : 0x80000000u);
     adst[j] = (unsigned)(c * G::APITCH + 8 * l7);
   }
-  u32x4 ar[8];
-  auto fetch_a = [&](int kb) __attribute__((always_inline)) {
+  u32x4 rb[2][AI];
+  auto fetch_a = [&](auto SET, int kb) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
     const unsigned soff = (unsigned)(b * C * T + kb * 32) * 4u;
-    const unsigned dead = kb * 32 + 4 * l7 < T ? 0u : 0x80000000u;
+    const unsigned dead = (FULL || kb * 32 + 4 * l7 < T) ? 0u : 0x80000000u;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      ar[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(avo[j] | dead), (int)soff, 0));
-  };
-  auto stage_a = [&](unsigned char* buf, float s) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) put(buf, G::AP, adst[j], ar[j], s);
+    for (int j = 0; j < AI; ++j)
+      rb[S][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(avo[j] | dead), (int)soff, 0));
   };
   const int fk = lane >> 5, fc = lane & 31;
-  floatx16 oacc[2][2];
-  auto mma_b = [&](const unsigned char* abuf, int kb) __attribute__((always_inline)) {
-    if (2 * wid >= cw) return;                                 // wave-uniform: no live channels in this wave's rows
+  floatx16 oacc[CBW][2];
+  constexpr int NMB = 12 * CBW, PRE_B = (2 * AI) / 5, REST_B = 2 * AI - PRE_B;
+  // One 32-position block of phase B, the next block's pieces staged between the MFMAs
+  auto block_b = [&](auto PAR, auto MORE, bool fetch2, int kb, float s_a) __attribute__((always_inline)) {
+    constexpr int P = decltype(PAR)::value;
+    constexpr bool more = decltype(MORE)::value;
+    const unsigned char* abuf = lds + P * G::ASTAGE;
+    unsigned char* nxt = lds + (1 - P) * G::ASTAGE;
+    if (fetch2) fetch_a(PAR, kb + 2);
+    halfx8 af[2][CBW][2], bf[2][2][2];                          // [k step][block][plane]
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      halfx8 af[2][2], bf[2][2];
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-          af[cb][p] = *reinterpret_cast<const halfx8*>(abuf + p * G::AP + ((2 * wid + cb) * 32 + fc) * G::APITCH + (kk * 16 + 8 * fk) * 2);
+        for (int cb = 0; cb < CBW; ++cb)
+          af[kk][cb][p] = *reinterpret_cast<const halfx8*>(abuf + p * G::AP + ((CBW * wid + cb) * 32 + fc) * G::APITCH + (kk * 16 + 8 * fk) * 2);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
-          bf[nb][p] = *reinterpret_cast<const halfx8*>(bm + p * G::BP + (nb * 32 + fc) * G::BPITCH + (kb * 32 + kk * 16 + 8 * fk) * 2);
+          bf[kk][nb][p] = *reinterpret_cast<const halfx8*>(bm + p * G::BP + (nb * 32 + fc) * G::BPITCH + (kb * 32 + kk * 16 + 8 * fk) * 2);
       }
+    Half h;
+    int hp = 0;
+    auto half_piece = [&]() __attribute__((always_inline)) {
+      if (more) {
+        if ((hp & 1) == 0) half_a(h, rb[1 - P][hp >> 1], s_a); else half_b(h, nxt, G::AP, adst[hp >> 1]);
+      }
+      ++hp;
+    };
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int pr = 0; pr < 3; ++pr)
+    for (int i = 0; i < PRE_B; ++i) half_piece();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb)
-            oacc[cb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][SA[pr]], bf[nb][SB[pr]], oacc[cb][nb], 0, 0, 0);
+    for (int i = 0; i < NMB; ++i) {
+      const int kk = i / (6 * CBW), r = i % (6 * CBW), pr = r / (2 * CBW), cb = (r / 2) % CBW, nb = r % 2;
+      oacc[cb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][cb][SA[pr]], bf[kk][nb][SB[pr]], oacc[cb][nb], 0, 0, 0);
+      if (((i + 1) * REST_B) / NMB > (i * REST_B) / NMB) half_piece();
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // probabilities (or score gradients) of this thread's accumulator tiles -> bm[n][m], two planes
-  auto put_bm = [&](const floatx16 (&d)[MBW][2], float s) __attribute__((always_inline)) {
+  auto put_bm = [&](const floatx16 (&d)[2], float s) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mb = 0; mb < MBW; ++mb)
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float v[4] = {s * d[mb][nb][4 * j], s * d[mb][nb][4 * j + 1], s * d[mb][nb][4 * j + 2], s * d[mb][nb][4 * j + 3]};
-          u32x2 hi, lo;
-          split4(v, hi, lo);
-          const unsigned o = (unsigned)((nb * 32 + fc) * G::BPITCH + ((wid * MBW + mb) * 32 + 8 * j + 4 * fk) * 2);
-          *reinterpret_cast<u32x2*>(bm + o) = hi;
-          *reinterpret_cast<u32x2*>(bm + G::BP + o) = lo;
-        }
+      for (int j = 0; j < 4; ++j) {
+        const float v[4] = {s * d[nb][4 * j], s * d[nb][4 * j + 1], s * d[nb][4 * j + 2], s * d[nb][4 * j + 3]};
+        u32x2 hi, lo;
+        split4(v, hi, lo);
+        const unsigned o = (unsigned)((nb * 32 + fc) * G::BPITCH + (wid * 32 + 8 * j + 4 * fk) * 2);
+        *reinterpret_cast<u32x2*>(bm + o) = hi;
+        *reinterpret_cast<u32x2*>(bm + G::BP + o) = lo;
+      }
   };
   // one GEMM of phase B: out[c, n] = beta out + post[n] / (sa sb) sum_m A[c, m] bm[n, m]
   auto phase_b = [&](int which, float s_a, float s_b, const float (&post)[2]) __attribute__((always_inline)) {
     ars = make_rsrc(a.a[which], tensor_bytes);
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[cb][nb][e] = 0.f;
-    fetch_a(0);
-    stage_a(lds, s_a);
-    if (KB > 1) fetch_a(1);
+    fetch_a(P0{}, 0);
+    if (KB > 1) fetch_a(P1{}, 1);
+#pragma unroll
+    for (int j = 0; j < AI; ++j) { Half h; half_a(h, rb[0][j], s_a); half_b(h, lds, G::AP, adst[j]); }
     __syncthreads();                                           // also: bm is complete
-    for (int kb = 0; kb < KB; ++kb) {
-      if (kb + 1 < KB) stage_a(lds + ((kb + 1) & 1) * G::ASTAGE, s_a);
-      if (kb + 2 < KB) fetch_a(kb + 2);
-      mma_b(lds + (kb & 1) * G::ASTAGE, kb);
-      __syncthreads();
+    stamp();
+    if constexpr (FULL) {
+      constexpr int NKB = TK / 32;
+      static_for<NKB>([&](auto ki) __attribute__((always_inline)) {
+        constexpr int kb = decltype(ki)::value;
+        block_b(std::integral_constant<int, (kb & 1)>{}, std::bool_constant<(kb + 1 < NKB)>{}, kb + 2 < NKB, kb, s_a);
+        __syncthreads();
+      });
+    } else {
+      for (int kb = 0; kb < KB; kb += 2) {
+        if (kb + 1 < KB) block_b(P0{}, std::true_type{}, kb + 2 < KB, kb, s_a); else block_b(P0{}, std::false_type{}, false, kb, s_a);
+        __syncthreads();
+        if (kb + 1 < KB) {
+          if (kb + 2 < KB) block_b(P1{}, std::true_type{}, kb + 3 < KB, kb + 1, s_a); else block_b(P1{}, std::false_type{}, false, kb + 1, s_a);
+          __syncthreads();
+        }
+      }
     }
-    if (2 * wid >= cw) return;
-    float* out = a.out[which] + (long)b * C * T;
+    stamp();
+    // rows of channels >= C were computed from zeros and are not stored
+    __amdgpu_buffer_rsrc_t ors = make_rsrc(a.out[which], tensor_bytes);
     const float beta = a.beta[which];
     const float inv = 1.f / (s_a * s_b);
+    const unsigned obase = (unsigned)(b * C * T) * 4u;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const int n = n0 + nb * 32 + fc;
-      if (n >= T) continue;
       const float f = inv * post[nb];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        const int cbase = (2 * wid + cb) * 32 + 4 * fk;
-        if (cbase >= C) continue;
+      for (int cb = 0; cb < CBW; ++cb) {
+        const int cbase = (CBW * wid + cb) * 32 + 4 * fk;
+        const unsigned vo = (unsigned)(cbase * T + n) * 4u | ((n < T && cbase < C) ? 0u : 0x80000000u);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          float* p = out + (long)(cbase + acc_row(e)) * T + n;
-          const float v = f * oacc[cb][nb][e];
-          *p = beta != 0.f ? __fmaf_rn(beta, *p, v) : v;
+          const unsigned so = obase + (unsigned)(acc_row(e) * T) * 4u;
+          float v = f * oacc[cb][nb][e];
+          if (beta != 0.f)
+            v = __fmaf_rn(beta, __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, (int)vo, (int)so, 0)), v);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, (int)vo, (int)so, 0);
         }
       }
     }
   };
 
-  // column statistics over m: this thread's MBW x 16 values of column (nb, fc), its partner half-wave, the four waves
+  // column statistics over m: this thread's 16 values of column (nb, fc), its partner half-wave, the NW waves
   auto col_reduce = [&](float (&v)[2], int slot, bool is_max) __attribute__((always_inline)) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -409,9 +527,10 @@ __global__ __launch_bounds__(256, 1) void attn_kernel(Args a) {
     __syncthreads();
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      const float r0 = red[slot][0][nb * 32 + fc], r1 = red[slot][1][nb * 32 + fc];
-      const float r2 = red[slot][2][nb * 32 + fc], r3 = red[slot][3][nb * 32 + fc];
-      v[nb] = is_max ? fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)) : (r0 + r1) + (r2 + r3);
+      float r = red[slot][0][nb * 32 + fc];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) r = is_max ? fmaxf(r, red[slot][w][nb * 32 + fc]) : r + red[slot][w][nb * 32 + fc];
+      v[nb] = r;
     }
   };
   const float ones[2] = {1.f, 1.f};
@@ -421,37 +540,35 @@ __global__ __launch_bounds__(256, 1) void attn_kernel(Args a) {
     const float us = a.scale / (sx[0] * sy[0]);
     float mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
-    for (int mb = 0; mb < MBW; ++mb)
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = (wid * MBW + mb) * 32 + 4 * fk + acc_row(e);
-          const float s = m < T ? us * acc[0][mb][nb][e] : -INFINITY;
-          acc[0][mb][nb][e] = s;
-          mx[nb] = fmaxf(mx[nb], s);
-        }
+      for (int e = 0; e < 16; ++e) {
+        const int m = wid * 32 + 4 * fk + acc_row(e);
+        const float s = (FULL || m < T) ? us * acc[0][nb][e] : -INFINITY;
+        acc[0][nb][e] = s;
+        mx[nb] = fmaxf(mx[nb], s);
+      }
     col_reduce(mx, 0, true);
     float sum[2] = {0.f, 0.f};
 #pragma unroll
-    for (int mb = 0; mb < MBW; ++mb)
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float p = expf(acc[0][mb][nb][e] - mx[nb]);
-          acc[0][mb][nb][e] = p;
-          sum[nb] += p;
-        }
+      for (int e = 0; e < 16; ++e) {
+        const float p = expf(acc[0][nb][e] - mx[nb]);
+        acc[0][nb][e] = p;
+        sum[nb] += p;
+      }
     col_reduce(sum, 1, false);
     if (wid == 0 && fk == 0) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
         if (n0 + nb * 32 + fc < T) a.lse[(long)b * T + n0 + nb * 32 + fc] = mx[nb] + logf(sum[nb]);
     }
+    stamp();
     put_bm(acc[0], P_SCALE);
     const float post[2] = {1.f / sum[0], 1.f / sum[1]};
     phase_b(0, sa[0], P_SCALE, post);
+    stamp();
   } else {
     // p = exp(scale s - lse), ds = scale p (dp - delta): lse / delta per column (DQ) or per row (DKV)
     const float us = a.scale / (sx[0] * sy[0]), ud = 1.f / (sx[1] * sy[1]);
@@ -464,18 +581,16 @@ __global__ __launch_bounds__(256, 1) void attn_kernel(Args a) {
         lse_n[nb] = n < T ? a.lse[(long)b * T + n] : 0.f;
       }
 #pragma unroll
-      for (int mb = 0; mb < MBW; ++mb)
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int m = (wid * MBW + mb) * 32 + 4 * fk + acc_row(e);
-            const float p = (m < T && nlive[nb]) ? expf(us * acc[0][mb][nb][e] - lse_n[nb]) : 0.f;
-            const float dp = ud * acc[1][mb][nb][e];
-            acc[0][mb][nb][e] = p;
-            acc[1][mb][nb][e] = dp;
-            dl[nb] = __fmaf_rn(p, dp, dl[nb]);
-          }
+        for (int e = 0; e < 16; ++e) {
+          const int m = wid * 32 + 4 * fk + acc_row(e);
+          const float p = (FULL || (m < T && nlive[nb])) ? expf(us * acc[0][nb][e] - lse_n[nb]) : 0.f;
+          const float dp = ud * acc[1][nb][e];
+          acc[0][nb][e] = p;
+          acc[1][nb][e] = dp;
+          dl[nb] = __fmaf_rn(p, dp, dl[nb]);
+        }
       col_reduce(dl, 0, false);
       if (wid == 0 && fk == 0) {
 #pragma unroll
@@ -485,28 +600,29 @@ __global__ __launch_bounds__(256, 1) void attn_kernel(Args a) {
     }
     float dmax = 0.f;
 #pragma unroll
-    for (int mb = 0; mb < MBW; ++mb)
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float p, dp, de;
-          if (MODE == MODE_DQ) {
-            p = acc[0][mb][nb][e]; dp = acc[1][mb][nb][e]; de = dl[nb];
-          } else {
-            const int m = (wid * MBW + mb) * 32 + 4 * fk + acc_row(e);
-            p = nlive[nb] ? expf(us * acc[0][mb][nb][e] - rowstat[0][m]) : 0.f;
-            dp = ud * acc[1][mb][nb][e]; de = rowstat[1][m];
-            acc[0][mb][nb][e] = p;
-          }
-          const float ds = a.scale * (p * (dp - de));
-          acc[1][mb][nb][e] = ds;
-          dmax = fmaxf(dmax, fabsf(ds));
+      for (int e = 0; e < 16; ++e) {
+        float p, dp, de;
+        if (MODE == MODE_DQ) {
+          p = acc[0][nb][e]; dp = acc[1][nb][e]; de = dl[nb];
+        } else {
+          const int m = wid * 32 + 4 * fk + acc_row(e);
+          p = (FULL || nlive[nb]) ? expf(us * acc[0][nb][e] - rowstat[0][m]) : 0.f;
+          dp = ud * acc[1][nb][e]; de = rowstat[1][m];
+          acc[0][nb][e] = p;
         }
+        const float ds = a.scale * (p * (dp - de));
+        acc[1][nb][e] = ds;
+        dmax = fmaxf(dmax, fabsf(ds));
+      }
     dmax = wave_max(dmax);
     if (lane == 0) sred[wid] = dmax;
     __syncthreads();
-    const float sds = pow2_scale_of(fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3])));
+    float dm = sred[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) dm = fmaxf(dm, sred[w]);
+    const float sds = pow2_scale_of(dm);
     if (MODE == MODE_DQ) {
       put_bm(acc[1], sds);
       phase_b(0, sa[0], sds, ones);                            // dq = k ds
@@ -526,8 +642,9 @@ inline bool attn_ok(int B, int C, int T) {
 template <int MODE>
 int launch(const Args& a, hipStream_t s) {
   const unsigned grid = (unsigned)(a.B * ((a.T + 63) / 64));
-  if (a.T <= 128) hipLaunchKernelGGL((attn_kernel<MODE, 128>), dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((attn_kernel<MODE, 256>), dim3(grid), dim3(256), 0, s, a);
+  if (a.T == 256 && a.C == 256) hipLaunchKernelGGL((attn_kernel<MODE, 256, true>), dim3(grid), dim3(512), 0, s, a);
+  else if (a.T <= 128) hipLaunchKernelGGL((attn_kernel<MODE, 128, false>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attn_kernel<MODE, 256, false>), dim3(grid), dim3(512), 0, s, a);
   STK_CHECK_LAUNCH();
   return STK_OK;
 }
@@ -553,6 +670,16 @@ int stk_attention_fwd_f32(const float* q, const float* k, const float* v, float*
   a.out[0] = o; a.out[1] = o; a.beta[0] = a.beta[1] = 0.f; a.lse = lse; a.delta = nullptr;
   a.B = B; a.C = C; a.T = T; a.scale = scale;
   return launch<MODE_FWD>(a, s);
+}
+
+/* development aid (not in include/stk.h): the forward kernel alone with cycle stamps of workgroup 0 in dbg[0..8) */
+int stk_attention_fwd_debug(const float* q, const float* k, const float* v, float* o, float* lse, float* rec, int B, int C,
+                            int T, float scale, long long* dbg, void* stream) {
+  Args a = {};
+  a.x[0] = k; a.rx[0] = rec + NPART; a.y[0] = q; a.ry[0] = rec; a.a[0] = v; a.ra[0] = rec + 2 * NPART;
+  a.x[1] = k; a.rx[1] = rec + NPART; a.y[1] = q; a.ry[1] = rec; a.a[1] = v; a.ra[1] = rec + 2 * NPART;
+  a.out[0] = o; a.out[1] = o; a.lse = lse; a.B = B; a.C = C; a.T = T; a.scale = scale; a.dbg = dbg;
+  return launch<MODE_FWD>(a, (hipStream_t)stream);
 }
 
 int stk_attention_bwd_f32(const float* q, const float* k, const float* v, const float* d_o, const float* lse, float* rec,

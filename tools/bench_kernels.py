@@ -130,6 +130,36 @@ def main():
       rec('gn_silu.fwd', shape, timeit(lambda: call(lib, 'gn_fwd_f32', x, C, None, 0, g, b, y, mean, rstd, Nb, H * H, G, 1e-6, 1, 0.1, 1, None, ws), args.reps), nbytes=2 * nb)
       rec('gn_silu.bwd', shape, timeit(lambda: call(lib, 'gn_bwd_f32', dy, x, C, None, 0, g, b, mean, rstd, dx, 0.0, None, 0.0, dg, db, ws, Nb, H * H, G, 1, 0.1, 1, None), args.reps), nbytes=3 * nb)
 
+  if not args.only or 'attn' in args.only:
+    # attention core: fused kernels against the GEMM + softmax sequence they replace (engine/graph.py AttentionCore)
+    for C, T in ([(256, 256)] if 'attn256' in args.only else [(256, 256), (256, 64), (256, 16)]):
+      B = N
+      q, k, v, do = (torch.randn(B, C, T, device=d) for _ in range(4))
+      o, dq, dk, dv = (torch.empty(B, C, T, device=d) for _ in range(4))
+      lse, delta, rcd = torch.empty(B, T, device=d), torch.empty(B, T, device=d), torch.empty(1024, device=d)
+      S, Pm = torch.empty(B, T, T, device=d), torch.empty(B, T, T, device=d)
+      sc = float(C) ** -0.5
+      shape = f'C{C} T{T} b{B}'
+      fl = 2.0 * B * T * T * C
+      rec('attn.fwd.fused', shape, timeit(lambda: call(lib, 'attention_fwd_f32', q, k, v, o, lse, rcd, B, C, T, sc), args.reps), flops=2 * fl)
+      rec('attn.bwd.fused', shape, timeit(lambda: call(lib, 'attention_bwd_f32', q, k, v, do, lse, rcd, delta, dq, 0.0, dk, 0.0, dv, 0.0, B, C, T, sc), args.reps), flops=4 * fl)
+
+      def unfused_fwd():
+        call(lib, 'gemm_f32', q, 1, T, C * T, k, T, 1, C * T, S, T, 1, T * T, None, 0, T, T, C, B, 1.0, 0.0)
+        call(lib, 'softmax_fwd_f32', S, Pm, B * T, T, sc)
+        call(lib, 'gemm_f32', v, T, 1, C * T, Pm, 1, T, T * T, o, T, 1, C * T, None, 0, C, T, T, B, 1.0, 0.0)
+
+      def unfused_bwd():
+        call(lib, 'gemm_f32', do, 1, T, C * T, v, T, 1, C * T, S, T, 1, T * T, None, 0, T, T, C, B, 1.0, 0.0)
+        call(lib, 'gemm_f32', do, T, 1, C * T, Pm, T, 1, T * T, dv, T, 1, C * T, None, 0, C, T, T, B, 1.0, 0.0)
+        call(lib, 'softmax_bwd_f32', Pm, S, S, B * T, T, sc)
+        call(lib, 'gemm_f32', k, T, 1, C * T, S, 1, T, T * T, dq, T, 1, C * T, None, 0, C, T, T, B, 1.0, 0.0)
+        call(lib, 'gemm_f32', q, T, 1, C * T, S, T, 1, T * T, dk, T, 1, C * T, None, 0, C, T, T, B, 1.0, 0.0)
+      if 'attn256' in args.only:
+        continue
+      rec('attn.fwd.gemms', shape, timeit(unfused_fwd, args.reps), flops=2 * fl)
+      rec('attn.bwd.gemms', shape, timeit(unfused_bwd, args.reps), flops=4 * fl)
+
   if not args.only or 'bias' in args.only:
     for C, H in [(128, 32), (256, 16), (256, 8), (256, 4)]:
       dy = torch.randn(N, C, H, H, device=d)
