@@ -163,7 +163,7 @@ struct DropMask {
   template <int V> __device__ void run(long i) const {
     Vec<V> v;
 #pragma unroll
-    for (int j = 0; j < V; ++j) v.v[j] = (stk_uniform(seed, (unsigned long long)(i * V + j)) >= p) ? ks : 0.f;
+    for (int j = 0; j < V; ++j) v.v[j] = stk_keep(seed, (unsigned long long)(i * V + j), stk_drop_threshold(p)) ? ks : 0.f;
     v.store(mask, i);
   }
 };

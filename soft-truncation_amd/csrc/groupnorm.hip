@@ -28,7 +28,7 @@ struct GnArgs {
   int C1, C2;
   const float* gamma; const float* beta;
   int N, HW, G, cpg;
-  int act; float drop_p; float keep_scale;
+  int act; float drop_p; float keep_scale; unsigned drop_thr;     // drop_thr = stk_drop_threshold(drop_p)
   unsigned long long seed; const unsigned long long* seed_dev;
 };
 
@@ -59,8 +59,8 @@ __device__ __forceinline__ void group_segments(const GnArgs& a, int n, int g, Se
 // u * sigmoid(u) with the accurate expf and the IEEE division.  The hardware forms were tried and rejected: __expf
 // (argument scaling costs |u| * 2^-24) moved the likelihood ODE's latent to 3e-4 from the reference's fixture, and
 // even the 1-ulp v_rcp_f32 raised the noise floor of the adaptive solver enough for 10 % more function evaluations.
-// Dropout indices of a float4 are written as (multiple of 4) + j with the multiple made visible to the compiler
-// (`& ~3`, a no-op on these values), so the two stk_uniform calls of a pair share one 64-bit mix (stk_rng.h).
+// Dropout: a float4 item is exactly one quad of the counter RNG (stk_rng.h): one 64-bit mix per item, a 16-bit field
+// per element (its flat index is a multiple of 4 because H*W is).
 __device__ __forceinline__ float silu_f(float u) { return u / (1.f + expf(-u)); }
 
 // ---- forward ------------------------------------------------------------------------------------
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(1024) void gn_fwd_flat_kernel(GnArgs a, float* __re
     for (int j = 0; j < 4; ++j) {
       float u = ga * ((r[j] - mean) * rstd) + be;
       float t = a.act ? silu_f(u) : u;
-      if (a.drop_p > 0.f) t = (stk_uniform(seed, ((flat0 + (unsigned long long)(i * 4)) & ~3ULL) + j) >= a.drop_p) ? t * a.keep_scale : 0.f;
+      if (a.drop_p > 0.f) t = stk_drop_field(stk_mix64(seed, (flat0 + (unsigned long long)(i * 4)) >> 2), j) >= a.drop_thr ? t * a.keep_scale : 0.f;
       r[j] = t;
     }
     o4[i] = make_float4(r[0], r[1], r[2], r[3]);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs a, float* __restrict
         for (int j = 0; j < 4; ++j) {
           float u = ga * ((r[j] - mean) * rstd) + be;
           float t = a.act ? silu_f(u) : u;
-          if (a.drop_p > 0.f) t = (stk_uniform(seed, ((flat0 + (unsigned long long)(i * 4)) & ~3ULL) + j) >= a.drop_p) ? t * a.keep_scale : 0.f;
+          if (a.drop_p > 0.f) t = stk_drop_field(stk_mix64(seed, (flat0 + (unsigned long long)(i * 4)) >> 2), j) >= a.drop_thr ? t * a.keep_scale : 0.f;
           r[j] = t;
         }
         o4[i] = make_float4(r[0], r[1], r[2], r[3]);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs a, float* __restrict
         const int c = seg[q].c_first + i / a.HW;
         float u = a.gamma[c] * ((p[i] - mean) * rstd) + a.beta[c];
         float t = a.act ? silu_f(u) : u;
-        if (a.drop_p > 0.f) t = (stk_uniform(seed, flat0 + (unsigned long long)i) >= a.drop_p) ? t * a.keep_scale : 0.f;
+        if (a.drop_p > 0.f) t = stk_keep(seed, flat0 + (unsigned long long)i, a.drop_thr) ? t * a.keep_scale : 0.f;
         o[i] = t;
       }
     }
@@ -215,7 +215,7 @@ __device__ __forceinline__ float gn_du(const GnArgs& a, float xv, float dyv, flo
                                        unsigned long long seed, unsigned long long flat, float& xhat) {
   xhat = (xv - mean) * rstd;
   float go = dyv;
-  if (a.drop_p > 0.f) go = (stk_uniform(seed, flat) >= a.drop_p) ? go * a.keep_scale : 0.f;
+  if (a.drop_p > 0.f) go = stk_keep(seed, flat, a.drop_thr) ? go * a.keep_scale : 0.f;
   if (a.act) {
     const float u = ga * xhat + be;
     const float sg = 1.f / (1.f + expf(-u));
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void gn_split_fwd_kernel(GnArgs a, const float
     for (int j = 0; j < 4; ++j) {
       const float u = ga * ((r[j] - mean) * rstd) + be;
       float t = a.act ? silu_f(u) : u;
-      if (a.drop_p > 0.f) t = (stk_uniform(seed, ((flat0 + (unsigned long long)(e * 4)) & ~3ULL) + j) >= a.drop_p) ? t * a.keep_scale : 0.f;
+      if (a.drop_p > 0.f) t = stk_drop_field(stk_mix64(seed, (flat0 + (unsigned long long)(e * 4)) >> 2), j) >= a.drop_thr ? t * a.keep_scale : 0.f;
       r[j] = t;
     }
     o4[e] = make_float4(r[0], r[1], r[2], r[3]);
@@ -701,16 +701,34 @@ __global__ __launch_bounds__(1024) void gn_fwd_pl_kernel(GnArgs a, float* __rest
 #pragma unroll
   for (int k = 0; k < PASSES; ++k) {
     const int px = (tid + T * k) >> 2;
+    // Dropout: the four lanes of a row that hold pixels 4 m .. 4 m + 3 of the same 8-channel piece (lanes 4 apart) need
+    // the same eight RNG quads (one per channel, stk_rng.h).  Lane r of the four computes the two mixes of channels 2 r,
+    // 2 r + 1 and the others fetch their 16-bit fields by lane shuffle: 2 mixes per thread and pass instead of 8.
+    unsigned keep = 0xffu;
+    if (a.drop_p > 0.f) {
+      const int r = (tid >> 2) & 3;                              // = px & 3: T / 4 is a multiple of 4
+      const unsigned long long fa = ((unsigned long long)n * C + (c0 + 8 * q + 2 * r)) * a.HW + px;
+      const unsigned long long za = stk_mix64(seed, fa >> 2), zb = stk_mix64(seed, (fa + a.HW) >> 2);
+      keep = 0u;
+#pragma unroll
+      for (int rot = 0; rot < 4; ++rot) {
+        // round `rot`: lane r reads from the lane that owns channel pair pr = (r + rot) & 3; seen from the sender, its
+        // reader is lane (r - rot) & 3, so it sends that lane's two 16-bit fields packed into one word
+        const unsigned rd = (unsigned)((r - rot) & 3);
+        const unsigned send = stk_drop_field(za, rd) | (stk_drop_field(zb, rd) << 16);
+        const int pr = (r + rot) & 3;
+        const unsigned got = rot == 0 ? send : (unsigned)__shfl((int)send, (lane & ~12) | (pr << 2), 64);
+        keep |= ((got & 0xffffu) >= a.drop_thr ? 1u : 0u) << (2 * pr);
+        keep |= ((got >> 16) >= a.drop_thr ? 1u : 0u) << (2 * pr + 1);
+      }
+    }
     float t[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float mean = j < 4 ? m_lo : m_hi, rstd = j < 4 ? r_lo : r_hi;
       const float u = ga[j] * ((v[k][j] - mean) * rstd) + be8[j];
       float r = a.act ? silu_f(u) : u;
-      if (a.drop_p > 0.f) {
-        const unsigned long long flat = ((unsigned long long)n * C + (c0 + 8 * q + j)) * a.HW + px;
-        r = (stk_uniform(seed, flat) >= a.drop_p) ? r * a.keep_scale : 0.f;
-      }
+      if (a.drop_p > 0.f) r = ((keep >> j) & 1u) ? r * a.keep_scale : 0.f;
       t[j] = r;
       if (yo) yo[(long)(8 * q + j) * a.HW + px] = r;
     }
@@ -759,7 +777,7 @@ int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float
     return STK_EINVAL;
   GnArgs a;
   a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
-  a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p);
+  a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p); a.drop_thr = stk_drop_threshold(drop_p);
   a.seed = seed; a.seed_dev = seed_dev;
   const bool vec = (HW & 3) == 0 && stk_aligned16(x1) && stk_aligned16(y) && (!x2 || stk_aligned16(x2));
   if (ws && vec && gn_split_ok(HW, a.cpg)) {
@@ -806,7 +824,7 @@ int stk_gn_fwd_pl_f32(const float* x1, int C1, const float* x2, int C2, const fl
   if (gn_pl_fused_ok(C1, C2, HW, G)) {
     GnArgs a;
     a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
-    a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p);
+    a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p); a.drop_thr = stk_drop_threshold(drop_p);
     a.seed = seed; a.seed_dev = seed_dev;
     const int items = HW * 4, T = items < 1024 ? items : 1024, passes = items / T;
     const float sq = sqrtf((float)((long)a.cpg * HW) - 1.f);
@@ -840,7 +858,7 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
     return STK_EINVAL;
   GnArgs a;
   a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
-  a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p);
+  a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p); a.drop_thr = stk_drop_threshold(drop_p);
   a.seed = seed; a.seed_dev = seed_dev;
   const long L = (long)a.cpg * HW;
   int hw_log2 = 0;
