@@ -89,6 +89,17 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
                    float* dgamma, float* dbeta, float* ws,
                    int N, int HW, int G, int act, float drop_p,
                    unsigned long long seed, const unsigned long long* seed_dev, void* stream);
+/* The affine-parameter gradients of MANY GroupNorm layers in one launch.  stk_gn_bwd_f32 with dgamma == dbeta == NULL
+ * leaves its per-(sample, channel) sums in ws[0 .. 2*N*C) ([n][c]{sum du, sum du*xhat}) and skips its own fold; this
+ * entry then does, for every descriptor, dgamma[c] += sum_n part[n][c][1], dbeta[c] += sum_n part[n][c][0] (same
+ * summation order as the per-layer fold, so results are bit-identical).  A training step has ~95 GroupNorm layers:
+ * one launch per backward segment instead of one 7 us launch per layer.  descs_dev: device array (host array for the
+ * checker); max_C >= every descriptor's C. */
+typedef struct StkGnFoldDesc {
+  const float* part; float* dgamma; float* dbeta; int N, C;
+} StkGnFoldDesc;
+int stk_gn_param_grad_batch(const StkGnFoldDesc* descs_dev, int count, int max_C, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on the matrix cores.  Input = concat(x1[N,C1,H,W], x2[N,C2,H,W]).

@@ -555,9 +555,16 @@ __global__ __launch_bounds__(256) void gn_split_bwd_kernel(GnArgs a, const float
 inline bool gn_split_ok(int HW, int cpg) { return (long)cpg * HW > 16384 && HW % GN_CHUNK == 0; }
 
 // dgamma[c] += sum_n ws[n,c,1];  dbeta[c] += sum_n ws[n,c,0].  32 channels per block, 8-way split over n.
+// With a descriptor table, blockIdx.y picks the layer (stk_gn_param_grad_batch).
 __global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int N, int C) {
+                                                            float* __restrict__ dbeta, int N, int C,
+                                                            const StkGnFoldDesc* __restrict__ descs) {
   __shared__ float redb[256], redg[256];
+  if (descs) {
+    const StkGnFoldDesc d = descs[blockIdx.y];
+    ws = d.part; dgamma = d.dgamma; dbeta = d.dbeta; N = d.N; C = d.C;
+    if ((int)blockIdx.x * 32 >= C) return;             // block-uniform: a layer narrower than the widest one
+  }
   const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float sb = 0.f, sg = 0.f;
@@ -897,9 +904,17 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
   STK_CHECK_LAUNCH();
   if (dgamma || dbeta) {
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3(stk_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, ws, dgamma,
-                       dbeta, N, C);
+                       dbeta, N, C, (const StkGnFoldDesc*)nullptr);
     STK_CHECK_LAUNCH();
   }
+  return STK_OK;
+}
+
+int stk_gn_param_grad_batch(const StkGnFoldDesc* descs_dev, int count, int max_C, void* stream) {
+  if (!descs_dev || count <= 0 || max_C <= 0) return STK_EINVAL;
+  hipLaunchKernelGGL(gn_param_grad_kernel, dim3(stk_cdiv(max_C, 32), (unsigned)count), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0, 0, descs_dev);
+  STK_CHECK_LAUNCH();
   return STK_OK;
 }
 

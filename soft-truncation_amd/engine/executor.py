@@ -48,6 +48,11 @@ class _WprepDesc(ctypes.Structure):        # StkWprepDesc of include/stk.h
               ('flip', ctypes.c_int), ('reserved', ctypes.c_int)]
 
 
+class _GnFoldDesc(ctypes.Structure):       # StkGnFoldDesc of include/stk.h
+  _fields_ = [('part', ctypes.c_void_p), ('dgamma', ctypes.c_void_p), ('dbeta', ctypes.c_void_p),
+              ('N', ctypes.c_int), ('C', ctypes.c_int)]
+
+
 class Context:
   """Buffers of one forward call, kept until its backward has run."""
   __slots__ = ('prog', 'act', 'gact', 'rt', 'released', 'seed_t', 'graphs', 'uses', 'pl')
@@ -90,6 +95,29 @@ class Program:
     self.wp_items = 0
     self.wp_frozen = 0           # entries valid under Executor.frozen_weights()
     self._segments = {}          # bucket_elems -> backward segments for the overlapped gradient exchange
+    # deferred GroupNorm parameter-gradient folds (include/stk.h stk_gn_param_grad_batch): partial-sum arena + table
+    self.gnpart = None
+    self.gn_table = None
+    self.gn_maxc = 0
+
+  def build_gn_folds(self, gparam_base):
+    g = self.graph
+    if not getattr(g, 'gn_folds', None):
+      return
+    self.gnpart = _arena(g.gnpart_size, self.device)
+    base = self.gnpart.data_ptr()
+    descs = []
+    for op in g.gn_folds:
+      d = _GnFoldDesc()
+      d.part = base + 4 * op.fold_off
+      d.dgamma = gparam_base + 4 * op.gamma.goff if op.gamma.needs_grad else None
+      d.dbeta = gparam_base + 4 * op.beta_t.goff if op.beta_t.needs_grad else None
+      d.N, d.C = op.N, op.C1 + op.C2
+      self.gn_maxc = max(self.gn_maxc, d.C)
+      descs.append(d)
+    assert ctypes.sizeof(_GnFoldDesc) == 32
+    raw = b''.join(bytes(d) for d in descs)
+    self.gn_table = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(self.device)
 
   def backward_segments(self, n_train, bucket_elems):
     """Cut the backward launch sequence where buckets of the flat gradient buffer become final.
@@ -301,6 +329,10 @@ class Executor:
     if c.pl is not None:
       rt.pl = c.pl.data_ptr()
       rt.dypl = rt.pl + prog.graph.pl_bytes
+    if with_backward and getattr(prog.graph, 'gn_folds', None):
+      if prog.gn_table is None:
+        prog.build_gn_folds(flat.grad.data_ptr())
+      rt.gnpart, rt.gn_table, rt.gn_maxc = prog.gnpart.data_ptr(), prog.gn_table.data_ptr(), prog.gn_maxc
     return rt
 
   def _replay(self, c, direction, training, span=None, with_backward=True):
@@ -323,9 +355,11 @@ class Executor:
           elif span is None:
             for op in reversed(ops):
               op.backward(rt)
+            rt.flush_folds()
           else:
             for op in list(reversed(ops))[span[0]:span[1]]:
               op.backward(rt)
+            rt.flush_folds()
       except Exception as e:   # capture is an optimisation: report, disable, run eagerly
         warnings.warn(f'hipGraph capture failed ({e!r}); continuing with eager launches')
         self.use_graphs = False
@@ -400,6 +434,7 @@ class Executor:
               rt.stream = stk_lib.stream_ptr(flat.device)
             for op in order[begin:end]:
               op.backward(rt)
+            rt.flush_folds()
         begin = end
         for lo, hi in ranges:
           hook(lo, hi)
@@ -413,6 +448,7 @@ class Executor:
       rt.prof = self.profiler
       for op in reversed(g.ops):
         op.backward(rt)
+      rt.flush_folds()
     gx = None
     xin = g.inputs['x']
     if xin.needs_grad:

@@ -77,6 +77,28 @@ class Runtime:
     self.pl = 0           # base address of the context's planes arena (pre-split conv operands)
     self.dypl = 0         # ... and of its scratch for the planes of the gradient a data-gradient call consumes
     self.prof = None      # optional engine.profile.KernelTimer: HIP events around the contraction launches
+    # deferred GroupNorm parameter-gradient folds (stk_gn_param_grad_batch): base of the program's partial-sum arena,
+    # device address of its descriptor table (entries in backward order), and the pending range of entries
+    self.gnpart = 0
+    self.gn_table = 0
+    self.gn_maxc = 0
+    self._fold_lo = None
+    self._fold_hi = None
+
+  def defer_fold(self, index):
+    """A GroupNorm backward left its per-(sample, channel) sums behind; entry `index` of the table folds them."""
+    if self._fold_lo is None:
+      self._fold_lo = index
+    assert self._fold_hi is None or index == self._fold_hi, 'GroupNorm folds must be deferred in table order'
+    self._fold_hi = index + 1
+
+  def flush_folds(self):
+    """One launch for every fold deferred since the last flush (end of a backward segment / of the backward)."""
+    if self._fold_lo is None:
+      return
+    lo, hi = self._fold_lo, self._fold_hi
+    self._fold_lo = self._fold_hi = None
+    self.lib.gn_param_grad_batch(self.gn_table + 32 * lo, hi - lo, self.gn_maxc, self.stream)
 
   def timed(self, kind, flops, fn, *args):
     """Launch `fn(*args)`; with a profiler attached, bracket it with HIP events on the launch stream."""
@@ -156,6 +178,8 @@ class GroupNormAct(Op):
     self.inputs = (x1, x2)
     self.op_id = g.next_id()
     self.fused = False        # the library's one-pass GroupNorm -> planes kernel takes this shape (Graph.finalize)
+    self.fold_off = None      # float offset of this layer's [N][C][2] partial sums in the program's arena (Graph.finalize)
+    self.fold_index = None    # its entry in the fold table (backward order)
 
   def _p(self, rt):
     return self.drop_p if rt.training else 0.0
@@ -177,10 +201,16 @@ class GroupNormAct(Op):
                       self.act, self._p(rt), seed, rt.seed_dev, rt.ws, rt.stream)
 
   def backward(self, rt):
+    dgamma, dbeta, ws = rt.g(self.gamma), rt.g(self.beta_t), rt.ws
+    if rt.gn_table and self.fold_index is not None and (dgamma is not None or dbeta is not None):
+      # leave the per-(sample, channel) sums in this layer's own slot; one launch folds a whole segment's layers
+      dgamma = dbeta = None
+      ws = rt.gnpart + 4 * self.fold_off
+      rt.defer_fold(self.fold_index)
     rt.lib.gn_bwd_f32(rt.g(self.y), rt.v(self.x1), self.C1, rt.v(self.x2), self.C2,
                       rt.v(self.gamma), rt.v(self.beta_t), rt.v(self.mean), rt.v(self.rstd),
                       rt.g(self.x1), self.b(self.x1), rt.g(self.x2), self.b(self.x2) if self.x2 is not None else 0.0,
-                      rt.g(self.gamma), rt.g(self.beta_t), rt.ws,
+                      dgamma, dbeta, ws,
                       self.N, self.HW, self.G, self.act, self._p(rt),
                       (rt.seed + 0x9E3779B1 * self.op_id) & 0xFFFFFFFFFFFFFFFF, rt.seed_dev, rt.stream)
 
@@ -791,6 +821,18 @@ class Graph:
       op.plan_backward()
     self.ws_bytes = max([256] + [op.ws_bytes(lib) for op in self.ops])
     self.ws_bytes = _round_up(self.ws_bytes, 256)
+    # deferred GroupNorm parameter-gradient folds: a slot of partial sums per layer, table entries in backward order
+    # (STK_GN_FOLD_BATCH=0: every layer folds its own sums -- a debugging switch, results are bit-identical)
+    self.gnpart_size = 0
+    self.gn_folds = []
+    if os.environ.get('STK_GN_FOLD_BATCH', '1') != '0' and hasattr(lib, 'gn_param_grad_batch'):
+      for op in reversed(self.ops):
+        if isinstance(op, GroupNormAct) and (op.gamma.needs_grad or op.beta_t.needs_grad):
+          op.fold_off = self.gnpart_size
+          op.fold_index = len(self.gn_folds)
+          self.gnpart_size += _round_up(max(int(lib.gn_ws_bytes(op.N, op.C1 + op.C2, op.HW, op.G)) // 4,
+                                            2 * op.N * (op.C1 + op.C2)))
+          self.gn_folds.append(op)
     # prepared-weight arena: one block per conv layer and direction that runs on the split kernel
     self.wp_bytes = 0
     for op in self.ops:

@@ -32,6 +32,7 @@ SIGNATURES = {
   'stk_gn_fwd_f32': [P, I, P, I, P, P, P, P, P, I, I, I, F, I, F, U64, P, P, S],
   'stk_gn_ws_bytes': [I, I, I, I],
   'stk_gn_bwd_f32': [P, P, I, P, I, P, P, P, P, P, F, P, F, P, P, P, I, I, I, I, F, U64, P, S],
+  'stk_gn_param_grad_batch': [P, I, I, S],
   'stk_conv2d_variant': [I, I, I, I, I, I, I, I, I, I, I, I, I, I],
   'stk_conv2d_fwd_ws_bytes': [I, I, I, I, I, I, I, I, I, I],
   'stk_conv2d_dgrad_ws_bytes': [I, I, I, I, I, I, I, I, I, I],
