@@ -329,9 +329,7 @@ class Executor:
     if c.pl is not None:
       rt.pl = c.pl.data_ptr()
       rt.dypl = rt.pl + prog.graph.pl_bytes
-    if with_backward and getattr(prog.graph, 'gn_folds', None):
-      if prog.gn_table is None:
-        prog.build_gn_folds(flat.grad.data_ptr())
+    if with_backward and prog.gn_table is not None:
       rt.gnpart, rt.gn_table, rt.gn_maxc = prog.gnpart.data_ptr(), prog.gn_table.data_ptr(), prog.gn_maxc
     return rt
 
@@ -380,6 +378,8 @@ class Executor:
     if sigma is not None:
       self._copy_in(c, 'sigma', sigma)
     self._prepare_weights(prog, with_backward)
+    if with_backward and prog.gn_table is None and getattr(g, 'gn_folds', None):
+      prog.build_gn_folds(flat.grad.data_ptr())          # allocation + upload: never inside a hipGraph capture
     seed = 0
     if training and self.model._uses_dropout():
       seed = int(torch.randint(0, 2 ** 62, (1,)).item())
