@@ -270,15 +270,18 @@ int stk_softmax_bwd_f32(const float* y, const float* dy, float* dx, long rows, i
  *         by the forward and of d_o written by the backward; the backward reads the forward's three
  *   delta [B, T]   scratch of the backward: sum_t' p[t, t'] dp[t, t']
  *   dq / dk / dv = beta * dq / dk / dv + gradient  (beta == 0: not read)
+ *   qkv_bstride / grad_bstride: floats between consecutive images of q, k, v / of dq, dk, dv (C*T for separate
+ *         tensors; 3*C*T when the three are the channel slices of one [B, 3C, T] tensor, as the engine's stacked
+ *         q / k / v projection produces them); o and d_o are contiguous [B, C, T]
  * stk_attention_ok: 1 if the fused kernels take the shape (C % 32 == 0, 32 <= C <= 256, T % 4 == 0, T <= 256); other
  * shapes return STK_EUNSUPPORTED and go through stk_gemm_f32 / stk_softmax_*.
  * ------------------------------------------------------------------------------------------ */
 int stk_attention_ok(int B, int C, int T);
-int stk_attention_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, float* rec,
+int stk_attention_fwd_f32(const float* q, const float* k, const float* v, long qkv_bstride, float* o, float* lse, float* rec,
                           int B, int C, int T, float scale, void* stream);
-int stk_attention_bwd_f32(const float* q, const float* k, const float* v, const float* d_o, const float* lse, float* rec,
-                          float* delta, float* dq, float beta_q, float* dk, float beta_k, float* dv, float beta_v,
-                          int B, int C, int T, float scale, void* stream);
+int stk_attention_bwd_f32(const float* q, const float* k, const float* v, long qkv_bstride, const float* d_o, const float* lse,
+                          float* rec, float* delta, float* dq, float beta_q, float* dk, float beta_k, float* dv, float beta_v,
+                          long grad_bstride, int B, int C, int T, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Element-wise and small helpers.

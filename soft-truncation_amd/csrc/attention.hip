@@ -55,22 +55,22 @@ constexpr int NPART = 256;          // partial |x| maxima per tensor (a "scale r
 constexpr int MODE_FWD = 0, MODE_DQ = 1, MODE_DKV = 2;
 
 // ---- |x| maxima of up to four tensors of n floats each in one launch: blockIdx.y picks the tensor ----------------------
-struct AmaxArgs { const float* x[4]; float* rec[4]; long n; };
-__global__ __launch_bounds__(1024) void attn_amax_kernel(AmaxArgs a) {
+struct AmaxArgs { const float* x[4]; float* rec[4]; long bs4[4]; long ct4; long n4; };    // tensor t: B segments of ct4 float4
+__global__ __launch_bounds__(1024) void attn_amax_kernel(AmaxArgs a) {                     // bs4[t] float4 apart
   __shared__ float red[16];
-  const float* x = a.x[blockIdx.y];
-  const float4* x4 = reinterpret_cast<const float4*>(x);
-  const long n4 = a.n >> 2;                                   // n % 4 == 0, 16-byte aligned (checked by the host)
+  const float4* x4 = reinterpret_cast<const float4*>(a.x[blockIdx.y]);
+  const long bs4 = a.bs4[blockIdx.y], ct4 = a.ct4;
   float m0 = 0.f, m1 = 0.f;
   const long stride = (long)NPART * 1024;
+  auto at = [&](long i) { const long b = i / ct4; return x4[b * bs4 + (i - b * ct4)]; };
   long i = (long)blockIdx.x * 1024 + threadIdx.x;
-  for (; i + stride < n4; i += 2 * stride) {
-    const float4 u = x4[i], v = x4[i + stride];
+  for (; i + stride < a.n4; i += 2 * stride) {
+    const float4 u = at(i), v = at(i + stride);
     m0 = fmaxf(fmaxf(m0, fmaxf(fabsf(u.x), fabsf(u.y))), fmaxf(fabsf(u.z), fabsf(u.w)));
     m1 = fmaxf(fmaxf(m1, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
-  if (i < n4) {
-    const float4 u = x4[i];
+  if (i < a.n4) {
+    const float4 u = at(i);
     m0 = fmaxf(fmaxf(m0, fmaxf(fabsf(u.x), fabsf(u.y))), fmaxf(fabsf(u.z), fabsf(u.w)));
   }
   float m = wave_max(fmaxf(m0, m1));
@@ -117,6 +117,7 @@ struct Args {
   const float* a[2];      // phase B operands [B, C, T] (rows c, contraction along T)
   const float* rx[2]; const float* ry[2]; const float* ra[2];    // their scale records
   float* out[2]; float beta[2];                                  // phase B results [B, C, T]
+  long xs[2], ys[2], as[2], os[2];                               // floats between consecutive images of each operand
   float* lse;             // [B, T]  FWD: written; DQ / DKV: read
   float* delta;           // [B, T]  DQ: written; DKV: read
   int B, C, T; float scale;
@@ -214,11 +215,11 @@ __global__ __launch_bounds__(TK * 2, TK / 128) void attn_kernel(Args a) {   // N
 
   stamp();
   // ---- phase A: D_g[m, n] = sum_c X_g[c, m] Y_g[c, n];  wave w owns rows m = 32 w .. 32 w + 31 -------------------------
-  const long tensor_bytes = (long)a.B * C * T * 4;
+  auto bytes_of = [&](long bstride) { return ((long)(a.B - 1) * bstride + (long)C * T) * 4; };
   const int l8 = lane >> 3, l7 = lane & 7;
   __amdgpu_buffer_rsrc_t xrs[NG], yrs[NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) { xrs[g] = make_rsrc(a.x[g], tensor_bytes); yrs[g] = make_rsrc(a.y[g], tensor_bytes); }
+  for (int g = 0; g < NG; ++g) { xrs[g] = make_rsrc(a.x[g], bytes_of(a.xs[g])); yrs[g] = make_rsrc(a.y[g], bytes_of(a.ys[g])); }
   // A 16-byte load covers 4 positions of one channel; a wave instruction 8 channels x 32 positions (one 32-block).
   // X tiles: wave w stages 32-block w (the rows it multiplies), channel groups j = 0 .. CK / 8 - 1.
   // Y tiles (2 blocks x CK / 8 groups x NG operands = NW YT instructions): flat index f = wid + NW j.
@@ -244,16 +245,20 @@ __global__ __launch_bounds__(TK * 2, TK / 128) void attn_kernel(Args a) {   // N
   u32x4 ra[2][NPA];
   auto fetch = [&](auto SET, int chunk) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    const unsigned soff = (unsigned)((b * C + chunk * CK) * T) * 4u;
+    const unsigned coff = (unsigned)(chunk * CK * T) * 4u;
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int j = 0; j < G::XI; ++j)
-        ra[S][g * G::XI + j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs[g], (int)xvo[j], (int)soff, 0));
+        ra[S][g * G::XI + j] = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs[g], (int)xvo[j], (int)((unsigned)(b * a.xs[g]) * 4u + coff), 0));
 #pragma unroll
-    for (int j = 0; j < G::YT; ++j)
+    for (int j = 0; j < G::YT; ++j) {
+      const bool second = NG == 2 && yg[j];
       ra[S][NG * G::XI + j] = __builtin_bit_cast(
-          u32x4, __builtin_amdgcn_raw_buffer_load_b128(NG == 2 && yg[j] ? yrs[NG - 1] : yrs[0], (int)yvo[j], (int)soff, 0));
+          u32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? yrs[NG - 1] : yrs[0], (int)yvo[j],
+                                                       (int)((unsigned)(b * (second ? a.ys[NG - 1] : a.ys[0])) * 4u + coff), 0));
+    }
   };
   // A piece goes to LDS in two halves (so that they can be placed between MFMAs): scale + hi terms, then lo terms + stores
   // (instruction selection is pinned by inline asm: left to itself the compiler packs the multiplies into v_pk_mul_f32
@@ -384,7 +389,8 @@ __global__ __launch_bounds__(TK * 2, TK / 128) void attn_kernel(Args a) {   // N
   stamp();
   // ---- phase B plumbing: out[c, n] = sum_k A[c, k] bm[n, k];  wave w owns channel blocks CBW w .. CBW w + CBW - 1 ------
   constexpr int CBW = G::CBW, AI = G::AI;
-  __amdgpu_buffer_rsrc_t ars = make_rsrc(a.a[0], tensor_bytes);
+  __amdgpu_buffer_rsrc_t ars = make_rsrc(a.a[0], bytes_of(a.as[0]));
+  long a_bs = a.as[0];
   const int KB = FULL ? TK / 32 : (T + 31) >> 5;              // 32-position blocks of the contraction
   unsigned avo[AI], adst[AI];
 #pragma unroll
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(TK * 2, TK / 128) void attn_kernel(Args a) {   // N
   u32x4 rb[2][AI];
   auto fetch_a = [&](auto SET, int kb) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    const unsigned soff = (unsigned)(b * C * T + kb * 32) * 4u;
+    const unsigned soff = (unsigned)(b * a_bs + kb * 32) * 4u;
     const unsigned dead = (FULL || kb * 32 + 4 * l7 < T) ? 0u : 0x80000000u;
 #pragma unroll
     for (int j = 0; j < AI; ++j)
@@ -460,7 +466,8 @@ __global__ __launch_bounds__(TK * 2, TK / 128) void attn_kernel(Args a) {   // N
   };
   // one GEMM of phase B: out[c, n] = beta out + post[n] / (sa sb) sum_m A[c, m] bm[n, m]
   auto phase_b = [&](int which, float s_a, float s_b, const float (&post)[2]) __attribute__((always_inline)) {
-    ars = make_rsrc(a.a[which], tensor_bytes);
+    ars = make_rsrc(a.a[which], bytes_of(a.as[which]));
+    a_bs = a.as[which];
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
@@ -492,10 +499,10 @@ __global__ __launch_bounds__(TK * 2, TK / 128) void attn_kernel(Args a) {   // N
     }
     stamp();
     // rows of channels >= C were computed from zeros and are not stored
-    __amdgpu_buffer_rsrc_t ors = make_rsrc(a.out[which], tensor_bytes);
+    __amdgpu_buffer_rsrc_t ors = make_rsrc(a.out[which], bytes_of(a.os[which]));
     const float beta = a.beta[which];
     const float inv = 1.f / (s_a * s_b);
-    const unsigned obase = (unsigned)(b * C * T) * 4u;
+    const unsigned obase = (unsigned)(b * a.os[which]) * 4u;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const int n = n0 + nb * 32 + fc;
@@ -638,6 +645,9 @@ __global__ __launch_bounds__(TK * 2, TK / 128) void attn_kernel(Args a) {   // N
 inline bool attn_ok(int B, int C, int T) {
   return B > 0 && C >= 32 && C <= 256 && C % 32 == 0 && T >= 4 && T <= 256 && T % 4 == 0 && (long)B * C * T * 4 < 0x7fffffffL;
 }
+inline bool stride_ok(int B, int C, int T, long bs) {
+  return bs >= (long)C * T && bs % 4 == 0 && ((long)(B - 1) * bs + (long)C * T) * 4 < 0x7fffffffL;
+}
 
 template <int MODE>
 int launch(const Args& a, hipStream_t s) {
@@ -649,26 +659,35 @@ int launch(const Args& a, hipStream_t s) {
   return STK_OK;
 }
 
+void fwd_args(Args& a, const float* q, const float* k, const float* v, long bs, float* o, float* lse, float* rec, int B, int C,
+              int T, float scale) {
+  const long ct = (long)C * T;
+  a.x[0] = k; a.rx[0] = rec + NPART; a.y[0] = q; a.ry[0] = rec; a.a[0] = v; a.ra[0] = rec + 2 * NPART;
+  a.x[1] = k; a.rx[1] = rec + NPART; a.y[1] = q; a.ry[1] = rec; a.a[1] = v; a.ra[1] = rec + 2 * NPART;
+  a.xs[0] = a.xs[1] = a.ys[0] = a.ys[1] = a.as[0] = a.as[1] = bs;
+  a.out[0] = o; a.out[1] = o; a.os[0] = a.os[1] = ct; a.beta[0] = a.beta[1] = 0.f; a.lse = lse; a.delta = nullptr;
+  a.B = B; a.C = C; a.T = T; a.scale = scale;
+}
+
 }  // namespace
 
 extern "C" {
 
 int stk_attention_ok(int B, int C, int T) { return attn_ok(B, C, T) ? 1 : 0; }
 
-int stk_attention_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, float* rec, int B, int C,
-                          int T, float scale, void* stream) {
+int stk_attention_fwd_f32(const float* q, const float* k, const float* v, long qkv_bstride, float* o, float* lse, float* rec,
+                          int B, int C, int T, float scale, void* stream) {
   if (!q || !k || !v || !o || !lse || !rec || B <= 0 || C <= 0 || T <= 0) return STK_EINVAL;
-  if (!attn_ok(B, C, T) || !stk_aligned16(q) || !stk_aligned16(k) || !stk_aligned16(v)) return STK_EUNSUPPORTED;
+  if (!attn_ok(B, C, T) || !stride_ok(B, C, T, qkv_bstride) || !stk_aligned16(q) || !stk_aligned16(k) || !stk_aligned16(v))
+    return STK_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   AmaxArgs m = {};
-  m.x[0] = q; m.x[1] = k; m.x[2] = v; m.rec[0] = rec; m.rec[1] = rec + NPART; m.rec[2] = rec + 2 * NPART; m.n = (long)B * C * T;
+  m.x[0] = q; m.x[1] = k; m.x[2] = v; m.rec[0] = rec; m.rec[1] = rec + NPART; m.rec[2] = rec + 2 * NPART;
+  m.bs4[0] = m.bs4[1] = m.bs4[2] = qkv_bstride / 4; m.ct4 = (long)C * T / 4; m.n4 = (long)B * m.ct4;
   hipLaunchKernelGGL(attn_amax_kernel, dim3(NPART, 3), dim3(1024), 0, s, m);
   STK_CHECK_LAUNCH();
   Args a = {};
-  a.x[0] = k; a.rx[0] = rec + NPART; a.y[0] = q; a.ry[0] = rec; a.a[0] = v; a.ra[0] = rec + 2 * NPART;
-  a.x[1] = k; a.rx[1] = rec + NPART; a.y[1] = q; a.ry[1] = rec; a.a[1] = v; a.ra[1] = rec + 2 * NPART;
-  a.out[0] = o; a.out[1] = o; a.beta[0] = a.beta[1] = 0.f; a.lse = lse; a.delta = nullptr;
-  a.B = B; a.C = C; a.T = T; a.scale = scale;
+  fwd_args(a, q, k, v, qkv_bstride, o, lse, rec, B, C, T, scale);
   return launch<MODE_FWD>(a, s);
 }
 
@@ -676,34 +695,40 @@ int stk_attention_fwd_f32(const float* q, const float* k, const float* v, float*
 int stk_attention_fwd_debug(const float* q, const float* k, const float* v, float* o, float* lse, float* rec, int B, int C,
                             int T, float scale, long long* dbg, void* stream) {
   Args a = {};
-  a.x[0] = k; a.rx[0] = rec + NPART; a.y[0] = q; a.ry[0] = rec; a.a[0] = v; a.ra[0] = rec + 2 * NPART;
-  a.x[1] = k; a.rx[1] = rec + NPART; a.y[1] = q; a.ry[1] = rec; a.a[1] = v; a.ra[1] = rec + 2 * NPART;
-  a.out[0] = o; a.out[1] = o; a.lse = lse; a.B = B; a.C = C; a.T = T; a.scale = scale; a.dbg = dbg;
+  fwd_args(a, q, k, v, (long)C * T, o, lse, rec, B, C, T, scale);
+  a.dbg = dbg;
   return launch<MODE_FWD>(a, (hipStream_t)stream);
 }
 
-int stk_attention_bwd_f32(const float* q, const float* k, const float* v, const float* d_o, const float* lse, float* rec,
-                          float* delta, float* dq, float beta_q, float* dk, float beta_k, float* dv, float beta_v, int B,
-                          int C, int T, float scale, void* stream) {
+int stk_attention_bwd_f32(const float* q, const float* k, const float* v, long qkv_bstride, const float* d_o, const float* lse,
+                          float* rec, float* delta, float* dq, float beta_q, float* dk, float beta_k, float* dv, float beta_v,
+                          long grad_bstride, int B, int C, int T, float scale, void* stream) {
   if (!q || !k || !v || !d_o || !lse || !rec || !delta || !dq || !dk || !dv || B <= 0 || C <= 0 || T <= 0) return STK_EINVAL;
-  if (!attn_ok(B, C, T) || !stk_aligned16(q) || !stk_aligned16(k) || !stk_aligned16(v) || !stk_aligned16(d_o))
+  if (!attn_ok(B, C, T) || !stride_ok(B, C, T, qkv_bstride) || !stride_ok(B, C, T, grad_bstride) || !stk_aligned16(q) ||
+      !stk_aligned16(k) || !stk_aligned16(v) || !stk_aligned16(d_o))
     return STK_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  const long ct = (long)C * T;
   float* rq = rec; float* rk = rec + NPART; float* rv = rec + 2 * NPART; float* rdo = rec + 3 * NPART;
   AmaxArgs m = {};
-  m.x[0] = d_o; m.rec[0] = rdo; m.n = (long)B * C * T;
+  m.x[0] = d_o; m.rec[0] = rdo; m.bs4[0] = ct / 4; m.ct4 = ct / 4; m.n4 = (long)B * m.ct4;
   hipLaunchKernelGGL(attn_amax_kernel, dim3(NPART, 1), dim3(1024), 0, s, m);
   STK_CHECK_LAUNCH();
   Args a = {};
   a.B = B; a.C = C; a.T = T; a.scale = scale; a.lse = const_cast<float*>(lse); a.delta = delta;
+  const long bs = qkv_bstride, gs = grad_bstride;
   // DQ: rows m = keys: X = (k, v); columns n = queries: Y = (q, do); phase B: dq = k ds
-  a.x[0] = k; a.rx[0] = rk; a.x[1] = v; a.rx[1] = rv; a.y[0] = q; a.ry[0] = rq; a.y[1] = d_o; a.ry[1] = rdo;
-  a.a[0] = k; a.ra[0] = rk; a.a[1] = k; a.ra[1] = rk; a.out[0] = dq; a.out[1] = dq; a.beta[0] = a.beta[1] = beta_q;
+  a.x[0] = k; a.rx[0] = rk; a.xs[0] = bs; a.x[1] = v; a.rx[1] = rv; a.xs[1] = bs;
+  a.y[0] = q; a.ry[0] = rq; a.ys[0] = bs; a.y[1] = d_o; a.ry[1] = rdo; a.ys[1] = ct;
+  a.a[0] = k; a.ra[0] = rk; a.as[0] = bs; a.a[1] = k; a.ra[1] = rk; a.as[1] = bs;
+  a.out[0] = dq; a.out[1] = dq; a.os[0] = a.os[1] = gs; a.beta[0] = a.beta[1] = beta_q;
   int rc = launch<MODE_DQ>(a, s);
   if (rc) return rc;
   // DKV: rows m = queries: X = (q, do); columns n = keys: Y = (k, v); phase B: dv = do p, dk = q ds
-  a.x[0] = q; a.rx[0] = rq; a.x[1] = d_o; a.rx[1] = rdo; a.y[0] = k; a.ry[0] = rk; a.y[1] = v; a.ry[1] = rv;
-  a.a[0] = d_o; a.ra[0] = rdo; a.a[1] = q; a.ra[1] = rq; a.out[0] = dv; a.out[1] = dk; a.beta[0] = beta_v; a.beta[1] = beta_k;
+  a.x[0] = q; a.rx[0] = rq; a.xs[0] = bs; a.x[1] = d_o; a.rx[1] = rdo; a.xs[1] = ct;
+  a.y[0] = k; a.ry[0] = rk; a.ys[0] = bs; a.y[1] = v; a.ry[1] = rv; a.ys[1] = bs;
+  a.a[0] = d_o; a.ra[0] = rdo; a.as[0] = ct; a.a[1] = q; a.ra[1] = rq; a.as[1] = bs;
+  a.out[0] = dv; a.out[1] = dk; a.os[0] = a.os[1] = gs; a.beta[0] = beta_v; a.beta[1] = beta_k;
   return launch<MODE_DKV>(a, s);
 }
 

@@ -606,15 +606,26 @@ class AddDiv(Op):
 
 class AttentionCore(Op):
   """o = softmax(q^T k / sqrt(C)) applied to v -- the two einsums and the softmax of AttnBlockpp
-  (models/layerspp.py:95-99), q/k/v/o all [B,C,H,W], single head of dimension C.
+  (models/layerspp.py:95-99), single head of dimension C.  q, k, v are either three [B,C,H,W] tensors or, with
+  `qkv`, the channel slices [0,C), [C,2C), [2C,3C) of ONE [B,3C,H,W] tensor (the stacked projection of
+  AttnBlockpp.emit), read and differentiated in place through a batch stride of 3 C T.
 
   Shapes the library's fused kernels take (stk_attention_ok: every shipped config) run as one launch per direction pair
   with no [B,T,T] matrix in memory; the rest as batched GEMMs around stk_softmax_*.  STK_ATTN_FUSED=0 forces the latter."""
 
-  def __init__(self, g, q, k, v, name='attn'):
-    self.q, self.k, self.vv = q, k, v
-    B, C, H, W = q.shape
+  def __init__(self, g, q, k, v, name='attn', qkv=None):
+    self.qkv = qkv
+    if qkv is not None:
+      B, C3, H, W = qkv.shape
+      C = C3 // 3
+      self.q = self.k = self.vv = None
+      self.inputs = (qkv,)
+    else:
+      self.q, self.k, self.vv = q, k, v
+      B, C, H, W = q.shape
+      self.inputs = (q, k, v)
     self.B, self.C, self.T = B, C, H * W
+    self.bs = (3 if qkv is not None else 1) * C * self.T       # floats between consecutive images of q / k / v
     self.scale = float(int(C) ** (-0.5))
     lib = g.lib
     self.fused = bool(lib is not None and os.environ.get('STK_ATTN_FUSED', '1') != '0' and hasattr(lib, 'attention_ok') and
@@ -626,65 +637,75 @@ class AttentionCore(Op):
     else:
       self.s = g.new((B, self.T, self.T), needs_grad=False, name=name + '.s')
       self.p = g.new((B, self.T, self.T), needs_grad=False, name=name + '.p')
-    self.o = g.new(q.shape, name=name + '.o')
+    self.o = g.new((B, C, H, W), name=name + '.o')
     self.y = self.o
-    self.inputs = (q, k, v)
     # algorithmic FLOPs: forward 2 GEMMs, backward 4 (+ 3 recomputed by the fused kernels, not counted)
     self.flops = 2.0 * 2.0 * B * self.T * self.T * C
 
+  def _qkv(self, rt):
+    """addresses of q, k, v and of their gradients (None = not wanted) + the gradients' beta"""
+    n4 = 4 * self.C * self.T
+    if self.qkv is not None:
+      base, gbase = rt.v(self.qkv), rt.g(self.qkv)
+      grads = (None, None, None) if gbase is None else (gbase, gbase + n4, gbase + 2 * n4)
+      beta = self.b(self.qkv)
+      return (base, base + n4, base + 2 * n4), grads, (beta, beta, beta)
+    return ((rt.v(self.q), rt.v(self.k), rt.v(self.vv)), (rt.g(self.q), rt.g(self.k), rt.g(self.vv)),
+            (self.b(self.q), self.b(self.k), self.b(self.vv)))
+
   def forward(self, rt):
-    B, C, T = self.B, self.C, self.T
+    B, C, T, bs = self.B, self.C, self.T, self.bs
     lib = rt.lib
+    (q, k, v), _, _ = self._qkv(rt)
     if self.fused:
-      rt.timed('attention.fwd.x2', self.flops, lib.attention_fwd_f32, rt.v(self.q), rt.v(self.k), rt.v(self.vv), rt.v(self.o),
+      rt.timed('attention.fwd.x2', self.flops, lib.attention_fwd_f32, q, k, v, bs, rt.v(self.o),
                rt.v(self.lse), rt.v(self.rec), B, C, T, self.scale, rt.stream)
       return
     # S[b][t][t'] = sum_c Q[b][c][t] K[b][c][t']
-    lib.gemm_f32(rt.v(self.q), 1, T, C * T, rt.v(self.k), T, 1, C * T, rt.v(self.s), T, 1, T * T,
+    lib.gemm_f32(q, 1, T, bs, k, T, 1, bs, rt.v(self.s), T, 1, T * T,
                  None, 0, T, T, C, B, 1.0, 0.0, rt.stream)
     lib.softmax_fwd_f32(rt.v(self.s), rt.v(self.p), B * T, T, self.scale, rt.stream)
     # O[b][c][t] = sum_t' V[b][c][t'] P[b][t][t']
-    lib.gemm_f32(rt.v(self.vv), T, 1, C * T, rt.v(self.p), 1, T, T * T, rt.v(self.o), T, 1, C * T,
+    lib.gemm_f32(v, T, 1, bs, rt.v(self.p), 1, T, T * T, rt.v(self.o), T, 1, C * T,
                  None, 0, C, T, T, B, 1.0, 0.0, rt.stream)
 
   def backward(self, rt):
-    B, C, T = self.B, self.C, self.T
+    B, C, T, bs = self.B, self.C, self.T, self.bs
     lib = rt.lib
     go = rt.g(self.o)
-    if self.fused:
-      gq, gk, gv = rt.g(self.q), rt.g(self.k), rt.g(self.vv)
-      if gq is None and gk is None and gv is None:
-        return
-      # the kernels write all three gradients; one that nobody asked for goes to the workspace
-      n4 = 4 * self.q.numel
-      spare = [rt.ws + i * n4 for i in range(3)]
-      rt.timed('attention.bwd.x2', 2.0 * self.flops, lib.attention_bwd_f32, rt.v(self.q), rt.v(self.k), rt.v(self.vv), go,
-               rt.v(self.lse), rt.v(self.rec), rt.v(self.delta),
-               gq if gq is not None else spare[0], self.b(self.q) if gq is not None else 0.0,
-               gk if gk is not None else spare[1], self.b(self.k) if gk is not None else 0.0,
-               gv if gv is not None else spare[2], self.b(self.vv) if gv is not None else 0.0,
-               B, C, T, self.scale, rt.stream)
+    (q, k, v), (gq, gk, gv), (bq, bk, bv) = self._qkv(rt)
+    if gq is None and gk is None and gv is None:
       return
+    if self.fused:
+      # the kernels write all three gradients; one that nobody asked for goes to the workspace (separate tensors only)
+      n4 = 4 * B * C * T
+      gs = bs if self.qkv is not None else C * T
+      spare = [rt.ws + i * n4 for i in range(3)]
+      rt.timed('attention.bwd.x2', 2.0 * self.flops, lib.attention_bwd_f32, q, k, v, bs, go,
+               rt.v(self.lse), rt.v(self.rec), rt.v(self.delta),
+               gq if gq is not None else spare[0], bq if gq is not None else 0.0,
+               gk if gk is not None else spare[1], bk if gk is not None else 0.0,
+               gv if gv is not None else spare[2], bv if gv is not None else 0.0,
+               gs, B, C, T, self.scale, rt.stream)
+      return
+    gs = bs if self.qkv is not None else C * T
     dp = rt.v(self.s)   # S is dead after the forward softmax: reuse it for dP, then dS
     # dP[b][t][t'] = sum_c dO[b][c][t] V[b][c][t']
-    lib.gemm_f32(go, 1, T, C * T, rt.v(self.vv), T, 1, C * T, dp, T, 1, T * T,
+    lib.gemm_f32(go, 1, T, C * T, v, T, 1, bs, dp, T, 1, T * T,
                  None, 0, T, T, C, B, 1.0, 0.0, rt.stream)
-    gv = rt.g(self.vv)
     if gv is not None:  # dV[b][c][t'] = sum_t dO[b][c][t] P[b][t][t']
-      lib.gemm_f32(go, T, 1, C * T, rt.v(self.p), T, 1, T * T, gv, T, 1, C * T,
-                   None, 0, C, T, T, B, 1.0, self.b(self.vv), rt.stream)
+      lib.gemm_f32(go, T, 1, C * T, rt.v(self.p), T, 1, T * T, gv, T, 1, gs,
+                   None, 0, C, T, T, B, 1.0, bv, rt.stream)
     lib.softmax_bwd_f32(rt.v(self.p), dp, dp, B * T, T, self.scale, rt.stream)   # dS in place
-    gq = rt.g(self.q)
     if gq is not None:  # dQ[b][c][t] = sum_t' K[b][c][t'] dS[b][t][t']
-      lib.gemm_f32(rt.v(self.k), T, 1, C * T, dp, 1, T, T * T, gq, T, 1, C * T,
-                   None, 0, C, T, T, B, 1.0, self.b(self.q), rt.stream)
-    gk = rt.g(self.k)
+      lib.gemm_f32(k, T, 1, bs, dp, 1, T, T * T, gq, T, 1, gs,
+                   None, 0, C, T, T, B, 1.0, bq, rt.stream)
     if gk is not None:  # dK[b][c][t'] = sum_t Q[b][c][t] dS[b][t][t']
-      lib.gemm_f32(rt.v(self.q), T, 1, C * T, dp, T, 1, T * T, gk, T, 1, C * T,
-                   None, 0, C, T, T, B, 1.0, self.b(self.k), rt.stream)
+      lib.gemm_f32(q, T, 1, bs, dp, T, 1, T * T, gk, T, 1, gs,
+                   None, 0, C, T, T, B, 1.0, bk, rt.stream)
 
   def ws_bytes(self, lib):
-    return 3 * 4 * self.q.numel if self.fused else 0
+    return 3 * 4 * self.B * self.C * self.T if (self.fused and self.qkv is None) else 0
 
 
 class RowScale(Op):
@@ -799,6 +820,11 @@ class Graph:
     op = Conv(self, x1, x2, self.param(weight), self.param(bias), w_layout, Cout, KH, KW, stride, pad, OH, OW,
               temb=temb, temb_col=temb_col, res=res, out_div=out_div, name=name)
     return self.add(op)
+
+  def conv1x1_t(self, x1, w_tensor, b_tensor, Cout, name='conv'):
+    """1x1 convolution (NIN layout, w[Cin][Cout]) on graph tensors that stand for SEVERAL stacked parameters."""
+    H, W = x1.shape[2], x1.shape[3]
+    return self.add(Conv(self, x1, None, w_tensor, b_tensor, 1, Cout, 1, 1, 1, 0, H, W, name=name))
 
   def linear(self, x, weight, bias, name='linear'):
     return self.add(Linear(self, x, self.param(weight), self.param(bias), name))

@@ -64,8 +64,8 @@ SIGNATURES = {
   'stk_softmax_fwd_f32': [P, P, L, I, F, S],
   'stk_softmax_bwd_f32': [P, P, P, L, I, F, S],
   'stk_attention_ok': [I, I, I],
-  'stk_attention_fwd_f32': [P, P, P, P, P, P, I, I, I, F, S],
-  'stk_attention_bwd_f32': [P, P, P, P, P, P, P, P, F, P, F, P, F, I, I, I, F, S],
+  'stk_attention_fwd_f32': [P, P, P, L, P, P, P, I, I, I, F, S],
+  'stk_attention_bwd_f32': [P, P, P, L, P, P, P, P, P, F, P, F, P, F, L, I, I, I, F, S],
   'stk_silu_fwd_f32': [P, P, L, S],
   'stk_silu_bwd_f32': [P, P, P, F, L, S],
   'stk_axpby_f32': [P, F, P, F, P, L, S],

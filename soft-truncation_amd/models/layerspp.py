@@ -9,6 +9,8 @@ evaluated as one GEMM by the caller (``temb`` below is that shared [B, sum Cout]
 block's column offset).
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -77,13 +79,34 @@ class AttnBlockpp(nn.Module):
     self.NIN_3 = NIN(channels, channels, init_scale=init_scale)
     self.skip_rescale = skip_rescale
 
+  def qkv_params(self):
+    """The three projections as one: weights to be interleaved column-wise ([in, 3 out]), biases back to back
+    (engine/flat.py; NCSNpp._flat_groups asks for exactly this layout)."""
+    return [self.NIN_0.W, self.NIN_1.W, self.NIN_2.W], [self.NIN_0.b, self.NIN_1.b, self.NIN_2.b]
+
   def emit(self, g, x, name='attn'):
-    from ..engine.graph import AttentionCore
+    from ..engine.graph import AttentionCore, Tensor
     h = g.gn_act(x, None, self.GroupNorm_0, act=False, name=name + '.gn')
-    q = self.NIN_0.emit(g, h, name=name + '.q')
-    k = self.NIN_1.emit(g, h, name=name + '.k')
-    v = self.NIN_2.emit(g, h, name=name + '.v')
-    o = g.add(AttentionCore(g, q, k, v, name=name))
+    ws, bs = self.qkv_params()
+    C = self.NIN_0.W.shape[1]
+    w_off = g.flat.cols_block(ws) if hasattr(g.flat, 'cols_block') else None
+    b0 = g.param(bs[0])
+    stacked = (w_off is not None and os.environ.get('STK_QKV_STACKED', '1') != '0' and
+               all(g.flat.offset_of(b)[0] == b0.off + i * C for i, b in enumerate(bs)))
+    if stacked:
+      # q, k, v = three NIN layers on the same input (layerspp.py:91-93) as ONE 1x1 convolution with 3 C output
+      # channels: h is read once, and the backward is one data gradient and one weight gradient instead of three each
+      w_all = Tensor((ws[0].shape[0], 3 * C), 'param', w_off, True, name + '.Wqkv')
+      w_all.goff = w_off
+      b_all = Tensor((3 * C,), 'param', b0.off, True, name + '.bqkv')
+      b_all.goff = b0.off
+      qkv = g.conv1x1_t(h, w_all, b_all, 3 * C, name=name + '.qkv')
+      o = g.add(AttentionCore(g, None, None, None, name=name, qkv=qkv))
+    else:
+      q = self.NIN_0.emit(g, h, name=name + '.q')
+      k = self.NIN_1.emit(g, h, name=name + '.k')
+      v = self.NIN_2.emit(g, h, name=name + '.v')
+      o = g.add(AttentionCore(g, q, k, v, name=name))
     return self.NIN_3.emit(g, o, res=x, out_div=SQRT2 if self.skip_rescale else 1.0, name=name + '.out')
 
   def forward(self, x):

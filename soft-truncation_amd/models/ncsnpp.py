@@ -221,10 +221,15 @@ class NCSNpp(nn.Module):
     return [mod for mod in self.all_modules if hasattr(mod, 'Dense_0')]
 
   def _flat_groups(self):
+    groups = []
     dense = self._dense_blocks()
-    if not dense:
-      return ()
-    return ([b.Dense_0.weight for b in dense], [b.Dense_0.bias for b in dense])
+    if dense:
+      groups += [[b.Dense_0.weight for b in dense], [b.Dense_0.bias for b in dense]]
+    for mod in self.modules():
+      if isinstance(mod, layerspp.AttnBlockpp):
+        ws, bs = mod.qkv_params()
+        groups += [('cols', ws), bs]
+    return tuple(groups)
 
   def _uses_dropout(self):
     return any(isinstance(mod, nn.Dropout) and mod.p > 0 for mod in self.modules())

@@ -170,3 +170,25 @@ def test_linear_data_gradient_k_split(st, ref_lib, monkeypatch):
   model(torch.randn(2, 3, 16, 16), torch.rand(2) * 999).sum().backward()
   lins = [op for pr in model.module.engine().programs.values() for op in pr.graph.ops if isinstance(op, G.Linear)]
   assert any(op.ksplit > 1 for op in lins)
+
+
+def test_qkv_projection_is_planned_stacked(st, ref_lib):
+  """AttnBlockpp's q / k / v NIN layers share their input: the flat layout interleaves their [in, out] weights into one
+  [in, 3 out] matrix (engine/flat.py 'cols' group) and the plan holds ONE 1x1 convolution with 3 C output channels whose
+  channel slices the attention op reads through a batch stride.  The parameters stay separate nn.Parameters (strided
+  views) with the reference's names, values and gradients -- checked against RefNet by forward_backward."""
+  import torch
+  from importlib import import_module
+  G = import_module('soft-truncation_amd.engine.graph')
+  cases.forward_backward(st, ref_lib, 'vp')
+  cfg, cfg_cpu, sde, model, ref = cases.build_pair(st, cases.tiny_config(st, 'vp'), ref_lib)
+  model(torch.randn(2, 3, 16, 16), torch.rand(2) * 999).sum().backward()
+  ops = [op for pr in model.module.engine().programs.values() for op in pr.graph.ops]
+  attn = [op for op in ops if isinstance(op, G.AttentionCore)]
+  assert attn and all(op.qkv is not None for op in attn)
+  net = model.module
+  blk = next(m for m in net.modules() if type(m).__name__ == 'AttnBlockpp')
+  assert not blk.NIN_1.W.is_contiguous() and blk.NIN_1.W.grad is not None and blk.NIN_1.W.grad.abs().sum() > 0
+  sd = model.state_dict()
+  key = next(k for k in sd if k.endswith('NIN_1.W'))
+  assert sd[key].shape == blk.NIN_1.W.shape

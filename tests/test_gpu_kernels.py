@@ -606,19 +606,37 @@ ATTN_CASES = [
 ]
 
 
+@pytest.mark.parametrize('stacked', [False, True], ids=['separate', 'stacked'])
 @pytest.mark.parametrize('case', ATTN_CASES, ids=lambda c: f'B{c[0]}C{c[1]}T{c[2]}b{c[3]}m{c[4][0]:g}')
-def test_attention(ref_lib, hip_lib, case):
+def test_attention(ref_lib, hip_lib, case, stacked):
+  """stacked: q, k, v (and dq, dk, dv) are the channel slices of one [B, 3C, T] tensor, addressed through the batch
+  stride, as the engine's stacked q / k / v projection hands them over."""
   B, C, T, beta, (mq, mk, mv, mdo) = case
   assert hip_lib.attention_ok(B, C, T) == 1
   q, k, v, do = rnd(B, C, T, seed=1) * mq, rnd(B, C, T, seed=2) * mk, rnd(B, C, T, seed=3) * mv, rnd(B, C, T, seed=4) * mdo
   g0 = [rnd(B, C, T, seed=5 + i) * m * 0.1 for i, m in enumerate((mk, mq, mdo))]       # accumulated into when beta != 0
   scale = float(C) ** -0.5
+  bs = 3 * C * T if stacked else C * T
 
   def fn(lib, to):
     o, lse, rec, delta = to(torch.zeros(B, C, T)), to(torch.zeros(B, T)), to(torch.zeros(1024)), to(torch.zeros(B, T))
-    call(lib, 'attention_fwd_f32', to(q), to(k), to(v), o, lse, rec, B, C, T, scale)
-    dq, dk, dv = (to(g.clone()) for g in g0)
-    call(lib, 'attention_bwd_f32', to(q), to(k), to(v), to(do), lse, rec, delta, dq, beta, dk, beta, dv, beta, B, C, T, scale)
+    if stacked:
+      qkv, g = to(torch.cat([q, k, v], 1)), to(torch.cat(g0, 1))
+      ins = [qkv[0, i * C:].data_ptr() for i in range(3)]
+      outs_ = [g[0, i * C:].data_ptr() for i in range(3)]
+    else:
+      keep = [to(q), to(k), to(v)] + [to(t.clone()) for t in g0]
+      ins, outs_ = [t.data_ptr() for t in keep[:3]], [t.data_ptr() for t in keep[3:]]
+    stream = torch.cuda.current_stream().cuda_stream if lib.is_device else 0
+    lib.attention_fwd_f32(ins[0], ins[1], ins[2], bs, o.data_ptr(), lse.data_ptr(), rec.data_ptr(), B, C, T, scale, stream)
+    lib.attention_bwd_f32(ins[0], ins[1], ins[2], bs, to(do).data_ptr(), lse.data_ptr(), rec.data_ptr(), delta.data_ptr(),
+                          outs_[0], beta, outs_[1], beta, outs_[2], beta, bs, B, C, T, scale, stream)
+    if lib.is_device:
+      torch.cuda.synchronize()
+    if stacked:
+      dq, dk, dv = (g[:, i * C:(i + 1) * C].contiguous() for i in range(3))
+    else:
+      dq, dk, dv = keep[3:]
     return {'o': o, 'lse': lse, 'delta': delta, 'dq': dq, 'dk': dk, 'dv': dv}
 
   outs = both(ref_lib, hip_lib, fn)
@@ -635,7 +653,7 @@ def test_attention_unsupported_shapes_are_refused(hip_lib):
   assert hip_lib.attention_ok(2, 64, 1024) == 0 and hip_lib.attention_ok(2, 64, 30) == 0
   x = torch.zeros(2 * 48 * 64, device='cuda')
   r = torch.zeros(1024, device='cuda')
-  rc = hip_lib.attention_fwd_f32.raw(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), r.data_ptr(), r.data_ptr(),
+  rc = hip_lib.attention_fwd_f32.raw(x.data_ptr(), x.data_ptr(), x.data_ptr(), 48 * 64, x.data_ptr(), r.data_ptr(), r.data_ptr(),
                                      2, 48, 64, 0.1, 0)
   assert rc != 0
 

@@ -10,7 +10,7 @@ B, C, T = 128, 256, 256
 d = torch.device('cuda:0')
 q, k, v = (torch.randn(B, C, T, device=d) for _ in range(3))
 o, lse, rec = torch.empty(B, C, T, device=d), torch.empty(B, T, device=d), torch.empty(1024, device=d)
-lib.attention_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), rec.data_ptr(), B, C, T, C ** -0.5, 0)
+lib.attention_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), C * T, o.data_ptr(), lse.data_ptr(), rec.data_ptr(), B, C, T, C ** -0.5, 0)
 dbg = torch.zeros(16, dtype=torch.int64, device=d)
 fn = lib._cdll.stk_attention_fwd_debug
 fn.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]

@@ -141,8 +141,8 @@ def main():
       sc = float(C) ** -0.5
       shape = f'C{C} T{T} b{B}'
       fl = 2.0 * B * T * T * C
-      rec('attn.fwd.fused', shape, timeit(lambda: call(lib, 'attention_fwd_f32', q, k, v, o, lse, rcd, B, C, T, sc), args.reps), flops=2 * fl)
-      rec('attn.bwd.fused', shape, timeit(lambda: call(lib, 'attention_bwd_f32', q, k, v, do, lse, rcd, delta, dq, 0.0, dk, 0.0, dv, 0.0, B, C, T, sc), args.reps), flops=4 * fl)
+      rec('attn.fwd.fused', shape, timeit(lambda: call(lib, 'attention_fwd_f32', q, k, v, C * T, o, lse, rcd, B, C, T, sc), args.reps), flops=2 * fl)
+      rec('attn.bwd.fused', shape, timeit(lambda: call(lib, 'attention_bwd_f32', q, k, v, C * T, do, lse, rcd, delta, dq, 0.0, dk, 0.0, dv, 0.0, C * T, B, C, T, sc), args.reps), flops=4 * fl)
 
       def unfused_fwd():
         call(lib, 'gemm_f32', q, 1, T, C * T, k, T, 1, C * T, S, T, 1, T * T, None, 0, T, T, C, B, 1.0, 0.0)
