@@ -243,6 +243,12 @@ int stk_bias_grad_f32(const float* dy, int N, int C, int HW, float alpha,
  * c < C <= 256, zeros behind -- the bias gradient reads every element of dy anyway.  dtemb and dbias may both be NULL. */
 int stk_bias_grad_amax_f32(const float* dy, int N, int C, int HW, float alpha,
                            float* dtemb, int temb_stride, float* dbias, float* amax, float* ws, void* stream);
+/* The same plus the gradient of a residual branch in the same pass: dres = alpha * dy + dres_beta * dres (the skip
+ * connection of a ResnetBlock / attention block whose last convolution produced y = (conv + res) / out_div,
+ * models/layerspp.py:104,287; alpha = 1 / out_div).  dres [N, C, HW]; beta == 0: not read. */
+int stk_bias_grad_amax_res_f32(const float* dy, int N, int C, int HW, float alpha,
+                               float* dtemb, int temb_stride, float* dbias, float* amax,
+                               float* dres, float dres_beta, float* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batched strided GEMM on the fp32 MFMA path:

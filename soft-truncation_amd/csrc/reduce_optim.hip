@@ -107,34 +107,55 @@ __device__ __forceinline__ float row_sum(const float* __restrict__ p, int HW, in
 // AMAX: also track max |dy| of the channel (the sums need every element anyway) and leave it in amax[c] -- a planes scale
 // record of the gradient tensor (include/stk.h "Planes") with one entry per channel, zero-filled up to 256 entries, so
 // the data-gradient call that follows needs no |dy| pass of its own.
-template <bool AMAX>
-__device__ __forceinline__ float row_sum_max(const float* __restrict__ p, int HW, int lane, bool vec, float& m) {
+// RES: the row also is the gradient of a residual branch, res = alpha * dy + rbeta * res (the skip of a ResnetBlock /
+// attention block whose last convolution this is, models/layerspp.py:104,287) -- written on the way instead of by a
+// separate 3-stream axpby pass.
+template <bool AMAX, bool RES>
+__device__ __forceinline__ float row_sum_max(const float* __restrict__ p, int HW, int lane, bool vec, float& m,
+                                             float* __restrict__ res, float alpha, float rbeta) {
   float s = 0.f;
   if (vec) {
     const float4* p4 = reinterpret_cast<const float4*>(p);
+    float4* r4 = reinterpret_cast<float4*>(res);
     for (int i = lane; i < (HW >> 2); i += 64) {
       const float4 v = p4[i];
       s += (v.x + v.y) + (v.z + v.w);
       if (AMAX) m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      if (RES) {
+        float4 o = make_float4(alpha * v.x, alpha * v.y, alpha * v.z, alpha * v.w);
+        if (rbeta != 0.f) {
+          const float4 r = r4[i];
+          o.x = __fmaf_rn(rbeta, r.x, o.x); o.y = __fmaf_rn(rbeta, r.y, o.y);
+          o.z = __fmaf_rn(rbeta, r.z, o.z); o.w = __fmaf_rn(rbeta, r.w, o.w);
+        }
+        r4[i] = o;
+      }
     }
   } else {
-    for (int i = lane; i < HW; i += 64) { s += p[i]; if (AMAX) m = fmaxf(m, fabsf(p[i])); }
+    for (int i = lane; i < HW; i += 64) {
+      s += p[i];
+      if (AMAX) m = fmaxf(m, fabsf(p[i]));
+      if (RES) res[i] = rbeta != 0.f ? __fmaf_rn(rbeta, res[i], alpha * p[i]) : alpha * p[i];
+    }
   }
   return s;
 }
-template <bool AMAX>
+template <bool AMAX, bool RES = false>
 __global__ __launch_bounds__(1024) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ rows,
                                                          int rows_stride, float* __restrict__ dbias, int N, int C,
-                                                         int HW, float alpha, float* __restrict__ amax) {
+                                                         int HW, float alpha, float* __restrict__ amax,
+                                                         float* __restrict__ res = nullptr, float rbeta = 0.f) {
   __shared__ float red[16];
   __shared__ float redm[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = blockIdx.x;
-  const bool vec = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+  const bool vec = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+                   (!RES || (reinterpret_cast<uintptr_t>(res) & 15) == 0);
   float tot = 0.f, mx = 0.f;
   for (int n = wv; n < N; n += 32) {
     const int n2 = n + 16;
-    float s0 = row_sum_max<AMAX>(dy + ((long)n * C + c) * HW, HW, lane, vec, mx);
-    float s1 = n2 < N ? row_sum_max<AMAX>(dy + ((long)n2 * C + c) * HW, HW, lane, vec, mx) : 0.f;
+    const long o0 = ((long)n * C + c) * HW, o1 = ((long)n2 * C + c) * HW;
+    float s0 = row_sum_max<AMAX, RES>(dy + o0, HW, lane, vec, mx, RES ? res + o0 : nullptr, alpha, rbeta);
+    float s1 = n2 < N ? row_sum_max<AMAX, RES>(dy + o1, HW, lane, vec, mx, RES ? res + o1 : nullptr, alpha, rbeta) : 0.f;
     s0 = alpha * wave_sum(s0);
     s1 = alpha * wave_sum(s1);
     if (rows && lane == 0) {
@@ -328,6 +349,21 @@ int stk_bias_grad_amax_f32(const float* dy, int N, int C, int HW, float alpha, f
     if (rc) return rc;
   }
   return stk_amax_partial_f32(dy, (long)N * C * HW, amax, stream);
+}
+
+/* stk_bias_grad_amax_f32 + dres = alpha * dy + dres_beta * dres in the same pass over dy (the residual branch's gradient). */
+int stk_bias_grad_amax_res_f32(const float* dy, int N, int C, int HW, float alpha, float* dtemb, int temb_stride,
+                               float* dbias, float* amax, float* dres, float dres_beta, float* ws, void* stream) {
+  if (!dy || !amax || !dres || N <= 0 || C <= 0 || C > 256 || HW <= 0 || (!dtemb && !dbias && !ws)) return STK_EINVAL;
+  if (HW < 4096) {
+    hipLaunchKernelGGL((bias_grad_kernel<true, true>), dim3((unsigned)C), dim3(1024), 0, S(stream), dy, dtemb, temb_stride,
+                       dbias, N, C, HW, alpha, amax, dres, dres_beta);
+    STK_CHECK_LAUNCH();
+    return STK_OK;
+  }
+  const int rc = stk_axpby_f32(dy, alpha, dres, dres_beta, dres, (long)N * C * HW, stream);
+  if (rc) return rc;
+  return stk_bias_grad_amax_f32(dy, N, C, HW, alpha, dtemb, temb_stride, dbias, amax, ws, stream);
 }
 
 int stk_bias_grad_f32(const float* dy, int N, int C, int HW, float alpha, float* dtemb, int temb_stride, float* dbias,

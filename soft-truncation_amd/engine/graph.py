@@ -338,9 +338,6 @@ class Conv(Op):
     gy = rt.g(self.y)
     alpha = 1.0 / self.out_div
     lib = rt.lib
-    if self.res is not None and self.res.needs_grad:
-      gr = rt.g(self.res)
-      lib.axpby_f32(gy, alpha, gr, self.b(self.res), gr, self.y.numel, rt.stream)
     dtemb = None
     if self.temb is not None and self.temb.needs_grad:
       dtemb = rt.g(self.temb) + 4 * self.temb_col
@@ -351,12 +348,23 @@ class Conv(Op):
     pl_wgrad = self.pl_wgrad and gw is not None
     dy_rec = rt.v(self.amax) + 4 * 512           # |dy| scale record: planes of dy, reused by the weight gradient
     rec_done = False
-    if (pl_dgrad or pl_wgrad) and self.Cout <= 256 and (dtemb is not None or gb is not None):
+    fuse_rec = (pl_dgrad or pl_wgrad) and self.Cout <= 256 and (dtemb is not None or gb is not None)
+    res_grad = self.res is not None and self.res.needs_grad
+    if res_grad and fuse_rec and hasattr(lib, 'bias_grad_amax_res_f32') and os.environ.get('STK_RES_FUSED', '1') != '0':
+      # one pass over dy: bias / time-embedding sums, the |dy| scale record AND the residual branch's gradient
+      lib.bias_grad_amax_res_f32(gy, self.N, self.Cout, self.OH * self.OW, alpha, dtemb, self.temb_stride, gb, dy_rec,
+                                 rt.g(self.res), self.b(self.res), rt.ws, rt.stream)
+      rec_done = True
+      res_grad = fuse_rec = False
+    if res_grad:
+      gr = rt.g(self.res)
+      lib.axpby_f32(gy, alpha, gr, self.b(self.res), gr, self.y.numel, rt.stream)
+    if fuse_rec:
       # the bias gradient reads all of dy: it leaves the per-channel |dy| maxima behind as the scale record
       lib.bias_grad_amax_f32(gy, self.N, self.Cout, self.OH * self.OW, alpha, dtemb, self.temb_stride, gb, dy_rec,
                              rt.ws, rt.stream)
       rec_done = True
-    elif dtemb is not None or gb is not None:
+    elif not rec_done and (dtemb is not None or gb is not None):
       lib.bias_grad_f32(gy, self.N, self.Cout, self.OH * self.OW, alpha, dtemb, self.temb_stride, gb,
                         rt.ws, rt.stream)
     # data gradient first: its |dy| maxima are reused by the weight gradient (the two are independent otherwise)

@@ -60,6 +60,7 @@ SIGNATURES = {
   'stk_conv2d_wgrad_pl_f32': [P, P, P, P, P, F, P, L, I, I, I, I, I, S],
   'stk_bias_grad_f32': [P, I, I, I, F, P, I, P, P, S],
   'stk_bias_grad_amax_f32': [P, I, I, I, F, P, I, P, P, P, S],
+  'stk_bias_grad_amax_res_f32': [P, I, I, I, F, P, I, P, P, P, F, P, S],
   'stk_gemm_f32': [P, L, L, L, P, L, L, L, P, L, L, L, P, I, I, I, I, I, F, F, S],
   'stk_softmax_fwd_f32': [P, P, L, I, F, S],
   'stk_softmax_bwd_f32': [P, P, P, L, I, F, S],

@@ -263,6 +263,39 @@ def test_bias_grad_with_scale_record(ref_lib, hip_lib, case):
   assert (hdt - rdt).abs().max().item() <= 1e-5 * rdt.abs().max().item()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('beta', [0.0, 1.0], ids=lambda b: f'beta{b:g}')
+@pytest.mark.parametrize('case', [(8, 128, 1024), (5, 256, 64), (3, 96, 256), (2, 64, 4096), (3, 40, 25)], ids=str)
+def test_bias_grad_with_scale_record_and_residual(ref_lib, hip_lib, case, beta):
+  """stk_bias_grad_amax_res_f32 = stk_bias_grad_amax_f32 + dres = alpha dy + beta dres in the same pass over dy (the
+  skip connection's gradient): the sums and the record as the plain call, dres to one rounding of the axpby it replaces."""
+  N, C, HW = case
+  dy = rnd(N, C, HW, seed=5) * torch.logspace(-3, 1, N)[:, None, None]
+  r0 = rnd(N, C, HW, seed=6)
+  res = {}
+  for name, lib in (('ref', ref_lib), ('hip', hip_lib)):
+    d = dev_of(lib)
+    out = []
+    for fused in (True, False):
+      db, dt = torch.ones(C, device=d), torch.zeros(N, C + 8, device=d)
+      rec = torch.full((256,), float('nan'), device=d)
+      ws = torch.zeros(N * C + 64, device=d)
+      dres = r0.to(d).clone() if beta else torch.full((N, C, HW), float('nan'), device=d)
+      if fused:
+        call(lib, 'bias_grad_amax_res_f32', dy.to(d), N, C, HW, 0.5, dt, C + 8, db, rec, dres, beta, ws)
+      else:
+        call(lib, 'bias_grad_amax_f32', dy.to(d), N, C, HW, 0.5, dt, C + 8, db, rec, ws)
+        call(lib, 'axpby_f32', dy.to(d), 0.5, dres, beta, dres, N * C * HW)
+      out.append((db.cpu(), dt.cpu(), rec.cpu(), dres.cpu()))
+    res[name] = out
+  (hf, hp), (rf, _) = res['hip'], res['ref']
+  assert torch.equal(hf[2], hp[2]) and float(hf[2].max()) == float(dy.abs().max())       # the record: bit-exact
+  assert torch.equal(hf[0], hp[0]) and torch.equal(hf[1], hp[1])                           # same summation order
+  assert (hf[3] - hp[3]).abs().max().item() <= 1e-6 * hp[3].abs().max().item()
+  assert (hf[3] - rf[3]).abs().max().item() <= 1e-6 * rf[3].abs().max().item()
+  assert (hf[0] - rf[0]).abs().max().item() <= 1e-5 * rf[0].abs().max().item()
+
+
 WGRAD_PL_CASES = [
   # N, Cin, Cout, H
   (8, 128, 128, 32),      # COLS = 32, one row per chunk
