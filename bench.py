@@ -245,7 +245,7 @@ def sampler_rate(st, cfg, sde, score_model, batch, steps, device):
 
 def arithmetic_check(device):
   """Accuracy of the two convolution paths on one layer of the workload's shape (128 -> 128, 3x3, 32x32, batch 24),
-  each against float64: the bf16 three-way-split kernel (ws given) and the f32-input MFMA kernel (ws = NULL).
+  each against float64: the fp16 two-way-split kernel (ws given) and the f32-input MFMA kernel (ws = NULL).
   Reported so that the `dtype: f32` claim of this line can be checked from the line itself."""
   from importlib import import_module
   lib = import_module('soft-truncation_amd.engine.lib').load()
@@ -267,6 +267,25 @@ def arithmetic_check(device):
     out[name + '_max_err_over_max_abs'] = float((y.double() - ref).abs().max() / ref.abs().max())
   out['split_path_selected'] = nbytes > 0
   return out
+
+
+def pipe_probe(device):
+  """What the 16-bit matrix pipe sustains on THIS box on random data: a 4096^3 fp16 library GEMM (torch.matmul ->
+  hipBLASLt).  The nominal 2500 TFLOP/s is a 2.4 GHz figure; under matrix load the chip clocks to its power budget
+  (MI355X_MICROARCH.md "DVFS give-back") and the vendor's own GEMM reaches about half of it.  Reported next to the
+  roofline so that the fraction of the nominal peak can be read against what is attainable."""
+  a = torch.randn(4096, 4096, device=device, dtype=torch.float16)
+  b = torch.randn(4096, 4096, device=device, dtype=torch.float16)
+  for _ in range(5):
+    torch.matmul(a, b)
+  torch.cuda.synchronize()
+  s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  s.record()
+  for _ in range(20):
+    torch.matmul(a, b)
+  e.record()
+  torch.cuda.synchronize()
+  return 2.0 * 4096 ** 3 * 20 / (s.elapsed_time(e) * 1e-3) / 1e12
 
 
 def free_port():
@@ -437,6 +456,17 @@ def main():
                                                'parameter per step, against 8 TB/s'})
     if world == 1:
       out['arithmetic_check'] = arithmetic_check(device)
+      try:
+        lib_tf = pipe_probe(device)
+        if 'roofline' in out and out['roofline']['peak'] == PEAK_X2_TFLOPS:
+          out['roofline'].update({
+            'library_gemm_fp16_tflops': lib_tf,
+            'frac_of_library_gemm': 3.0 * out['roofline']['achieved'] / lib_tf,
+            'library_note': 'torch.matmul (hipBLASLt) fp16 4096^3 on random data, timed in this process: what the 16-bit '
+                            'matrix pipe sustains at its power-limited clock; the kernel issues 3 MFMAs per fp32 product, so '
+                            'frac_of_library_gemm = 3 x achieved / library rate'})
+      except Exception as e:   # reported, never fatal
+        out['pipe_probe_error'] = repr(e)
     if world == 1 and args.sampler_steps > 0:        # like the CPU baseline: only in the single-GPU run
       try:
         out['sampler'] = sampler_rate(st, cfg, sde, score_model, per_gpu_batch, args.sampler_steps, device)

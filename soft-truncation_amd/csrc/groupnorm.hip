@@ -56,12 +56,34 @@ __device__ __forceinline__ void group_segments(const GnArgs& a, int n, int g, Se
   }
 }
 
-// u * sigmoid(u) with the accurate expf and the IEEE division.  The hardware forms were tried and rejected: __expf
-// (argument scaling costs |u| * 2^-24) moved the likelihood ODE's latent to 3e-4 from the reference's fixture, and
-// even the 1-ulp v_rcp_f32 raised the noise floor of the adaptive solver enough for 10 % more function evaluations.
+// u * sigmoid(u) = u / (1 + exp(-u)), to the accuracy of the libm expf + IEEE division it replaces (<= ~1.5 ulp in the
+// exponential, a correctly rounded quotient in all but rare cases) at about half their VALU cost (14 instead of ~25
+// instructions per element -- the forward GroupNorm + SiLU kernels are VALU-limited, not HBM-limited, at that cost):
+//   exp(-u) = 2^t (1 + r ln 2),  t = fl(-u log2 e),  r = the exact residual of that product plus the low part of log2 e
+//             (two FMAs), 2^t from v_exp_f32 (1 ulp);
+//   u / d   = one v_rcp_f32, one Newton step, and a residual correction of the quotient (FMAs).
+// The raw hardware forms had been tried and rejected: __expf without the residual (argument scaling costs |u| 2^-24)
+// moved the likelihood ODE's latent to 3e-4 from the reference's fixture, and the bare 1-ulp v_rcp_f32 raised the noise
+// floor of the adaptive solver enough for 10 % more function evaluations.  STK_SILU_LIBM (compile time) restores libm.
 // Dropout: a float4 item is exactly one quad of the counter RNG (stk_rng.h): one 64-bit mix per item, a 16-bit field
 // per element (its flat index is a multiple of 4 because H*W is).
-__device__ __forceinline__ float silu_f(float u) { return u / (1.f + expf(-u)); }
+__device__ __forceinline__ float silu_f(float u) {
+#ifdef STK_SILU_LIBM
+  return u / (1.f + expf(-u));
+#else
+  const float NL2E_HI = -1.44269502162933349609375f, NL2E_LO = -1.925963033500011e-8f;     // -log2(e) = HI + LO
+  const float t = u * NL2E_HI;
+  float r = __fmaf_rn(u, NL2E_HI, -t);
+  r = __fmaf_rn(u, NL2E_LO, r);
+  const float p = __builtin_amdgcn_exp2f(t);
+  const float e = fminf(__fmaf_rn(p, r * 0.693147182464599609375f, p), 3.0e38f);          // finite: 1 + e stays finite
+  const float d = 1.f + e;
+  float rc = __builtin_amdgcn_rcpf(d);
+  rc = __fmaf_rn(rc, __fmaf_rn(-d, rc, 1.f), rc);
+  const float q = u * rc;
+  return __fmaf_rn(__fmaf_rn(-q, d, u), rc, q);
+#endif
+}
 
 // ---- forward ------------------------------------------------------------------------------------
 // Register-resident forward for groups of up to 16384 elements (every group of the 32x32 / 64x64 networks): a thread

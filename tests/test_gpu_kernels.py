@@ -271,7 +271,7 @@ CONV_CASES = [
   (5, 40, 0, 4, 4, 56, 1, 1, 0, 4, 4, 1, False, False, False),          # NIN, ragged channels
   (2, 20, 12, 12, 10, 24, 3, 1, 1, 12, 10, 0, True, True, False),       # ragged everything
   (130, 128, 0, 4, 4, 128, 3, 1, 1, 4, 4, 0, True, False, True),        # many tiny images per tile
-  (24, 128, 0, 32, 32, 128, 3, 1, 1, 32, 32, 0, True, True, True),      # >= 192 tiles: bf16 three-way-split kernel
+  (24, 128, 0, 32, 32, 128, 3, 1, 1, 32, 32, 0, True, True, True),      # >= 192 tiles: fp16 two-way-split kernel
   (48, 64, 96, 16, 16, 160, 3, 1, 1, 16, 16, 0, False, True, False),    # split kernel: concat input, ragged Cout
   (43, 96, 0, 24, 24, 128, 3, 1, 1, 24, 24, 0, True, False, False),     # split kernel: ragged pixel tiles
   (6, 64, 0, 8, 8, 96, 3, 1, 1, 8, 8, 0, False, False, False),          # split wgrad: 8-wide maps (runs span two rows)
@@ -296,7 +296,7 @@ def _conv_id(c):
 @pytest.mark.parametrize('scratch', [True, False], ids=['ws', 'nows'])
 @pytest.mark.parametrize('case', CONV_CASES, ids=_conv_id)
 def test_conv(ref_lib, hip_lib, case, scratch):
-  """scratch=True hands fwd / dgrad their workspace (shapes that qualify then take the bf16 three-way-split
+  """scratch=True hands fwd / dgrad their workspace (shapes that qualify then take the fp16 two-way-split
   kernel); scratch=False keeps every shape on the f32-input MFMA kernels.  Same tolerance for both."""
   N, C1, C2, H, W, Cout, K, stride, pad, OH, OW, layout, use_temb, use_res, use_div = case
   Cin = C1 + C2
