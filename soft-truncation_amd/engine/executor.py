@@ -208,7 +208,7 @@ class _NetFn(torch.autograd.Function):
   def forward(ctx, ex, training, anchor, x, emb_in, sigma):
     need_xgrad = bool(ctx.needs_input_grad[3])
     # grad mode is OFF inside autograd.Function.forward: say explicitly that a backward will follow
-    out, c = ex.run_forward(x, emb_in, sigma, training, need_xgrad, with_backward=True)
+    out, c = ex.run_forward(x, emb_in, sigma, training, need_xgrad, with_backward=True, flat=ex.flat)
     ctx.ex, ctx.c, ctx.need_xgrad = ex, c, need_xgrad
     return out
 
@@ -367,8 +367,9 @@ class Executor:
     self.graph_replays += 1
     return True
 
-  def run_forward(self, x, emb_in, sigma, training, need_xgrad, with_backward=False):
-    flat = self.ensure_flat()
+  def run_forward(self, x, emb_in, sigma, training, need_xgrad, with_backward=False, flat=None):
+    if flat is None:                      # apply() has just checked the layout: one walk over the ~570 parameters per call
+      flat = self.ensure_flat()
     B, _, H, W = x.shape
     prog = self.program(B, H, W, need_xgrad)
     c = prog.acquire()
@@ -463,6 +464,6 @@ class Executor:
     x = x.contiguous()
     if torch.is_grad_enabled():
       return _NetFn.apply(self, training, self._anchor, x, emb_in, sigma)
-    out, c = self.run_forward(x, emb_in, sigma, training, False)
+    out, c = self.run_forward(x, emb_in, sigma, training, False, flat=self.flat)
     c.prog.release(c)
     return out

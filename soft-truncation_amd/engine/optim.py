@@ -88,8 +88,18 @@ class FusedAdam(torch.optim.Optimizer):
 
   @torch.no_grad()
   def step(self, closure=None):
+    """One fused update of the whole trainable range [0, n_train).  torch.optim.Adam skips parameters whose .grad is
+    None; here every slot is stepped with whatever the flat gradient buffer holds (zeros for a parameter the planned
+    graph never writes, e.g. the Dense_0 layers of an unconditional model).  With weight_decay == 0 -- every shipped
+    config -- a zero gradient leaves such a parameter untouched, as in the reference; with weight decay it would decay,
+    which the reference would not do, hence the warning."""
     flat = self._bind()
     group = self.param_groups[0]
+    if group['weight_decay'] != 0 and not getattr(self, '_wd_warned', False):
+      self._wd_warned = True
+      import warnings
+      warnings.warn('FusedAdam applies weight decay to every trainable parameter, including ones that receive no '
+                    'gradient (torch.optim.Adam would skip those)')
     b1, b2 = group['betas']
     self._step += 1
     bc1 = 1.0 - b1 ** self._step

@@ -46,6 +46,19 @@ class ExponentialMovingAverage:
     one_minus_decay = 1.0 - decay
     with torch.no_grad():
       if self._flat is not None:
+        parameters = list(parameters)
+        live = flat_of(parameters) if parameters else self._flat
+        if live is not None and live is not self._flat:
+          # the executor rebuilt its flat buffer (a .to() / dtype move): follow it, keeping the averaged values
+          old = [s.clone() for s in self.shadow_params]
+          self._flat = live
+          self._shadow = live.data[:live.n_train].clone()
+          self.shadow_params = live.trainable_views(self._shadow)
+          for s_new, s_old in zip(self.shadow_params, old):
+            s_new.copy_(s_old.to(s_new.device))
+        elif live is None:
+          raise RuntimeError('ExponentialMovingAverage.update: the parameters no longer live in an engine.flat.FlatParams '
+                             'buffer; rebuild the average from the current parameters')
         flat = self._flat
         with stk_lib.device_guard(flat.device):
           self._lib().ema_f32(self._shadow.data_ptr(), flat.data.data_ptr(), flat.n_train, one_minus_decay,
