@@ -250,6 +250,20 @@ int stk_bias_grad_amax_res_f32(const float* dy, int N, int C, int HW, float alph
                                float* dtemb, int temb_stride, float* dbias, float* amax,
                                float* dres, float dres_beta, float* ws, void* stream);
 
+/* Two layers with the SAME output gradient up to a factor -- the last 3x3 convolution of a ResnetBlock and the 1x1
+ * shortcut convolution on the block input, whose outputs are added (models/layerspp.py:283-287): d(shortcut out) =
+ * d(block out) / out_div.  One pass over dy serves both: stk_bias_grad_amax_f32 + dbias2 += the same sums, amax2 = the
+ * same record (maps below 64 x 64).  stk_conv2d_dgrad_rec_f32 = stk_conv2d_dgrad_wp_f32 whose amax[512..768) already
+ * holds the record of ITS dy operand, so it makes no |dy| pass of its own (the factor goes into alpha). */
+int stk_bias_grad_amax_dual_f32(const float* dy, int N, int C, int HW, float alpha,
+                                float* dtemb, int temb_stride, float* dbias, float* amax,
+                                float* dbias2, float* amax2, float* ws, void* stream);
+int stk_conv2d_dgrad_rec_f32(const float* dy, const float* w, int w_layout,
+                             float* dx1, int C1, float beta1, float* dx2, int C2, float beta2,
+                             float alpha, int N, int H, int W, int Cout, int OH, int OW,
+                             int KH, int KW, int stride, int pad,
+                             const void* wp, float* amax, void* ws, long ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Batched strided GEMM on the fp32 MFMA path:
  *   C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][k][n] + bias + beta * C[b][m][n]

@@ -917,7 +917,7 @@ inline void x3_weight_strides(const ConvP& p, int dgrad, long& sm, long& sk) {
 template <class EP>
 int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2, int S2, int M, long Ng, int dgrad,
               void* ws, hipStream_t s, const void* wp_ready = nullptr, float* amax = nullptr,
-              const void* planes = nullptr, const float* planes_amax = nullptr) {
+              const void* planes = nullptr, const float* planes_amax = nullptr, bool amax_valid = false) {
   x3::Src q;
   q.s1 = s1; q.s2 = S2 > 0 ? s2 : s1; q.S1 = S1; q.S2 = S2; q.Kc = S1 + S2; q.Mpad = x3::pad128(M); q.taps = p.taps;
   q.pl = static_cast<const unsigned char*>(planes); q.pl_stride = planes ? pl::plane_bytes(p.N, S1, p.HW) : 0;
@@ -932,7 +932,7 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
     if (amax) xpart = amax + (dgrad ? 2 * x2::NPART : 0);
     if (planes) {
       xpart = const_cast<float*>(planes_amax);      // the scale record the planes were written with
-    } else {
+    } else if (!(amax_valid && amax && S2 == 0)) {   // amax_valid: the caller's record already holds this operand's maxima
       hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s1, (long)p.N * S1 * p.HW, xpart);
       if (S2 > 0)
         hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s2, (long)p.N * S2 * p.HW,
@@ -1205,10 +1205,30 @@ int stk_conv2d_fwd_f32(const float* x1, int C1, const float* x2, int C2, const f
                                KH, KW, stride, pad, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
+static int dgrad_impl(const float* dy, const float* w, int w_layout, float* dx1, int C1, float beta1, float* dx2,
+                      int C2, float beta2, float alpha, int N, int H, int W, int Cout, int OH, int OW, int KH,
+                      int KW, int stride, int pad, const void* wp, float* amax, void* ws, long ws_bytes,
+                      void* stream, bool dy_rec_valid);
 int stk_conv2d_dgrad_wp_f32(const float* dy, const float* w, int w_layout, float* dx1, int C1, float beta1, float* dx2,
                             int C2, float beta2, float alpha, int N, int H, int W, int Cout, int OH, int OW, int KH,
                             int KW, int stride, int pad, const void* wp, float* amax, void* ws, long ws_bytes,
                             void* stream) {
+  return dgrad_impl(dy, w, w_layout, dx1, C1, beta1, dx2, C2, beta2, alpha, N, H, W, Cout, OH, OW, KH, KW, stride, pad, wp,
+                    amax, ws, ws_bytes, stream, false);
+}
+/* ... with the |dy| scale record already in amax[512..768) (written by stk_bias_grad_amax*_f32): no |dy| pass */
+int stk_conv2d_dgrad_rec_f32(const float* dy, const float* w, int w_layout, float* dx1, int C1, float beta1, float* dx2,
+                             int C2, float beta2, float alpha, int N, int H, int W, int Cout, int OH, int OW, int KH,
+                             int KW, int stride, int pad, const void* wp, float* amax, void* ws, long ws_bytes,
+                             void* stream) {
+  if (!amax) return STK_EINVAL;
+  return dgrad_impl(dy, w, w_layout, dx1, C1, beta1, dx2, C2, beta2, alpha, N, H, W, Cout, OH, OW, KH, KW, stride, pad, wp,
+                    amax, ws, ws_bytes, stream, true);
+}
+static int dgrad_impl(const float* dy, const float* w, int w_layout, float* dx1, int C1, float beta1, float* dx2,
+                      int C2, float beta2, float alpha, int N, int H, int W, int Cout, int OH, int OW, int KH,
+                      int KW, int stride, int pad, const void* wp, float* amax, void* ws, long ws_bytes,
+                      void* stream, bool dy_rec_valid) {
   if (!dy || !w || (!dx1 && !dx2) || (w_layout != 0 && w_layout != 1) || (w_layout == 1 && (KH != 1 || KW != 1)))
     return STK_EINVAL;
   ConvP p = {};
@@ -1231,7 +1251,7 @@ int stk_conv2d_dgrad_wp_f32(const float* dy, const float* w, int w_layout, float
   }
   const X3Plan xr = x3_plan(p, Cout, Cout, 0, Cin, Ng);
   if (ws && xr.ok && ws_bytes >= x3_ws_bytes(xr, Cin, Cout, p.taps))
-    return launch_x3<EpDgrad>(p, xr, dy, Cout, nullptr, 0, Cin, Ng, 1, ws, s, wp, amax);
+    return launch_x3<EpDgrad>(p, xr, dy, Cout, nullptr, 0, Cin, Ng, 1, ws, s, wp, amax, nullptr, nullptr, dy_rec_valid);
   if (wp) return STK_EINVAL;
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;

@@ -144,7 +144,9 @@ template <bool AMAX, bool RES = false>
 __global__ __launch_bounds__(1024) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ rows,
                                                          int rows_stride, float* __restrict__ dbias, int N, int C,
                                                          int HW, float alpha, float* __restrict__ amax,
-                                                         float* __restrict__ res = nullptr, float rbeta = 0.f) {
+                                                         float* __restrict__ res = nullptr, float rbeta = 0.f,
+                                                         float* __restrict__ dbias2 = nullptr,
+                                                         float* __restrict__ amax2 = nullptr) {
   __shared__ float red[16];
   __shared__ float redm[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = blockIdx.x;
@@ -173,12 +175,17 @@ __global__ __launch_bounds__(1024) void bias_grad_kernel(const float* __restrict
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q];
     if (dbias) dbias[c] += t;
+    if (dbias2) dbias2[c] += t;                      // a second layer with the same output gradient (see _dual below)
     if (AMAX) {
       float m = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) m = fmaxf(m, redm[q]);
       amax[c] = m;
       for (int i = c + C; i < 256; i += C) amax[i] = 0.f;
+      if (amax2) {
+        amax2[c] = m;
+        for (int i = c + C; i < 256; i += C) amax2[i] = 0.f;
+      }
     }
   }
 }
@@ -364,6 +371,16 @@ int stk_bias_grad_amax_res_f32(const float* dy, int N, int C, int HW, float alph
   const int rc = stk_axpby_f32(dy, alpha, dres, dres_beta, dres, (long)N * C * HW, stream);
   if (rc) return rc;
   return stk_bias_grad_amax_f32(dy, N, C, HW, alpha, dtemb, temb_stride, dbias, amax, ws, stream);
+}
+
+/* stk_bias_grad_amax_f32 for TWO layers that share dy: dbias2 += the same sums, amax2 = the same record. */
+int stk_bias_grad_amax_dual_f32(const float* dy, int N, int C, int HW, float alpha, float* dtemb, int temb_stride,
+                                float* dbias, float* amax, float* dbias2, float* amax2, float* ws, void* stream) {
+  if (!dy || !amax || !amax2 || N <= 0 || C <= 0 || C > 256 || HW <= 0 || HW >= 4096) return STK_EINVAL;
+  hipLaunchKernelGGL((bias_grad_kernel<true, false>), dim3((unsigned)C), dim3(1024), 0, S(stream), dy, dtemb, temb_stride,
+                     dbias, N, C, HW, alpha, amax, (float*)nullptr, 0.f, dbias2, amax2);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
 }
 
 int stk_bias_grad_f32(const float* dy, int N, int C, int HW, float alpha, float* dtemb, int temb_stride, float* dbias,

@@ -285,6 +285,12 @@ class Conv(Op):
     off = self.wp_off[direction]
     return rt.wp + off if (rt.wp and off is not None) else None
 
+  # shared output gradient (Graph._plan_shared_dy): this layer's residual input `res` is the output of a shortcut
+  # convolution nobody else reads, so d(res) = dy / out_div needs no tensor of its own -- `dy_peer` is that convolution
+  # (it differentiates from THIS layer's dy with the factor folded into alpha); `dy_from` is the reverse link
+  dy_peer = None
+  dy_from = None
+
   # planes (include/stk.h "Planes"): decided by Graph.finalize
   pl_fwd = False       # the forward call reads x1 as planes
   pl_dgrad = False     # the data-gradient call reads dy as planes (made here, into the context's scratch)
@@ -318,6 +324,14 @@ class Conv(Op):
     if self.pl_dgrad or self.pl_wgrad:
       g.dypl_bytes = max(g.dypl_bytes, _round_up(int(lib.planes_bytes(self.N, self.Cout, self.OH * self.OW)), 256))
 
+  def plan_backward(self):
+    if self.dy_peer is not None:                 # d(res) is never written: do not count this op as a writer of it
+      saved, self.inputs = self.inputs, (self.x1, self.x2)
+      Op.plan_backward(self)
+      self.inputs = saved
+    else:
+      Op.plan_backward(self)
+
   def forward(self, rt):
     temb = rt.v(self.temb) + 4 * self.temb_col if self.temb is not None else None
     if self.pl_fwd:
@@ -338,6 +352,10 @@ class Conv(Op):
     gy = rt.g(self.y)
     alpha = 1.0 / self.out_div
     lib = rt.lib
+    src = self.dy_from                          # a later layer whose output gradient, times 1 / its out_div, is ours
+    if src is not None:
+      gy = rt.g(src.y)
+      alpha = alpha / src.out_div
     dtemb = None
     if self.temb is not None and self.temb.needs_grad:
       dtemb = rt.g(self.temb) + 4 * self.temb_col
@@ -350,6 +368,18 @@ class Conv(Op):
     rec_done = False
     fuse_rec = (pl_dgrad or pl_wgrad) and self.Cout <= 256 and (dtemb is not None or gb is not None)
     res_grad = self.res is not None and self.res.needs_grad
+    peer = self.dy_peer
+    if src is not None:
+      # the peer's pass over dy already left our bias gradient and our |dy| record behind
+      gb = dtemb = None
+      fuse_rec = False
+      rec_done = True
+    elif peer is not None:
+      # one pass over dy for both layers: sums -> both bias gradients, maxima -> both records; d(res) is never formed
+      lib.bias_grad_amax_dual_f32(gy, self.N, self.Cout, self.OH * self.OW, alpha, dtemb, self.temb_stride, gb, dy_rec,
+                                  rt.g(peer.bias), rt.v(peer.amax) + 4 * 512, rt.ws, rt.stream)
+      rec_done = True
+      res_grad = fuse_rec = False
     if res_grad and fuse_rec and hasattr(lib, 'bias_grad_amax_res_f32') and os.environ.get('STK_RES_FUSED', '1') != '0':
       # one pass over dy: bias / time-embedding sums, the |dy| scale record AND the residual branch's gradient
       lib.bias_grad_amax_res_f32(gy, self.N, self.Cout, self.OH * self.OW, alpha, dtemb, self.temb_stride, gb, dy_rec,
@@ -371,6 +401,8 @@ class Conv(Op):
     have = 1 if self._kind(lib, 'fwd').endswith('.x2') else 0
     if self.pl_fwd and not self.x_rec_own:
       have = 0                                   # x1's record lives with another layer: the weight gradient measures
+    if src is not None:
+      have |= 2                                  # the peer wrote our |dy| record
     if pl_dgrad or pl_wgrad:
       rec = dy_rec
       if not rec_done:
@@ -384,7 +416,7 @@ class Conv(Op):
                alpha, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self._wp(rt, 1), rt.ws, rt.ws_bytes, rt.stream)
       have |= 2
     elif g1 is not None or g2 is not None:
-      rt.timed(self._kind(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_wp_f32,
+      rt.timed(self._kind(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_rec_f32 if src is not None else lib.conv2d_dgrad_wp_f32,
                gy, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
                alpha, *self._dims(), self._wp(rt, 1), rt.v(self.amax), rt.ws, rt.ws_bytes, rt.stream)
@@ -851,8 +883,6 @@ class Graph:
       if t.needs_grad:
         t.goff = self.gact_size
         self.gact_size += _round_up(t.numel)
-    for op in reversed(self.ops):
-      op.plan_backward()
     self.ws_bytes = max([256] + [op.ws_bytes(lib) for op in self.ops])
     self.ws_bytes = _round_up(self.ws_bytes, 256)
     # deferred GroupNorm parameter-gradient folds: a slot of partial sums per layer, table entries in backward order
@@ -881,7 +911,41 @@ class Graph:
         if isinstance(op, Conv):
           op.plan_planes(self, lib)
       self._plan_f32_copies(lib)
+    self._plan_shared_dy(lib)
+    for op in reversed(self.ops):
+      op.plan_backward()
     return self
+
+  def _plan_shared_dy(self, lib):
+    """ResnetBlockBigGANpp with a shortcut convolution: out = (Conv_2(x) + Conv_1(h)) / sqrt 2 (layerspp.py:283-287) is
+    planned as Conv_1 with res = Conv_2's output.  That output has one reader, so its gradient is just dy(Conv_1) /
+    out_div: instead of writing it (one pass), measuring it (another) and summing it for Conv_2's bias (a third), Conv_1's
+    own pass over dy serves both layers and Conv_2 differentiates from dy(Conv_1) directly."""
+    if os.environ.get('STK_SHARED_DY', '1') == '0' or not hasattr(lib, 'bias_grad_amax_dual_f32'):
+      return
+    readers = {}
+    for op in self.ops:
+      for v in vars(op).values():
+        if isinstance(v, Tensor) and v.space == 'act' and v.producer is not op:
+          readers.setdefault(id(v), []).append(op)
+    for op in self.ops:
+      if not isinstance(op, Conv) or op.res is None or not op.res.needs_grad:
+        continue
+      r = op.res
+      P = r.producer
+      if not isinstance(P, Conv) or P is op or r is self.output or readers.get(id(r), []) != [op]:
+        continue
+      if r is op.x1 or r is op.x2 or op.temb is r:
+        continue
+      # the consumer must take the one-pass bias / record path (maps below 64 x 64, <= 256 channels, a bias to sum),
+      # and the shortcut must have nothing in its own backward that the pass cannot provide
+      if not ((op.pl_dgrad or op.pl_wgrad) and op.Cout <= 256 and op.OH * op.OW < 4096 and op.bias is not None):
+        continue
+      if P.temb is not None or P.res is not None or P.bias is None or P.dy_from is not None or P.dy_peer is not None:
+        continue
+      if P.pl_dgrad or P.pl_wgrad or P.Cout != op.Cout:
+        continue
+      op.dy_peer, P.dy_from = P, op
 
   def _plan_f32_copies(self, lib):
     """For every GroupNorm output that is made as planes: who still reads its fp32 NCHW copy?  A convolution whose

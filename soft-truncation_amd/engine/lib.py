@@ -43,6 +43,7 @@ SIGNATURES = {
   'stk_conv2d_wprep_batch': [P, I, L, S],
   'stk_conv2d_fwd_wp_f32': [P, I, P, I, P, I, P, P, I, P, F, P, I, I, I, I, I, I, I, I, I, I, P, P, P, L, S],
   'stk_conv2d_dgrad_wp_f32': [P, P, I, P, I, F, P, I, F, F, I, I, I, I, I, I, I, I, I, I, P, P, P, L, S],
+  'stk_conv2d_dgrad_rec_f32': [P, P, I, P, I, F, P, I, F, F, I, I, I, I, I, I, I, I, I, I, P, P, P, L, S],
   'stk_conv2d_wgrad_ws_bytes': [I, I, I, I, I, I, I, I],
   'stk_conv2d_wgrad_f32': [P, I, P, I, P, P, I, F, P, L, I, I, I, I, I, I, I, I, I, I, S],
   'stk_conv2d_wgrad_amax_f32': [P, I, P, I, P, P, I, F, P, L, I, I, I, I, I, I, I, I, I, I, P, I, S],
@@ -61,6 +62,7 @@ SIGNATURES = {
   'stk_bias_grad_f32': [P, I, I, I, F, P, I, P, P, S],
   'stk_bias_grad_amax_f32': [P, I, I, I, F, P, I, P, P, P, S],
   'stk_bias_grad_amax_res_f32': [P, I, I, I, F, P, I, P, P, P, F, P, S],
+  'stk_bias_grad_amax_dual_f32': [P, I, I, I, F, P, I, P, P, P, P, P, S],
   'stk_gemm_f32': [P, L, L, L, P, L, L, L, P, L, L, L, P, I, I, I, I, I, F, F, S],
   'stk_softmax_fwd_f32': [P, P, L, I, F, S],
   'stk_softmax_bwd_f32': [P, P, P, L, I, F, S],

@@ -192,3 +192,32 @@ def test_qkv_projection_is_planned_stacked(st, ref_lib):
   sd = model.state_dict()
   key = next(k for k in sd if k.endswith('NIN_1.W'))
   assert sd[key].shape == blk.NIN_1.W.shape
+
+
+def test_shortcut_convolution_shares_the_block_output_gradient(st, ref_lib, monkeypatch):
+  """A ResnetBlock with a shortcut convolution is planned so that Conv_2 (1x1 on the block input) differentiates from
+  Conv_1's output gradient directly (engine/graph.py Graph._plan_shared_dy): d(Conv_2 out) = dy / sqrt 2 is never
+  written, measured or summed on its own.  Same gradients as the plain plan (STK_SHARED_DY=0) and as RefNet."""
+  import torch
+  from importlib import import_module
+  G = import_module('soft-truncation_amd.engine.graph')
+  cases.forward_backward(st, ref_lib, 'wide', B=2)                       # against RefNet, with the shared plan
+  cfg, cfg_cpu, sde, model, ref = cases.build_pair(st, cases.tiny_config(st, 'wide'), ref_lib)
+  x, t = torch.randn(2, 3, 16, 16), torch.rand(2) * 999
+  model(x, t).square().sum().backward()
+  convs = [op for pr in model.module.engine().programs.values() for op in pr.graph.ops if isinstance(op, G.Conv)]
+  pairs = [(op, op.dy_peer) for op in convs if op.dy_peer is not None]
+  assert pairs and all(p.dy_from is c and p.KH == 1 and c.KH == 3 for c, p in pairs)
+  shared = [p.grad.clone() for p in model.parameters()]
+  monkeypatch.setenv('STK_SHARED_DY', '0')
+  model.module.engine().programs.clear()
+  for p in model.parameters():
+    p.grad.zero_()
+  model(x, t).square().sum().backward()
+  convs = [op for pr in model.module.engine().programs.values() for op in pr.graph.ops if isinstance(op, G.Conv)]
+  assert all(op.dy_peer is None and op.dy_from is None for op in convs)
+  # (per-tensor scale with a floor: some gradients are zero in exact arithmetic -- the key bias of attention -- and hold
+  # only round-off)
+  top = max(p.grad.abs().max().item() for p in model.parameters())
+  for a, p in zip(shared, model.parameters()):
+    assert (a - p.grad).abs().max().item() <= 1e-5 * max(p.grad.abs().max().item(), 1e-4 * top)
