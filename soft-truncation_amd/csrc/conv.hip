@@ -908,6 +908,10 @@ inline long x3_ws_bytes(const X3Plan& r, int M, int Kc, int taps) {
 // false = bf16 three-way split (conv_x3.h, 6).  The weight gradient stays on the bf16 kernels of conv_x3.h.
 constexpr bool SPLIT_FWD_DGRAD_X2 = true;
 constexpr bool SPLIT_WGRAD3_X2 = true;      // the three-taps-per-workgroup 3x3 weight gradient on the fp16 split too
+// The per-tap weight gradients (1x1 layers, 3x3 on 4-wide maps) on the fp16 two-way split as well (x2::wgemm_kernel);
+// STK_WGRAD1_X2=0 keeps them on the bf16 three-way split (debugging / A-B switch, read once).
+inline bool wgrad1_x2() { static const bool v = [] { const char* e = getenv("STK_WGRAD1_X2"); return !e || atoi(e) != 0; }(); return v; }
+inline bool wgrad1_pin() { static const bool v = [] { const char* e = getenv("STK_W1_PIN"); return !e || atoi(e) != 0; }(); return v; }
 
 inline void x3_weight_strides(const ConvP& p, int dgrad, long& sm, long& sk) {
   if (p.w_layout == 0) { sm = dgrad ? p.taps : (long)p.Cin * p.taps; sk = dgrad ? (long)p.Cin * p.taps : p.taps; }
@@ -1077,7 +1081,8 @@ inline X3WgradPlan x3_wgrad_plan(int C1, int C2, int N, int Cout, int H, int W, 
   // 255; 128->256 at 16x16, 2 tiles: 32 against 41); with 512 workgroups it did not
   if (taps == 1 && tiles < 2) return q;
   const long chunks = K / 32;
-  long splits = (taps == 1 && tiles < 6 ? 256 : 512) / tiles;
+  static const long w1_wgs = [] { const char* e = getenv("STK_W1_WGS"); return e ? atol(e) : 256L; }();
+  long splits = (taps == 1 && tiles < 6 ? w1_wgs : 512) / tiles;
   if (splits > chunks / 8) splits = chunks / 8;
   if (splits < 1) splits = 1;
   q.chunks_per_split = (int)((chunks + splits - 1) / splits);
@@ -1375,7 +1380,8 @@ int stk_conv2d_wgrad_pl_f32(const void* xpl, const float* xrec, const void* dypl
   const dim3 grid((unsigned)(a.tiles_co * a.tiles_ci * q.splits));
   if (W >= 32) hipLaunchKernelGGL((x2w::wgrad_kernel<32>), grid, dim3(256), 0, s, a);
   else if (W == 16) hipLaunchKernelGGL((x2w::wgrad_kernel<16>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((x2w::wgrad_kernel<8>), grid, dim3(256), 0, s, a);
+  else if (W == 8) hipLaunchKernelGGL((x2w::wgrad_kernel<8>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((x2w::wgrad_kernel<4>), grid, dim3(256), 0, s, a);
   STK_CHECK_LAUNCH();
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((q.slab + 3) / 4)), dim3(256), 0, s, ws, dw, q.slab, q.splits,
                      q.slab, alpha, 0, Cout, Cin, 9);
@@ -1406,7 +1412,7 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
   if (thin::geometry_ok(p) && ((C2 == 0 && Cin <= 4) || Cout <= 4)) return 4;
   {
     const X3WgradPlan xq = x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad);
-    if (xq.ok) return xq.rows3 && SPLIT_WGRAD3_X2 ? 5 : 2;
+    if (xq.ok) return (xq.rows3 ? SPLIT_WGRAD3_X2 : wgrad1_x2()) ? 5 : 2;
   }
   const bool can9 = stride == 1 && pad == 1 && C2 == 0 && OH == H && OW == W && w_layout == 0;
   const WgradPlan q = wgrad_plan(Cin, N, Cout, OH, OW, KH, KW, can9);
@@ -1554,7 +1560,44 @@ int stk_conv2d_wgrad_amax_f32(const float* x1, int C1, const float* x2, int C2, 
       return STK_OK;
     }
     const dim3 grid((unsigned)(p.taps * tm * tn * xq.splits));
-#define STK_X3_WGRAD(DUAL, SEG)                                                                                      \
+    if (wgrad1_x2() && ws_bytes >= (long)xq.splits * xq.slab * 4 + 256 + 3L * x2::NPART * 4) {
+      // fp16 two-way split of both operands (x2::wgemm_kernel): maxima as for the three-taps kernel above
+      float* parts = reinterpret_cast<float*>(((uintptr_t)(ws + (long)xq.splits * xq.slab) + 255) & ~(uintptr_t)255);
+      const dim3 ab(x2::NPART), at(x2::AMAX_THREADS);
+      const float* dyp = parts;
+      const float* xp = parts + x2::NPART;
+      if (amax && (have & 2)) dyp = amax + 2 * x2::NPART;
+      else hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, dy, (long)N * Cout * p.OHW, parts);
+      if (amax && (have & 1)) {
+        xp = amax;
+      } else {
+        hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, x1, (long)N * C1 * p.HW, parts + x2::NPART);
+        if (C2 > 0) hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, x2, (long)N * C2 * p.HW, parts + 2 * x2::NPART);
+      }
+      const int nx = C2 > 0 ? 2 * x2::NPART : x2::NPART;
+      const bool pin = wgrad1_pin();
+#define STK_X2_WGRAD1(BLOADER)                                                                                              \
+  do {                                                                                                                      \
+    using AL_ = x2::RowsU<false, false>;                                                                                    \
+    if (pin) hipLaunchKernelGGL((x2::wgemm_kernel<AL_, BLOADER, EpWgrad, true>), grid, dim3(256), 0, s, p, Cout, p.Cin,      \
+                                tm, tn, nch, xq.chunks_per_split, p.taps, dyp, xp, nx);                                     \
+    else hipLaunchKernelGGL((x2::wgemm_kernel<AL_, BLOADER, EpWgrad, false>), grid, dim3(256), 0, s, p, Cout, p.Cin,         \
+                            tm, tn, nch, xq.chunks_per_split, p.taps, dyp, xp, nx);                                         \
+  } while (0)
+#define STK_COMMA ,
+      if (p.taps == 1) { if (C2 > 0) STK_X2_WGRAD1(x2::RowsU<true STK_COMMA true>); else STK_X2_WGRAD1(x2::RowsU<true STK_COMMA false>); }
+      else if (W >= 16) { if (C2 > 0) STK_X2_WGRAD1(x2::RowsB<true STK_COMMA 16>); else STK_X2_WGRAD1(x2::RowsB<false STK_COMMA 16>); }
+      else if (W == 8) { if (C2 > 0) STK_X2_WGRAD1(x2::RowsB<true STK_COMMA 8>); else STK_X2_WGRAD1(x2::RowsB<false STK_COMMA 8>); }
+      else { if (C2 > 0) STK_X2_WGRAD1(x2::RowsB<true STK_COMMA 4>); else STK_X2_WGRAD1(x2::RowsB<false STK_COMMA 4>); }
+#undef STK_COMMA
+#undef STK_X2_WGRAD1
+      STK_CHECK_LAUNCH();
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((xq.slab + 3) / 4)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
+                         xq.slab, alpha, w_layout, Cout, p.Cin, p.taps);
+      STK_CHECK_LAUNCH();
+      return STK_OK;
+    }
+#define STK_X3_WGRAD(DUAL, SEG)                                                                                     \
   hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false, SEG>, x3::RowsLoader<true, DUAL, SEG>, EpWgrad, false>), \
                      grid, dim3(256), 0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, p.taps)
     if (W >= 16) { if (C2 > 0) STK_X3_WGRAD(true, 16); else STK_X3_WGRAD(false, 16); }

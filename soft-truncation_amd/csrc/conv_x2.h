@@ -473,4 +473,178 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(ConvP p, int tiles_m, int t
   }
 }
 
+// ---- per-tap weight gradient (1x1 layers, 3x3 on 4-wide maps) on the two-way split --------------------------------------
+// x3::gemm_kernel<RowsLoader, RowsLoader, EpWgrad> with both operands scaled and split into two fp16 terms: 12 instead
+// of 24 MFMAs per 16-k step and ~6 instead of ~10 conversion VALU per element.  With half the MFMAs the conversions no
+// longer hide behind the second half-chunk alone, so a chunk's work is laid out over both halves: the split of chunk
+// c + 1 (registers only) and the load issue of chunk c + 2 ride on the MFMAs of kk = 0, the eight LDS stores on those of
+// kk = 1 (after the barrier that retires the reads of chunk c).
+template <bool DUAL, int SEG>
+struct RowsB : x3::RowsLoader<true, DUAL, SEG> {           // x: 16 consecutive (tap-shifted) pixels of one input channel
+  using B = x3::RowsLoader<true, DUAL, SEG>;
+  Split16 sp2; float scale;
+  __device__ __forceinline__ void st(int g, unsigned char* t) { sp2.st(g, B::r, scale, t, B::row, B::half * 16, B::okm); }
+};
+
+// Unshifted rows (dy always; x of a 1x1 layer): the thread's 16 consecutive pixels are one aligned 64-byte run, read as
+// four 16-byte loads.  (x3::RowsLoader reads a run element by element because a tap shift breaks the alignment and needs
+// a per-element mask; with 32 such loads per thread and chunk, each touching 64 separate 64-byte segments, the per-tap
+// kernel was bound by address processing: 54 us for the 256 -> 256 layer at 16 x 16 against ~6 us of MFMAs.)
+template <bool IS_X, bool DUAL>
+struct RowsU {
+  __amdgpu_buffer_rsrc_t rs;
+  int rowoff, bstride, row, half; bool rowok; unsigned voff;
+  float r[16]; Split16 sp2; float scale;
+  __device__ __forceinline__ void init(const ConvP& p, const x3::Src&, int o0, int tid, int) {
+    row = tid >> 1; half = tid & 1; voff = 0x80000000u;
+    const int ch = o0 + row;
+    if (IS_X) {
+      rowok = ch < p.Cin;
+      const int c = rowok ? ch : 0;
+      const bool first = !DUAL || __builtin_amdgcn_readfirstlane(o0 + (tid >> 6) * 32) < p.C1;   // wave-uniform
+      rs = first ? x3::make_rsrc(p.x1, (long)p.N * p.C1 * p.HW * 4) : x3::make_rsrc(p.x2, (long)p.N * p.C2 * p.HW * 4);
+      rowoff = (first ? c : (c >= p.C1 ? c - p.C1 : 0)) * p.HW;
+      bstride = (first ? p.C1 : p.C2) * p.HW;
+    } else {
+      rowok = ch < p.Cout;
+      rs = x3::make_rsrc(p.dy, (long)p.N * p.Cout * p.HW * 4);
+      rowoff = (rowok ? ch : 0) * p.HW;
+      bstride = p.Cout * p.HW;
+    }
+  }
+  // slice 14: the run's byte offset (bit 31 = outside: the loads return 0); slices 15..18: one 16-byte load each
+  __device__ __forceinline__ void ld(int g, const ConvP& p, const x3::Src&, int c) {
+    if (g == 14) {
+      const int k = c * KC + half * 16;
+      const bool kin = rowok && k < p.N * p.HW;
+      const int b = k >> p.ohw_shift, hw = k & (p.HW - 1);
+      voff = kin ? (unsigned)((b * bstride + rowoff + hw) * 4) : 0x80000000u;
+    } else if (g >= 15 && g < 19) {
+      const int j = g - 15;
+      const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, j * 16, 0));
+      r[4 * j] = __uint_as_float(v[0]); r[4 * j + 1] = __uint_as_float(v[1]);
+      r[4 * j + 2] = __uint_as_float(v[2]); r[4 * j + 3] = __uint_as_float(v[3]);
+    }
+  }
+  __device__ __forceinline__ void st(int g, unsigned char* t) { sp2.st(g, r, scale, t, row, half * 16); }
+};
+
+template <class AL, class BL, class EP, bool PIN>
+__global__ __launch_bounds__(256) void wgemm_kernel(ConvP p, int M, int Nn, int tiles_m, int tiles_n, int nchunks_total,
+                                                    int chunks_per_split, int taps_z, const float* __restrict__ dypart,
+                                                    const float* __restrict__ xpart, int nxpart) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  unsigned char* As = lds;
+  unsigned char* Bs = lds + OPER;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const float sa = pow2_scale_of(block_amax(dypart, NPART, reinterpret_cast<float*>(lds)));
+  const float sb = pow2_scale_of(block_amax(xpart, nxpart, reinterpret_cast<float*>(lds)));
+  const float unscale = 1.f / (sa * sb);
+  const int ntiles = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int zb = id % taps_z;
+  const int rest = id / taps_z;
+  const int tile = rest % ntiles;
+  const int zs = rest / ntiles;
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int c_begin = zs * chunks_per_split;
+  const int c_last = min(nchunks_total, c_begin + chunks_per_split) - 1;
+
+  x3::Src q = {};
+  AL al; BL bl;
+  al.init(p, q, m0, tid, 4); al.scale = sa;
+  bl.init(p, q, n0, tid, taps_z == 1 ? 4 : zb); bl.scale = sb;
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 64;
+  const int fk = lane >> 5, fc = lane & 31;
+  const unsigned char* a_rd = As + (wm0 + fc) * PITCH + fk * 16;
+  const unsigned char* b_rd = Bs + (wn0 + fc) * PITCH + fk * 16;
+
+#define STK_W1_FRAGS(KK)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s = 0; s < 2; ++s) {         \
+    a[i][s] = *reinterpret_cast<const halfx8*>(a_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);          \
+    b[i][s] = *reinterpret_cast<const halfx8*>(b_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);          \
+  }
+  constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};
+#define STK_W1_MFMA(G)                                                                                              \
+  acc[((G) >> 1) & 1][(G) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[((G) >> 1) & 1][SA[(G) >> 2]], b[(G) & 1][SB[(G) >> 2]], \
+                                                                        acc[((G) >> 1) & 1][(G) & 1], 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 24; ++g) { al.ld(g, p, q, c_begin); bl.ld(g, p, q, c_begin); }
+#pragma unroll
+  for (int g = 0; g < 12; ++g) { al.st(g, As); bl.st(g, Bs); }
+  {
+    const int c1 = min(c_begin + 1, c_last);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) { al.ld(g, p, q, c1); bl.ld(g, p, q, c1); }
+  }
+  halfx8 a[2][2], b[2][2];
+  for (int c = c_begin; c < c_last; ++c) {
+    __syncthreads();                                   // chunk c is in LDS
+    STK_W1_FRAGS(0)
+#pragma unroll
+    for (int g = 0; g < 12; ++g) { STK_W1_MFMA(g) }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { al.st(g, As); bl.st(g, Bs); }            // split of chunk c + 1: registers only
+    const int c2 = min(c + 2, c_last);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) { al.ld(g, p, q, c2); bl.ld(g, p, q, c2); }   // chunk c + 2: global -> registers
+    if (PIN) {
+#pragma unroll
+      for (int g = 0; g < 12; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);    // VALU
+        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);     // VMEM read
+      }
+    }
+    STK_W1_FRAGS(1)
+    __syncthreads();                                   // nobody reads chunk c any more
+#pragma unroll
+    for (int g = 0; g < 12; ++g) { STK_W1_MFMA(g) }
+#pragma unroll
+    for (int g = 8; g < 12; ++g) { al.st(g, As); bl.st(g, Bs); }           // chunk c + 1 -> LDS
+    if (PIN) {
+#pragma unroll
+      for (int g = 0; g < 12; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (g >= 2 && g < 10) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+      }
+    }
+  }
+  __syncthreads();
+  STK_W1_FRAGS(0)
+#pragma unroll
+  for (int g = 0; g < 12; ++g) { STK_W1_MFMA(g) }
+  STK_W1_FRAGS(1)
+#pragma unroll
+  for (int g = 0; g < 12; ++g) { STK_W1_MFMA(g) }
+#undef STK_W1_MFMA
+#undef STK_W1_FRAGS
+
+  EP ep;
+  ep.init(p, zb, zs);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn0 + j * 32 + fc;
+    const bool nok = n < Nn;
+    ep.col(p, nok ? n : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] *= unscale;
+      ep.strip(p, m0 + wm0 + i * 32 + 4 * fk, M, nok, nok ? n : 0, acc[i][j]);
+    }
+  }
+}
+
 }  // namespace x2

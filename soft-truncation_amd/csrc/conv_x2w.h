@@ -51,7 +51,9 @@ __device__ __forceinline__ halfx8 cat(s4 lo, s4 hi) {
 // 32-pixel piece of one row when W > 32)
 template <int COLS>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(Args a) {
-  constexpr int ROWS = 32 / COLS, TP = COLS + 2, TR = ROWS + 2;
+  // COLS = 4 (4 x 4 maps): a chunk is TWO whole images, each with its own 6 x 6 halo tile (slot = 36 img + 6 ty + tx)
+  constexpr bool TWO = COLS == 4;
+  constexpr int ROWS = 32 / COLS, TP = COLS + 2, TR = TWO ? 12 : ROWS + 2;
   static_assert(TR * TP <= B_INSTR * 16, "halo tile exceeds the staged slots");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,6 +75,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(Args a) {
   const unsigned piece = (unsigned)(lane & 3) * 16u;
   // dy: wave w stages block co_blk: (half, plane) -> 16 pixels x 64 bytes, contiguous in the planes
   const unsigned a_voff = (co_live ? 0u : 0x80000000u) | ((unsigned)(lane >> 2) * 64u + piece);
+  // second half of the chunk (pixels 16..31): the next 16 pixels of the block, or -- 4 x 4 maps -- the next IMAGE's block
+  const unsigned a_half = TWO ? (unsigned)a.Cob * (unsigned)a.HW * 64u : 1024u;
   // x halo tile: slot s = 16 j + lane / 4 holds tile pixel (ty, tx) = (s / TP, s % TP) = map pixel (y0 - 1 + ty, x0 - 1 + tx);
   // wave w issues instructions j = w and w + 4
   int b_rel[2], b_ty[2], b_tx[2];
@@ -80,8 +84,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(Args a) {
   for (int u = 0; u < 2; ++u) {
     const int j = wid + 4 * u, s = 16 * j + (lane >> 2);
     b_ty[u] = s / TP; b_tx[u] = s - b_ty[u] * TP;
+    int img = 0;
+    if (TWO) { img = b_ty[u] / 6; b_ty[u] -= 6 * img; }                 // row inside its image's tile
     if (j >= B_INSTR || s >= TR * TP) b_ty[u] = -1000000;               // never inside the map
-    b_rel[u] = ((b_ty[u] - 1) * a.W + (b_tx[u] - 1)) * 64 + (int)piece;
+    b_rel[u] = (img * a.Cib * a.HW + (b_ty[u] - 1) * a.W + (b_tx[u] - 1)) * 64 + (int)piece;   // next image: Cib blocks on
   }
   auto stage = [&](int c, unsigned char* buf) {
     const int p0 = c * 32;                                               // first pixel of the chunk, over N * HW
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(Args a) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(buf + s * A_PLANE + wid * A_BLK + h * 1024), 16,
-                                                 (int)(a_voff + h * 1024u), (int)(a_soff + s * (unsigned)a.dy_ps), 0, 0);
+                                                 (int)(a_voff + h * a_half), (int)(a_soff + s * (unsigned)a.dy_ps), 0, 0);
     const int b_chunk = ((b * a.Cib + tci) * a.HW + hw0) * 64;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -126,7 +132,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(Args a) {
       const int k = 16 * kk + 8 * (g >> 1) + 4 * h + (m >> 2);           // pixel of the chunk this lane addresses
       a_off[kk][h] = wid * A_BLK + k * 64 + ch_off;
       const int krow = k / COLS, kcol = k - krow * COLS;
-      b_off[kk][h] = 2 * A_PLANE + ((krow + 1) * TP + kcol + 1) * 64 + ch_off;      // tap (0, 0) of that pixel in the halo tile
+      const int trow = TWO ? (krow >> 2) * 6 + (krow & 3) : krow;        // two images: rows 0..3 | 4..7 -> tiles 0 | 1
+      b_off[kk][h] = 2 * A_PLANE + ((trow + 1) * TP + kcol + 1) * 64 + ch_off;      // tap (0, 0) of that pixel in the halo tile
     }
   constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};                    // cross terms first (fixed accumulation order)
 
@@ -183,12 +190,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(Args a) {
   }
 }
 
-// H = W a power of two >= 8 (a chunk of 32 pixels is whole rows or a piece of one row, never across images), channel
-// counts in whole 32-blocks (planes), enough work to fill the chip
+// H = W a power of two >= 8 (a chunk of 32 pixels is whole rows or a piece of one row, never across images) or H = W = 4
+// (a chunk is two whole images), channel counts in whole 32-blocks (planes), enough work to fill the chip
 struct Plan { int ok; int splits; int chunks_per_split; long slab; };
 inline Plan plan(int N, int H, int W, int Cin, int Cout) {
   Plan r = {0, 1, 0, 0};
-  if (H != W || W < 8 || (W & (W - 1)) || Cin % 32 || Cout % 32 || Cin < 32 || Cout < 32) return r;
+  if (H != W || W < 4 || (W & (W - 1)) || Cin % 32 || Cout % 32 || Cin < 32 || Cout < 32) return r;
   const long px = (long)N * H * W;
   if (px % 32 || px / 32 > 0x7fffffffL / 64) return r;
   const int nch = (int)(px / 32);

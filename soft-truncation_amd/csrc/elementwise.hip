@@ -106,6 +106,15 @@ struct Affine {
     v.store(out, i);
   }
 };
+struct Fill {
+  float v; float* out;
+  template <int V> __device__ void run(long i) const {
+    Vec<V> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.v[j] = v;
+    o.store(out, i);
+  }
+};
 struct BiasAct {   // op/fused_bias_act_kernel.cu:25-47
   const float* x; const float* b; const float* ref; float* out;
   int step_b, size_b, code; float alpha, scale;
@@ -301,6 +310,11 @@ int stk_add_div_f32(const float* a, const float* b, float div, float* out, long 
 int stk_affine_f32(const float* x, float a, float b, float* out, long n, void* stream) {
   if (!x || !out || n < 0) return STK_EINVAL;
   return launch_ew(n, stk_aligned16(x) && stk_aligned16(out), Affine{x, a, b, out}, S(stream));
+}
+
+int stk_fill_f32(float* out, float v, long n, void* stream) {
+  if (!out || n < 0) return STK_EINVAL;
+  return launch_ew(n, stk_aligned16(out), Fill{v, out}, S(stream));
 }
 
 int stk_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* out, long size_x,

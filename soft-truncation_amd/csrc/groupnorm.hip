@@ -32,6 +32,11 @@ struct GnArgs {
   unsigned long long seed; const unsigned long long* seed_dev;
 };
 
+// optional by-products of the flat backward kernel (stk_gn_bwd_out_f32); all NULL = none
+struct GnBwdOut {
+  float* sum; float* temb; int temb_stride; float scale; float* amax;
+};
+
 // Segment decomposition of group (n, g): channels [c0, c1) -> part in x1, part in x2.
 struct Seg {
   const float* p; int len; int c_first;   // len in floats, first channel index (global)
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
                                                           const float* __restrict__ mean_in,
                                                           const float* __restrict__ rstd_in, float* __restrict__ dx1,
                                                           float beta1, float* __restrict__ dx2, float beta2,
-                                                          float* __restrict__ ws, int hw_log2) {
+                                                          float* __restrict__ ws, int hw_log2, GnBwdOut out) {
   __shared__ float s_part[2048], s_ch[1024];
   const int T = blockDim.x;
   const int ng = blockIdx.x;
@@ -389,23 +394,51 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
   const float inv_l = 1.f / ((float)a.cpg * (float)a.HW);
   const float m1 = g0 * inv_l, m2 = g1 * inv_l;
 
+  // `out` (stk_gn_bwd_out_f32, single-source layers): what the consumer of dx1 -- the backward of the convolution that
+  // produced x1 -- would otherwise take one more pass over dx1 for: per-(sample, channel) sums of the FINAL dx1 values
+  // (bias / time-embedding gradients) and max |dx1| (scale record of its planes).  Block-uniform branches only.
+  const bool want = out.sum || out.temb || out.amax;
+  float amax_l = 0.f;
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
     const int i = threadIdx.x + T * k;
-    if (i >= L4) continue;
-    const int c = c0 + ((4 * i) >> hw_log2), off = (4 * i) & (a.HW - 1);
+    const bool valid = i < L4;
+    const int e = valid ? 4 * i : 0;
+    const int c = c0 + (e >> hw_log2), off = e & (a.HW - 1);
     float* op; float ob;
     if (c < a.C1) { op = dx1 ? dx1 + (((long)n * a.C1 + c) << hw_log2) + off : nullptr; ob = beta1; }
     else { op = dx2 ? dx2 + (((long)n * a.C2 + (c - a.C1)) << hw_log2) + off : nullptr; ob = beta2; }
-    if (!op) continue;
-    float r[4];
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid && op) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = rstd * (du[k][j] * gam[k] - m1 - xh[k][j] * m2);
-    if (ob != 0.f) {
-      const float4 old = *reinterpret_cast<const float4*>(op);
-      r[0] += ob * old.x; r[1] += ob * old.y; r[2] += ob * old.z; r[3] += ob * old.w;
+      for (int j = 0; j < 4; ++j) r[j] = rstd * (du[k][j] * gam[k] - m1 - xh[k][j] * m2);
+      if (ob != 0.f) {
+        const float4 old = *reinterpret_cast<const float4*>(op);
+        r[0] += ob * old.x; r[1] += ob * old.y; r[2] += ob * old.z; r[3] += ob * old.w;
+      }
+      *reinterpret_cast<float4*>(op) = make_float4(r[0], r[1], r[2], r[3]);
     }
-    *reinterpret_cast<float4*>(op) = make_float4(r[0], r[1], r[2], r[3]);
+    if (want) {
+      float rs = (r[0] + r[1]) + (r[2] + r[3]);
+      amax_l = fmaxf(amax_l, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
+      for (int o = 0; o < seglog; ++o) rs += __shfl_xor(rs, 1 << o);
+      if (valid && (lane & ((1 << seglog) - 1)) == 0) s_part[i >> seglog] = rs;     // s_part is free after the barrier above
+    }
+  }
+  if (want) {
+    __syncthreads();
+    for (int cl = threadIdx.x; cl < a.cpg; cl += T) {
+      float t = 0.f;
+      for (int q = 0; q < spc; ++q) t += s_part[cl * spc + q];
+      t *= out.scale;
+      if (out.sum) { out.sum[((long)n * C + c0 + cl) * 2] = t; out.sum[((long)n * C + c0 + cl) * 2 + 1] = 0.f; }
+      if (out.temb) out.temb[(long)n * out.temb_stride + c0 + cl] = t;
+    }
+    if (out.amax) {
+      // non-negative floats order like their bit patterns: an integer max is exact and order-independent
+      const float m = wave_max(amax_l);
+      if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(out.amax) + ((blockIdx.x + (threadIdx.x >> 6)) & 255), __float_as_uint(m));
+    }
   }
 }
 
@@ -855,13 +888,18 @@ int stk_gn_fwd_pl_f32(const float* x1, int C1, const float* x2, int C2, const fl
     a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
     a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p); a.drop_thr = stk_drop_threshold(drop_p);
     a.seed = seed; a.seed_dev = seed_dev;
-    const int items = HW * 4, T = items < 1024 ? items : 1024, passes = items / T;
+    // HW = 1024: two workgroups of 512 threads per CU instead of one of 1024 (STK_GN_PL_T, default 512): the same 16
+    // waves per CU, but the load phase of one block overlaps the arithmetic / store phase of the other
+    static const int tmax = [] { const char* e = getenv("STK_GN_PL_T"); const int v = e ? atoi(e) : 512; return v == 512 ? v : 1024; }();
+    int T = HW * 4 < 1024 ? HW * 4 : 1024;
+    if (HW * 4 > 1024 && tmax < T) T = tmax;
+    const int items = HW * 4, passes = items / T;
     const float sq = sqrtf((float)((long)a.cpg * HW) - 1.f);
     const dim3 grid((unsigned)(N * (C / 32)));
 #define STK_GN_PL(P)                                                                                               \
   hipLaunchKernelGGL((gn_fwd_pl_kernel<P>), grid, dim3(T), 0, (hipStream_t)stream, a, y, static_cast<unsigned char*>(planes), \
                      plane_stride, rec, mean, rstd, eps, sq)
-    if (passes == 1) STK_GN_PL(1); else if (passes == 2) STK_GN_PL(2); else STK_GN_PL(4);
+    if (passes == 1) STK_GN_PL(1); else if (passes == 2) STK_GN_PL(2); else if (passes == 4) STK_GN_PL(4); else if (passes == 8) STK_GN_PL(8); else return STK_EUNSUPPORTED;
 #undef STK_GN_PL
     STK_CHECK_LAUNCH();
     return STK_OK;
@@ -877,10 +915,43 @@ int stk_gn_fwd_pl_f32(const float* x1, int C1, const float* x2, int C2, const fl
 /* 1 if stk_gn_fwd_pl_f32 takes this shape in one pass (and therefore accepts y = NULL) */
 int stk_gn_fwd_pl_fused(int C1, int C2, int HW, int G) { return gn_pl_fused_ok(C1, C2, HW, G) ? 1 : 0; }
 
+/* shapes whose backward runs on the register-resident kernel and can therefore leave the by-products behind */
+static inline bool gn_bwd_flat_shape(int C, int HW, int G) {
+  if (C <= 0 || G <= 0 || C % G || HW < 16 || (HW & (HW - 1))) return false;
+  const long L = (long)(C / G) * HW;
+  return L <= 16384 && C / G <= 512 && !gn_split_ok(HW, C / G);
+}
+int stk_gn_bwd_out_ok(int C1, int C2, int HW, int G) { return C2 == 0 && gn_bwd_flat_shape(C1, HW, G) ? 1 : 0; }
+
+static int gn_bwd_impl(const float* dy, const float* x1, int C1, const float* x2, int C2, const float* gamma,
+                       const float* beta, const float* mean, const float* rstd, float* dx1, float dx1_beta, float* dx2,
+                       float dx2_beta, float* dgamma, float* dbeta, float* ws, int N, int HW, int G, int act, float drop_p,
+                       unsigned long long seed, const unsigned long long* seed_dev, void* stream, GnBwdOut out);
+
 int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, int C2, const float* gamma,
                    const float* beta, const float* mean, const float* rstd, float* dx1, float dx1_beta, float* dx2,
                    float dx2_beta, float* dgamma, float* dbeta, float* ws, int N, int HW, int G, int act, float drop_p,
                    unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
+  const GnBwdOut none = {nullptr, nullptr, 0, 1.f, nullptr};
+  return gn_bwd_impl(dy, x1, C1, x2, C2, gamma, beta, mean, rstd, dx1, dx1_beta, dx2, dx2_beta, dgamma, dbeta, ws, N, HW, G, act,
+                     drop_p, seed, seed_dev, stream, none);
+}
+
+int stk_gn_bwd_out_f32(const float* dy, const float* x1, int C1, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, float* dx1, float dx1_beta, float* dgamma, float* dbeta, float* ws, int N, int HW,
+                       int G, int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+                       float* dx_sum, float out_scale, float* dtemb, int temb_stride, float* dx_amax, void* stream) {
+  if (!dx1 || !stk_gn_bwd_out_ok(C1, 0, HW, G) || (dtemb && temb_stride < C1)) return STK_EINVAL;
+  if (!(stk_aligned16(x1) && stk_aligned16(dy) && stk_aligned16(dx1))) return STK_EUNSUPPORTED;
+  const GnBwdOut out = {dx_sum, dtemb, temb_stride, out_scale, dx_amax};
+  return gn_bwd_impl(dy, x1, C1, nullptr, 0, gamma, beta, mean, rstd, dx1, dx1_beta, nullptr, 0.f, dgamma, dbeta, ws, N, HW, G,
+                     act, drop_p, seed, seed_dev, stream, out);
+}
+
+static int gn_bwd_impl(const float* dy, const float* x1, int C1, const float* x2, int C2, const float* gamma,
+                       const float* beta, const float* mean, const float* rstd, float* dx1, float dx1_beta, float* dx2,
+                       float dx2_beta, float* dgamma, float* dbeta, float* ws, int N, int HW, int G, int act, float drop_p,
+                       unsigned long long seed, const unsigned long long* seed_dev, void* stream, GnBwdOut out) {
   const int C = C1 + C2;
   if (!dy || !x1 || !gamma || !beta || !mean || !rstd || !ws || N <= 0 || HW <= 0 || G <= 0 || C1 <= 0 || C2 < 0 ||
       C % G || (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f)
@@ -913,7 +984,7 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
     const int ipt = stk_cdiv(L4, T);
 #define STK_GN_FLAT(IPT)                                                                                          \
   hipLaunchKernelGGL((gn_bwd_flat_kernel<IPT>), dim3(N * G), dim3(T), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, \
-                     dx1_beta, dx2, dx2_beta, ws, hw_log2)
+                     dx1_beta, dx2, dx2_beta, ws, hw_log2, out)
     if (ipt <= 1) STK_GN_FLAT(1);
     else if (ipt <= 2) STK_GN_FLAT(2);
     else if (ipt <= 3) STK_GN_FLAT(3);

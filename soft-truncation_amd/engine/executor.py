@@ -107,12 +107,12 @@ class Program:
     self.gnpart = _arena(g.gnpart_size, self.device)
     base = self.gnpart.data_ptr()
     descs = []
-    for op in g.gn_folds:
+    for part_off, dgamma_off, dbeta_off, n, ch in g.gn_folds:
       d = _GnFoldDesc()
-      d.part = base + 4 * op.fold_off
-      d.dgamma = gparam_base + 4 * op.gamma.goff if op.gamma.needs_grad else None
-      d.dbeta = gparam_base + 4 * op.beta_t.goff if op.beta_t.needs_grad else None
-      d.N, d.C = op.N, op.C1 + op.C2
+      d.part = base + 4 * part_off
+      d.dgamma = gparam_base + 4 * dgamma_off if dgamma_off is not None else None
+      d.dbeta = gparam_base + 4 * dbeta_off if dbeta_off is not None else None
+      d.N, d.C = n, ch
       self.gn_maxc = max(self.gn_maxc, d.C)
       descs.append(d)
     assert ctypes.sizeof(_GnFoldDesc) == 32

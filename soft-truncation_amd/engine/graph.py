@@ -180,6 +180,10 @@ class GroupNormAct(Op):
     self.fused = False        # the library's one-pass GroupNorm -> planes kernel takes this shape (Graph.finalize)
     self.fold_off = None      # float offset of this layer's [N][C][2] partial sums in the program's arena (Graph.finalize)
     self.fold_index = None    # its entry in the fold table (backward order)
+    # Graph._plan_dy_producers: the convolution whose output this layer normalises and nobody else reads.  Its output
+    # gradient IS this layer's dx1, so the backward kernel leaves the bias / time-embedding sums and the |dy| scale
+    # record behind (stk_gn_bwd_out_f32) and the convolution's backward makes no pass of its own over dy.
+    self.dy_cons = None
 
   def _p(self, rt):
     return self.drop_p if rt.training else 0.0
@@ -202,11 +206,25 @@ class GroupNormAct(Op):
 
   def backward(self, rt):
     dgamma, dbeta, ws = rt.g(self.gamma), rt.g(self.beta_t), rt.ws
-    if rt.gn_table and self.fold_index is not None and (dgamma is not None or dbeta is not None):
+    cons = self.dy_cons
+    if rt.gn_table and self.fold_index is not None and (dgamma is not None or dbeta is not None or cons is not None):
       # leave the per-(sample, channel) sums in this layer's own slot; one launch folds a whole segment's layers
       dgamma = dbeta = None
       ws = rt.gnpart + 4 * self.fold_off
       rt.defer_fold(self.fold_index)
+    if cons is not None:
+      assert rt.gn_table and self.fold_index is not None, 'the by-products of the GroupNorm backward ride on the batched folds'
+      dsum = dtemb = None
+      if cons.bias is not None and rt.g(cons.bias) is not None:
+        dsum = rt.gnpart + 4 * cons.bsum_off
+        rt.defer_fold(cons.bsum_index)
+      if cons.temb is not None and cons.temb.needs_grad:
+        dtemb = rt.g(cons.temb) + 4 * cons.temb_col
+      rt.lib.gn_bwd_out_f32(rt.g(self.y), rt.v(self.x1), self.C1, rt.v(self.gamma), rt.v(self.beta_t), rt.v(self.mean),
+                            rt.v(self.rstd), rt.g(self.x1), self.b(self.x1), dgamma, dbeta, ws, self.N, self.HW, self.G,
+                            self.act, self._p(rt), (rt.seed + 0x9E3779B1 * self.op_id) & 0xFFFFFFFFFFFFFFFF, rt.seed_dev,
+                            dsum, 1.0 / cons.out_div, dtemb, cons.temb_stride, rt.v(cons.dyrec), rt.stream)
+      return
     rt.lib.gn_bwd_f32(rt.g(self.y), rt.v(self.x1), self.C1, rt.v(self.x2), self.C2,
                       rt.v(self.gamma), rt.v(self.beta_t), rt.v(self.mean), rt.v(self.rstd),
                       rt.g(self.x1), self.b(self.x1), rt.g(self.x2), self.b(self.x2) if self.x2 is not None else 0.0,
@@ -290,6 +308,13 @@ class Conv(Op):
   # (it differentiates from THIS layer's dy with the factor folded into alpha); `dy_from` is the reverse link
   dy_peer = None
   dy_from = None
+  # Graph._plan_dy_producers: the GroupNorm that reads this layer's output (and is its only reader) -- its backward leaves
+  # this layer's bias / time-embedding sums and |dy| record behind; dyrec = that record (zeroed once per backward),
+  # bsum_off / bsum_index = the partial-sum slot and fold-table entry of the bias gradient
+  dy_prod = None
+  dyrec = None
+  bsum_off = None
+  bsum_index = None
 
   # planes (include/stk.h "Planes"): decided by Graph.finalize
   pl_fwd = False       # the forward call reads x1 as planes
@@ -369,7 +394,13 @@ class Conv(Op):
     fuse_rec = (pl_dgrad or pl_wgrad) and self.Cout <= 256 and (dtemb is not None or gb is not None)
     res_grad = self.res is not None and self.res.needs_grad
     peer = self.dy_peer
-    if src is not None:
+    if self.dy_prod is not None:
+      # the GroupNorm backward that produced dy left the sums (bias: batched fold; time embedding: written) and the record
+      gb = dtemb = None
+      fuse_rec = False
+      rec_done = True
+      dy_rec = rt.v(self.dyrec)
+    elif src is not None:
       # the peer's pass over dy already left our bias gradient and our |dy| record behind
       gb = dtemb = None
       fuse_rec = False
@@ -776,6 +807,21 @@ class RowScale(Op):
     return 4 * self.x.numel
 
 
+class ZeroRecords(Op):
+  """Last op of the plan, i.e. first of the backward: zeroes the block of |dy| scale records that the GroupNorm backward
+  kernels fill by atomic maximum (Graph._plan_dy_producers)."""
+
+  def __init__(self, block):
+    self.block = block
+    self.y = block
+
+  def forward(self, rt):
+    pass
+
+  def backward(self, rt):
+    rt.lib.fill_f32(rt.v(self.block), 0.0, self.block.numel, rt.stream)
+
+
 # ------------------------------------------------------------------------------------------------
 # graph
 # ------------------------------------------------------------------------------------------------
@@ -885,18 +931,6 @@ class Graph:
         self.gact_size += _round_up(t.numel)
     self.ws_bytes = max([256] + [op.ws_bytes(lib) for op in self.ops])
     self.ws_bytes = _round_up(self.ws_bytes, 256)
-    # deferred GroupNorm parameter-gradient folds: a slot of partial sums per layer, table entries in backward order
-    # (STK_GN_FOLD_BATCH=0: every layer folds its own sums -- a debugging switch, results are bit-identical)
-    self.gnpart_size = 0
-    self.gn_folds = []
-    if os.environ.get('STK_GN_FOLD_BATCH', '1') != '0' and hasattr(lib, 'gn_param_grad_batch'):
-      for op in reversed(self.ops):
-        if isinstance(op, GroupNormAct) and (op.gamma.needs_grad or op.beta_t.needs_grad):
-          op.fold_off = self.gnpart_size
-          op.fold_index = len(self.gn_folds)
-          self.gnpart_size += _round_up(max(int(lib.gn_ws_bytes(op.N, op.C1 + op.C2, op.HW, op.G)) // 4,
-                                            2 * op.N * (op.C1 + op.C2)))
-          self.gn_folds.append(op)
     # prepared-weight arena: one block per conv layer and direction that runs on the split kernel
     self.wp_bytes = 0
     for op in self.ops:
@@ -912,9 +946,73 @@ class Graph:
           op.plan_planes(self, lib)
       self._plan_f32_copies(lib)
     self._plan_shared_dy(lib)
+    fold_batch = os.environ.get('STK_GN_FOLD_BATCH', '1') != '0' and hasattr(lib, 'gn_param_grad_batch')
+    if fold_batch:
+      self._plan_dy_producers(lib)
+    # deferred parameter-gradient folds: a slot of [N][C][2] partial sums per GroupNorm layer (and per convolution bias
+    # served by a GroupNorm backward), table entries (slot offset, dgamma offset, dbeta offset, N, C) in backward order
+    # (STK_GN_FOLD_BATCH=0: every layer folds its own sums -- a debugging switch, results are bit-identical)
+    self.gnpart_size = 0
+    self.gn_folds = []
+    if fold_batch:
+      for op in reversed(self.ops):
+        if not isinstance(op, GroupNormAct):
+          continue
+        cons = op.dy_cons
+        if op.gamma.needs_grad or op.beta_t.needs_grad or cons is not None:
+          op.fold_off = self.gnpart_size
+          op.fold_index = len(self.gn_folds)
+          self.gnpart_size += _round_up(max(int(lib.gn_ws_bytes(op.N, op.C1 + op.C2, op.HW, op.G)) // 4,
+                                            2 * op.N * (op.C1 + op.C2)))
+          self.gn_folds.append((op.fold_off, op.gamma.goff if op.gamma.needs_grad else None,
+                                op.beta_t.goff if op.beta_t.needs_grad else None, op.N, op.C1 + op.C2))
+        if cons is not None and cons.bias is not None and cons.bias.needs_grad:
+          cons.bsum_off = self.gnpart_size
+          cons.bsum_index = len(self.gn_folds)
+          self.gnpart_size += _round_up(2 * cons.N * cons.Cout)
+          self.gn_folds.append((cons.bsum_off, None, cons.bias.goff, cons.N, cons.Cout))
     for op in reversed(self.ops):
       op.plan_backward()
     return self
+
+  def _plan_dy_producers(self, lib):
+    """ResnetBlockBigGANpp: h = Conv_0(...) + temb; h = act(GroupNorm_1(h)) (layerspp.py:273-278).  Conv_0's output has ONE
+    reader, the GroupNorm, so d(Conv_0 out) is exactly that layer's dx1: its register-resident backward kernel sums the
+    values it is about to store per (sample, channel) and takes their maximum, and Conv_0's backward needs no pass over
+    dy for its bias / time-embedding gradients and its planes' scale record (it went: read dy for the sums and maxima,
+    then read it again to split)."""
+    if os.environ.get('STK_DY_PRODUCER', '1') == '0' or not hasattr(lib, 'gn_bwd_out_f32'):
+      return
+    readers = {}
+    for op in self.ops:
+      for v in vars(op).values():
+        if isinstance(v, Tensor) and v.space == 'act' and v.producer is not op:
+          readers.setdefault(id(v), []).append(op)
+    served = []
+    for op in self.ops:
+      if not isinstance(op, Conv) or not (op.pl_dgrad or op.pl_wgrad) or op.Cout > 256:
+        continue
+      if op.res is not None or op.dy_peer is not None or op.dy_from is not None or op.y is self.output:
+        continue
+      if op.bias is None and (op.temb is None or not op.temb.needs_grad):
+        continue
+      if op.w.needs_grad and not op.pl_wgrad:      # the fp32-operand weight gradient looks for the record in op.amax
+        continue
+      rd = readers.get(id(op.y), [])
+      if len(rd) != 1 or not isinstance(rd[0], GroupNormAct):
+        continue
+      gn = rd[0]
+      if gn.x1 is not op.y or gn.x2 is not None or gn.dy_cons is not None or not op.y.needs_grad:
+        continue
+      if not int(lib.gn_bwd_out_ok(gn.C1, 0, gn.HW, gn.G)):
+        continue
+      gn.dy_cons, op.dy_prod = op, gn
+      served.append(op)
+    if served:
+      block = self.new((256 * len(served),), needs_grad=False, name='dyrecs')
+      for i, op in enumerate(served):
+        op.dyrec = Tensor((256,), 'act', block.off + 256 * i, False, op.y.name + '.dyrec')
+      self.ops.append(ZeroRecords(block))
 
   def _plan_shared_dy(self, lib):
     """ResnetBlockBigGANpp with a shortcut convolution: out = (Conv_2(x) + Conv_1(h)) / sqrt 2 (layerspp.py:283-287) is

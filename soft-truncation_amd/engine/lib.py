@@ -32,6 +32,8 @@ SIGNATURES = {
   'stk_gn_fwd_f32': [P, I, P, I, P, P, P, P, P, I, I, I, F, I, F, U64, P, P, S],
   'stk_gn_ws_bytes': [I, I, I, I],
   'stk_gn_bwd_f32': [P, P, I, P, I, P, P, P, P, P, F, P, F, P, P, P, I, I, I, I, F, U64, P, S],
+  'stk_gn_bwd_out_ok': [I, I, I, I],
+  'stk_gn_bwd_out_f32': [P, P, I, P, P, P, P, P, F, P, P, P, I, I, I, I, F, U64, P, P, F, P, I, P, S],
   'stk_gn_param_grad_batch': [P, I, I, S],
   'stk_conv2d_variant': [I, I, I, I, I, I, I, I, I, I, I, I, I, I],
   'stk_conv2d_fwd_ws_bytes': [I, I, I, I, I, I, I, I, I, I],
@@ -74,6 +76,7 @@ SIGNATURES = {
   'stk_axpby_f32': [P, F, P, F, P, L, S],
   'stk_add_div_f32': [P, P, F, P, L, S],
   'stk_affine_f32': [P, F, F, P, L, S],
+  'stk_fill_f32': [P, F, L, S],
   'stk_resample_naive_f32': [P, P, L, I, I, I, F, F, S],
   'stk_rowscale_f32': [P, P, P, I, L, I, S],
   'stk_timestep_embedding_f32': [P, P, P, I, I, S],
@@ -91,7 +94,7 @@ SIGNATURES = {
 _RESTYPE = {'stk_strerror': c_char_p, 'stk_backend': c_char_p, 'stk_conv2d_wgrad_ws_bytes': c_long,
             'stk_conv2d_fwd_ws_bytes': c_long, 'stk_conv2d_dgrad_ws_bytes': c_long, 'stk_gn_ws_bytes': c_long,
             'stk_conv2d_wp_bytes': c_long, 'stk_conv2d_wp_desc': c_long, 'stk_planes_bytes': c_long, 'stk_conv2d_wgrad_pl_ws_bytes': c_long}
-_NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant', 'stk_conv2d_pl_ok', 'stk_gn_fwd_pl_fused', 'stk_conv2d_wgrad_pl_ok', 'stk_attention_ok'}
+_NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant', 'stk_conv2d_pl_ok', 'stk_gn_fwd_pl_fused', 'stk_conv2d_wgrad_pl_ok', 'stk_attention_ok', 'stk_gn_bwd_out_ok'}
 
 
 class StkMissingError(RuntimeError):

@@ -137,6 +137,36 @@ def test_planes_plumbing_on_checker(st, ref_lib):
   assert all(pr.graph.pl_bytes > 0 and pr.graph.dypl_bytes > 0 for pr in progs)
   gns = [op for pr in progs for op in pr.graph.ops if isinstance(op, G.GroupNormAct)]
   assert any(op.y.pl_maker is op for op in gns)
+  # Conv_0 of a ResnetBlock: its output gradient is GroupNorm_1's dx1, whose backward leaves the bias / time-embedding
+  # sums and the |dy| record behind (stk_gn_bwd_out_f32); the plan ends with the op that zeroes those records
+  served = [op for op in convs if op.dy_prod is not None]
+  assert served and all(op.dy_prod.dy_cons is op and op.temb is not None and op.bsum_index is not None for op in served)
+  assert all(isinstance(pr.graph.ops[-1], G.ZeroRecords) for pr in progs)
+
+
+def test_dy_producer_switch_off_gives_same_gradients(st, ref_lib, monkeypatch):
+  """STK_DY_PRODUCER=0 (every convolution sums and measures its own dy) against the default plan, on the checker: the
+  same parameter gradients (bias gradients through the batched fold, time-embedding gradients written by the GroupNorm
+  backward) to rounding."""
+  import torch
+  cfg, cfg_cpu, sde, model, ref = cases.build_pair(st, cases.tiny_config(st, 'wide'), ref_lib)
+  model.train()
+  x, t = torch.randn(2, 3, 16, 16), torch.rand(2) * 999
+
+  def grads():
+    model.zero_grad()
+    model(x, t).square().sum().backward()
+    return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+  torch.manual_seed(0)
+  g1 = grads()
+  monkeypatch.setenv('STK_DY_PRODUCER', '0')
+  model.module.engine().programs.clear()
+  torch.manual_seed(0)
+  g0 = grads()
+  assert g0.keys() == g1.keys()
+  for k in g0:
+    assert (g1[k] - g0[k]).abs().max().item() <= 2e-5 * max(g0[k].abs().max().item(), 1e-6), k
 
 
 def test_planes_switch_off_gives_same_answers(st, ref_lib, monkeypatch):

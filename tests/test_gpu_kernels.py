@@ -254,6 +254,50 @@ def test_groupnorm(ref_lib, hip_lib, case):
   compare(both(ref_lib, hip_lib, fn), 2e-5, 'groupnorm')
 
 
+GN_OUT_CASES = [
+  # N, C, H, G, act, p, beta1
+  (4, 128, 32, 32, 1, 0.1, 0.0),     # the 32x32 layers: IPT 4
+  (3, 256, 16, 32, 1, 0.0, 0.0),
+  (5, 256, 4, 32, 1, 0.1, 1.0),      # 4x4 maps, accumulating into dx1: the by-products come from the FINAL values
+  (2, 96, 8, 24, 0, 0.0, 0.0),
+]
+
+
+@pytest.mark.parametrize('case', GN_OUT_CASES, ids=str)
+def test_groupnorm_backward_byproducts(ref_lib, hip_lib, case):
+  """stk_gn_bwd_out_f32: dx1 as stk_gn_bwd_f32, plus the per-(sample, channel) sums of dx1 (fold-slot format and the
+  strided time-embedding gradient) and the atomic-maximum scale record, against the oracle."""
+  N, C, H, G, act, p, b1 = case
+  HW = H * H
+  x1 = rnd(N, C, H, H, seed=1) * 2 + 0.5
+  gamma, beta = rnd(C, seed=3) + 1, rnd(C, seed=4)
+  dy = rnd(N, C, H, H, seed=5) * torch.logspace(-3, 0, N)[:, None, None, None]
+  d1 = rnd(N, C, H, H, seed=6)
+  seed, stride, col = 0xABCDEF12345, 2 * C + 5, 3
+  assert int(hip_lib.gn_bwd_out_ok(C, 0, HW, G)) == 1 and int(ref_lib.gn_bwd_out_ok(C, 0, HW, G)) == 1
+
+  def fn(lib, to):
+    dev = dev_of(lib)
+    y, mean, rstd = to(torch.zeros(N, C, H, H)), to(torch.zeros(N * G)), to(torch.zeros(N * G))
+    sdev = torch.tensor([17], dtype=torch.int64, device=dev)
+    a1, ga, be = to(x1), to(gamma), to(beta)
+    ws = to(torch.zeros(max(int(lib.gn_ws_bytes(N, C, HW, G)) // 4, 2 * N * C)))
+    call(lib, 'gn_fwd_f32', a1, C, None, 0, ga, be, y, mean, rstd, N, HW, G, 1e-6, act, p, seed, sdev, ws)
+    dx1 = to(d1.clone())
+    dsum, dtemb, rec = to(torch.full((N, C, 2), 7.0)), to(torch.full((N, stride), 7.0)), to(torch.zeros(256))
+    call(lib, 'gn_bwd_out_f32', to(dy), a1, C, ga, be, mean, rstd, dx1, b1, None, None, ws, N, HW, G, act, p, seed, sdev,
+         dsum, 0.5, dtemb[:, col:], stride, rec)
+    return {'dx1': dx1, 'sum': dsum[:, :, 0].contiguous(), 'zero': dsum[:, :, 1].contiguous(),
+            'temb': dtemb[:, col:col + C].contiguous(), 'untouched': dtemb[:, :col].contiguous(),
+            'amax': rec.max().reshape(1), 'fold': ws[:2 * N * C].clone()}
+
+  out = both(ref_lib, hip_lib, fn)
+  compare(out, 2e-5, 'groupnorm by-products')
+  got = out[1] if isinstance(out, (tuple, list)) else None
+  if got is not None:
+    assert float(got['amax']) == float(got['dx1'].abs().max())            # the record is exact, not approximate
+
+
 # ---------------------------------------------------------------------------------------------------
 # convolution: forward / dgrad / wgrad / bias-grad
 # ---------------------------------------------------------------------------------------------------

@@ -303,6 +303,8 @@ WGRAD_PL_CASES = [
   (8, 256, 160, 8),       # COLS = 8, two co tiles, the second one ragged
   (2, 32, 32, 64),        # W > 32: a chunk is half a row
   (3, 96, 128, 16),
+  (16, 256, 256, 4),      # COLS = 4: a chunk is two whole images, each with its own halo tile
+  (18, 64, 160, 4),       # ... ragged co tile, K split with a short last slab
 ]
 
 
