@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnArgs a, const float* __re
 // (algorithmic traffic: read x, read dy, write dx).  Per-channel sums come from a segmented wave reduction (a wave
 // covers one channel or 64/(HW/4) whole channels) written to fixed LDS slots and folded in slot order -- no
 // atomics, so results are reproducible.  blockDim = 64/128/256 so small groups do not idle lanes.
-template <int IPT>
+template <int IPT, bool WANT>
 __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float* __restrict__ dy,
                                                           const float* __restrict__ mean_in,
                                                           const float* __restrict__ rstd_in, float* __restrict__ dx1,
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
   // `out` (stk_gn_bwd_out_f32, single-source layers): what the consumer of dx1 -- the backward of the convolution that
   // produced x1 -- would otherwise take one more pass over dx1 for: per-(sample, channel) sums of the FINAL dx1 values
   // (bias / time-embedding gradients) and max |dx1| (scale record of its planes).  Block-uniform branches only.
-  const bool want = out.sum || out.temb || out.amax;
+  constexpr bool want = WANT;            // compile-time: the plain instances carry none of the by-product code
   float amax_l = 0.f;
 #pragma unroll
   for (int k = 0; k < IPT; ++k) {
@@ -426,6 +426,10 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
     }
   }
   if (want) {
+    {
+      const float m = wave_max(amax_l);
+      if (lane == 0) s_ch[threadIdx.x >> 6] = m;          // s_ch was last read before the store loop above
+    }
     __syncthreads();
     for (int cl = threadIdx.x; cl < a.cpg; cl += T) {
       float t = 0.f;
@@ -434,10 +438,12 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
       if (out.sum) { out.sum[((long)n * C + c0 + cl) * 2] = t; out.sum[((long)n * C + c0 + cl) * 2 + 1] = 0.f; }
       if (out.temb) out.temb[(long)n * out.temb_stride + c0 + cl] = t;
     }
-    if (out.amax) {
-      // non-negative floats order like their bit patterns: an integer max is exact and order-independent
-      const float m = wave_max(amax_l);
-      if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(out.amax) + ((blockIdx.x + (threadIdx.x >> 6)) & 255), __float_as_uint(m));
+    if (out.amax && threadIdx.x == 0) {
+      // ONE atomic per workgroup (4096 workgroups on 256 slots: 16 per address; one per wave measured no gain over the
+      // separate pass).  Non-negative floats order like their bit patterns: an integer max is exact and order-independent
+      float m = 0.f;
+      for (int w = 0; w < (T >> 6); ++w) m = fmaxf(m, s_ch[w]);
+      atomicMax(reinterpret_cast<unsigned*>(out.amax) + (blockIdx.x & 255), __float_as_uint(m));
     }
   }
 }
@@ -983,8 +989,14 @@ static int gn_bwd_impl(const float* dy, const float* x1, int C1, const float* x2
     while (T < 1024 && T * tgt < L4) T <<= 1;
     const int ipt = stk_cdiv(L4, T);
 #define STK_GN_FLAT(IPT)                                                                                          \
-  hipLaunchKernelGGL((gn_bwd_flat_kernel<IPT>), dim3(N * G), dim3(T), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, \
-                     dx1_beta, dx2, dx2_beta, ws, hw_log2, out)
+  do {                                                                                                            \
+    if (out.sum || out.temb || out.amax)                                                                          \
+      hipLaunchKernelGGL((gn_bwd_flat_kernel<IPT, true>), dim3(N * G), dim3(T), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, \
+                         dx1_beta, dx2, dx2_beta, ws, hw_log2, out);                                               \
+    else                                                                                                          \
+      hipLaunchKernelGGL((gn_bwd_flat_kernel<IPT, false>), dim3(N * G), dim3(T), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, \
+                         dx1_beta, dx2, dx2_beta, ws, hw_log2, out);                                               \
+  } while (0)
     if (ipt <= 1) STK_GN_FLAT(1);
     else if (ipt <= 2) STK_GN_FLAT(2);
     else if (ipt <= 3) STK_GN_FLAT(3);

@@ -284,9 +284,10 @@ def test_groupnorm_backward_byproducts(ref_lib, hip_lib, case):
     ws = to(torch.zeros(max(int(lib.gn_ws_bytes(N, C, HW, G)) // 4, 2 * N * C)))
     call(lib, 'gn_fwd_f32', a1, C, None, 0, ga, be, y, mean, rstd, N, HW, G, 1e-6, act, p, seed, sdev, ws)
     dx1 = to(d1.clone())
-    dsum, dtemb, rec = to(torch.full((N, C, 2), 7.0)), to(torch.full((N, stride), 7.0)), to(torch.zeros(256))
+    dsum, dtemb, rec = to(torch.full((N, C, 2), 7.0)), to(torch.full((N * stride,), 7.0)), to(torch.zeros(256))
     call(lib, 'gn_bwd_out_f32', to(dy), a1, C, ga, be, mean, rstd, dx1, b1, None, None, ws, N, HW, G, act, p, seed, sdev,
-         dsum, 0.5, dtemb[:, col:], stride, rec)
+         dsum, 0.5, dtemb[col:], stride, rec)
+    dtemb = dtemb.view(N, stride)
     return {'dx1': dx1, 'sum': dsum[:, :, 0].contiguous(), 'zero': dsum[:, :, 1].contiguous(),
             'temb': dtemb[:, col:col + C].contiguous(), 'untouched': dtemb[:, :col].contiguous(),
             'amax': rec.max().reshape(1), 'fold': ws[:2 * N * C].clone()}
