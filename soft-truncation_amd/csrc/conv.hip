@@ -911,7 +911,6 @@ constexpr bool SPLIT_WGRAD3_X2 = true;      // the three-taps-per-workgroup 3x3 
 // The per-tap weight gradients (1x1 layers, 3x3 on 4-wide maps) on the fp16 two-way split as well (x2::wgemm_kernel);
 // STK_WGRAD1_X2=0 keeps them on the bf16 three-way split (debugging / A-B switch, read once).
 inline bool wgrad1_x2() { static const bool v = [] { const char* e = getenv("STK_WGRAD1_X2"); return !e || atoi(e) != 0; }(); return v; }
-inline bool x2d_early() { static const bool v = [] { const char* e = getenv("STK_X2D_EARLY"); return e && atoi(e) != 0; }(); return v; }
 inline bool wgrad1_pin() { static const bool v = [] { const char* e = getenv("STK_W1_PIN"); return !e || atoi(e) != 0; }(); return v; }
 
 inline void x3_weight_strides(const ConvP& p, int dgrad, long& sm, long& sk) {
@@ -985,19 +984,11 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
     const bool wide = pl::kernel_choice() == 3 && r.splits == 1 && p.HW % 256 == 0 && (long)tm * stk_cdiv((int)Ng, 256) >= 384; \
     if (wide) {                                                                                                   \
       const int tn2 = stk_cdiv((int)Ng, 256);                                                                     \
-      if (x2d_early())                                                                                            \
-        hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 256, E, true>), dim3((unsigned)(tm * tn2)), dim3(256), 0, s, p, q, M, (int)Ng, \
-                           tm, tn2, nch, r.chunks_per_split, xpart, nx);                                          \
-      else                                                                                                        \
-        hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 256, E>), dim3((unsigned)(tm * tn2)), dim3(256), 0, s, p, q, M, (int)Ng, \
-                           tm, tn2, nch, r.chunks_per_split, xpart, nx);                                          \
+      hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 256, E>), dim3((unsigned)(tm * tn2)), dim3(256), 0, s, p, q, M, (int)Ng, \
+                         tm, tn2, nch, r.chunks_per_split, xpart, nx);                                            \
     } else {                                                                                                      \
-      if (x2d_early())                                                                                            \
-        hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 128, E, true>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, \
-                           r.chunks_per_split, xpart, nx);                                                        \
-      else                                                                                                        \
-        hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 128, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, \
-                           r.chunks_per_split, xpart, nx);                                                        \
+      hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 128, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch,  \
+                         r.chunks_per_split, xpart, nx);                                                          \
     }                                                                                                             \
   } else if (pl::kernel_choice() == 1)                                                                            \
     hipLaunchKernelGGL((pl::gemm_db_kernel<pl::PlaneLoader<TAPS>, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, \

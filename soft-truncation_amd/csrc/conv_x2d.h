@@ -37,8 +37,10 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* 
 }
 
 // (Tried and dropped: a static wave priority per workgroup generation, s_setprio by (blockIdx >> 8) & 1, to break
-// the lockstep of the two workgroups of a CU -- 132 -> 142 us on the 128 -> 128 layer.)
-template <int TAPS, int TN, class EP, bool EARLY = false>
+// the lockstep of the two workgroups of a CU -- 132 -> 142 us on the 128 -> 128 layer.  Reading ALL fragments of a chunk
+// before its first MFMA, so that the tile is free and the next chunk's DMA in flight for 48 instead of 24 MFMAs: 250
+// VGPRs, the training step 43.9 -> 44.5 ms.)
+template <int TAPS, int TN, class EP>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M, int Nn, int tiles_m, int tiles_n,
                                                       int nchunks_total, int chunks_per_split,
                                                       const float* __restrict__ xpart, int nxpart) {
@@ -145,35 +147,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M,
 
   halfx8 a[2][2], b[G::NJ][2];
   stage(c_begin);
-  if (EARLY) {
-    // EARLY: all fragments of the chunk are read before any MFMA (twice the fragment registers), so the tile is free
-    // -- and the DMA of chunk c + 1 in flight -- for the whole chunk's 48 MFMAs instead of the second half's 24
-    halfx8 a2[2][2], b2[G::NJ][2];
-    for (int c = c_begin; c <= c_last; ++c) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      STK_D_FRAGS(ko0)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          a2[i][s] = *reinterpret_cast<const halfx8*>(a_rd + s * G::A_PLANE + i * 32 * 64 + ko1);
-#pragma unroll
-        for (int j = 0; j < G::NJ; ++j)
-          b2[j][s] = *reinterpret_cast<const halfx8*>(b_rd + s * G::B_PLANE + j * 32 * 64 + ko1);
-      }
-      __syncthreads();
-      if (c < c_last) stage(c + 1);
-      STK_D_MFMAS
-#pragma unroll
-      for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < G::NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[i][SA[pr]], b2[j][SB[pr]], acc[i][j], 0, 0, 0);
-    }
-  } else {
   for (int c = c_begin; c <= c_last; ++c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk c has landed ...
     __syncthreads();                                   // ... and so has everybody else's
@@ -183,7 +156,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M,
     __syncthreads();                                   // nobody reads the tile any more (the barrier waits lgkmcnt(0))
     if (c < c_last) stage(c + 1);                      // chunk c + 1 streams in under the second half's MFMAs
     STK_D_MFMAS
-  }
   }
 #undef STK_D_MFMAS
 #undef STK_D_FRAGS
