@@ -53,10 +53,20 @@ KERNEL_SYMBOL = {
   'conv3x3.wgrad.x2': 'x2::wgrad3_kernel<false>',
   'conv3x3.fwd.x2': 'x2::gemm_kernel<x2::ActLoader<false, 9>, EpFwd, 2>',
   'conv3x3.dgrad.x2': 'x2::gemm_kernel<x2::ActLoader<false, 9>, EpDgrad, 2>',
-  # plane operands (round 2): LDS-DMA staged forward / data gradient, transpose-read weight gradient
+  'conv1x1.fwd.x2': 'x2::gemm_kernel<x2::ActLoader<true, 1>, EpFwd, 2>',
+  'conv1x1.dgrad.x2': 'x2::gemm_kernel<x2::ActLoader<false, 1>, EpDgrad, 2>',
+  'conv1x1.wgrad.x2': 'x2::wgemm_kernel<x2::RowsU<false, false>, x2::RowsU<true, true>, EpWgrad, true>',
+  # plane operands (round 2): LDS-DMA staged forward / data gradient ('.k' = the K-split form of the small maps: EpSlab
+  # partial tiles + a slab-sum launch), transpose-read weight gradient (one symbol per map width)
   'conv3x3.fwd.x2p': 'x2d::gemm_kernel<9, 128, EpFwd>',
   'conv3x3.dgrad.x2p': 'x2d::gemm_kernel<9, 128, EpDgrad>',
-  'conv3x3.wgrad.x2p': 'x2w::wgrad_kernel<32>',
+  'conv3x3.fwd.x2p.k': 'x2d::gemm_kernel<9, 128, EpSlab>',
+  'conv3x3.dgrad.x2p.k': 'x2d::gemm_kernel<9, 128, EpSlab>',
+  'conv1x1.fwd.x2p': 'x2d::gemm_kernel<1, 128, EpFwd>',
+  'conv3x3.wgrad.x2p.w32': 'x2w::wgrad_kernel<32>',
+  'conv3x3.wgrad.x2p.w16': 'x2w::wgrad_kernel<16>',
+  'conv3x3.wgrad.x2p.w8': 'x2w::wgrad_kernel<8>',
+  'conv3x3.wgrad.x2p.w4': 'x2w::wgrad_kernel<4>',
 }
 
 
@@ -77,7 +87,7 @@ def traffic_of(kind):
 
 
 def kernel_peak(kind):
-  if kind.endswith('.x2') or kind.endswith('.x2p'):
+  if '.x2' in kind:                 # .x2 / .x2p / .x2p.k / .x2p.w32 ...
     return PEAK_X2_TFLOPS
   return PEAK_X3_TFLOPS if kind.endswith('.x3') else PEAK_F32_MFMA_TFLOPS
 TRAIN_FLOPS_PER_IMG = {'cifar10_ddpmpp_nll_st': 65.072e9, 'imagenet32_ddpmpp_st': 65.072e9,

@@ -1322,6 +1322,17 @@ int stk_conv2d_pl_ok(int dir, int C1, int C2, int N, int H, int W, int Cout, int
   return 0;
 }
 
+/* number of K splits the plane-operand forward (dir 0) / data-gradient (dir 1) call of this shape runs with: 1 = one
+ * launch of x2d::gemm_kernel<.., EpFwd / EpDgrad>, > 1 = EpSlab partial tiles + a slab-sum launch (small maps),
+ * 0 = the shape does not take plane operands.  (Profiler labels: bench.py names kernels by their rocprof symbol.) */
+int stk_conv2d_pl_ksplit(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW) {
+  if (!stk_conv2d_pl_ok(dir, C1, C2, N, H, W, Cout, KH, KW, 1, KH / 2)) return 0;
+  ConvP p = {};
+  if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, 1, KH / 2)) return 0;
+  const long Ng = (long)N * p.HW;
+  return dir == 0 ? x3_plan(p, p.Cin, C1, 0, Cout, Ng).splits : x3_plan(p, Cout, Cout, 0, p.Cin, Ng).splits;
+}
+
 int stk_conv2d_fwd_pl_f32(const void* xpl, const float* xamax, int C, const float* w, int w_layout, const float* bias,
                           const float* temb, int temb_stride, const float* res, float out_div, float* y, int N, int H,
                           int W, int Cout, int KH, int KW, const void* wp, void* ws, long ws_bytes, void* stream) {

@@ -217,7 +217,16 @@ class _NetFn(torch.autograd.Function):
     if ctx.c.released:
       raise RuntimeError('score-network backward called twice on the same forward; the engine frees '
                          'activations after the first backward')
-    gx = ctx.ex.run_backward(ctx.c, gout)
+    # Does this backward pass want parameter gradients at all?  torch.autograd.grad(out, x) (the divergence / ELBO
+    # estimators of likelihood.py) never reaches the anchor's accumulation node; .backward() does.  Without them the
+    # weight / bias / affine gradients are neither computed nor added into p.grad -- as in the reference, where autograd
+    # only walks the branches that were asked for.
+    pg = True
+    try:
+      pg = bool(torch._C._will_engine_execute_node(ctx.ex._anchor_acc))
+    except Exception:      # API absent, or the anchor itself is among autograd.grad's inputs
+      pg = True
+    gx = ctx.ex.run_backward(ctx.c, gout, param_grads=pg)
     return None, None, None, (gx if ctx.need_xgrad else None), None, None
 
 
@@ -228,6 +237,7 @@ class Executor:
     self.flat = None
     self.programs = {}
     self._anchor = None
+    self._anchor_acc = None
     self.profiler = None     # engine.profile.KernelTimer or None
     self.use_graphs = os.environ.get('STK_GRAPHS', '1') != '0'
     self.graph_replays = 0
@@ -252,6 +262,8 @@ class Executor:
       self.flat = FlatParams(params, device, groups=self.model._flat_groups())
       self.programs.clear()
       self._anchor = torch.zeros((), dtype=torch.float32, device=device, requires_grad=True)
+      with torch.enable_grad():
+        self._anchor_acc = self._anchor.view_as(self._anchor).grad_fn.next_functions[0][0]   # its AccumulateGrad node
     else:
       self.flat.rebind_grads()
     if self.lib.is_device != (device.type == 'cuda'):
@@ -333,10 +345,10 @@ class Executor:
       rt.gnpart, rt.gn_table, rt.gn_maxc = prog.gnpart.data_ptr(), prog.gn_table.data_ptr(), prog.gn_maxc
     return rt
 
-  def _replay(self, c, direction, training, span=None, with_backward=True):
+  def _replay(self, c, direction, training, span=None, with_backward=True, param_grads=True):
     """Replay (capturing on first use) the hipGraph of one direction of this context; `span` = (begin, end) restricts a
     backward graph to that slice of the backward op order (segments of the overlapped gradient exchange)."""
-    key = (direction, training, with_backward) if span is None else (direction, training, span)
+    key = (direction, training, with_backward, param_grads) if span is None else (direction, training, span)
     g = c.graphs.get(key)
     if g is None:
       ops = c.prog.graph.ops
@@ -347,6 +359,7 @@ class Executor:
         # multi-GPU run polling its events) must not invalidate the capture
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
           rt = self._runtime(c, training, 0, c.seed_t.data_ptr(), with_backward)   # stream = the capture stream
+          rt.param_grads = param_grads
           if direction == 'fwd':
             for op in ops:
               op.forward(rt)
@@ -404,15 +417,16 @@ class Executor:
     out = c.act[o.off:o.off + o.numel].view(o.shape).clone()
     return out, c
 
-  def run_backward(self, c, gout):
+  def run_backward(self, c, gout, param_grads=True):
     prog, g, rt = c.prog, c.prog.graph, c.rt
+    rt.param_grads = param_grads
     flat = self.flat
     if c.gact is None:
       c.gact = _arena(g.gact_size, prog.device)
     o = g.output
     c.gact[o.goff:o.goff + o.numel].view(o.shape).copy_(gout)
     done = False
-    hook = self.grad_hook
+    hook = self.grad_hook if param_grads else None      # nothing to exchange after an input-gradient-only backward
     if hook is not None:
       # overlapped exchange: segment by segment, handing finished buckets to the hook (which starts their all-reduce
       # on the communicator's stream, ordered behind the launches made so far)
@@ -441,7 +455,7 @@ class Executor:
           hook(lo, hi)
       done = True
     elif self._graphs_on() and rt.seed_dev is not None:
-      done = self._replay(c, 'bwd', rt.training)
+      done = self._replay(c, 'bwd', rt.training, param_grads=param_grads)
     if not done:
       rt.gbase['act'] = c.gact.data_ptr()
       rt.gbase['param'] = flat.grad.data_ptr()

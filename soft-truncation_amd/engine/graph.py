@@ -79,6 +79,9 @@ class Runtime:
     self.prof = None      # optional engine.profile.KernelTimer: HIP events around the contraction launches
     # deferred GroupNorm parameter-gradient folds (stk_gn_param_grad_batch): base of the program's partial-sum arena,
     # device address of its descriptor table (entries in backward order), and the pending range of entries
+    # False: the caller asked for the INPUT gradient only (torch.autograd.grad(out, x): likelihood.get_div_fn / get_elbo_fn)
+    # -- g() of a parameter is None, so no weight / bias / affine gradient is computed and flat.grad is not touched
+    self.param_grads = True
     self.gnpart = 0
     self.gn_table = 0
     self.gn_maxc = 0
@@ -87,9 +90,11 @@ class Runtime:
 
   def defer_fold(self, index):
     """A GroupNorm backward left its per-(sample, channel) sums behind; entry `index` of the table folds them."""
+    if self._fold_hi is not None and index != self._fold_hi:      # a skipped entry (frozen parameters): close the run
+      assert index > self._fold_hi, 'folds must be deferred in table order'
+      self.flush_folds()
     if self._fold_lo is None:
       self._fold_lo = index
-    assert self._fold_hi is None or index == self._fold_hi, 'GroupNorm folds must be deferred in table order'
     self._fold_hi = index + 1
 
   def flush_folds(self):
@@ -112,6 +117,8 @@ class Runtime:
 
   def g(self, t):
     if t is None or not t.needs_grad or t.goff is None:
+      return None
+    if t.space == 'param' and not self.param_grads:
       return None
     return self.gbase[t.space] + 4 * t.goff
 
@@ -207,7 +214,7 @@ class GroupNormAct(Op):
   def backward(self, rt):
     dgamma, dbeta, ws = rt.g(self.gamma), rt.g(self.beta_t), rt.ws
     cons = self.dy_cons
-    if rt.gn_table and self.fold_index is not None and (dgamma is not None or dbeta is not None or cons is not None):
+    if rt.gn_table and self.fold_index is not None and (dgamma is not None or dbeta is not None):
       # leave the per-(sample, channel) sums in this layer's own slot; one launch folds a whole segment's layers
       dgamma = dbeta = None
       ws = rt.gnpart + 4 * self.fold_off
@@ -275,6 +282,24 @@ class Conv(Op):
                                  self.W, self.Cout, self.OH, self.OW, self.KH, self.KW, self.stride, self.pad,
                                  self.w_layout))
       k = f'conv{self.KH}x{self.KW}.{direction}.{self._VARIANT.get(v, "t64")}'
+      setattr(self, key, k)
+    return k
+
+  def _label_pl(self, lib, direction):
+    """Profiler label of a plane-operand launch: one label per kernel SYMBOL (bench.py's roofline is per kernel):
+    fwd / dgrad: '...x2p' = x2d::gemm_kernel<.., EpFwd / EpDgrad>, '...x2p.k' = its K-split form (EpSlab + slab sum, small
+    maps); wgrad: '...x2p.w32' / '.w16' / '.w8' / '.w4' = x2w::wgrad_kernel<min(W, 32)>."""
+    key = '_label_' + direction
+    k = getattr(self, key, None)
+    if k is None:
+      k = self._kind(lib, direction) + 'p'
+      if direction == 'wgrad':
+        k += f'.w{min(self.W, 32)}'
+      elif hasattr(lib, 'conv2d_pl_ksplit'):
+        d = 0 if direction == 'fwd' else 1
+        c2 = 0 if d == 0 else self.C2
+        if int(lib.conv2d_pl_ksplit(d, self.C1, c2, self.N, self.H, self.W, self.Cout, self.KH, self.KW)) > 1:
+          k += '.k'
       setattr(self, key, k)
     return k
 
@@ -363,7 +388,7 @@ class Conv(Op):
       t = self.x1
       if t.pl_maker is self:
         rt.make_planes(t)
-      rt.timed(self._kind(rt.lib, 'fwd') + 'p', self.flops, rt.lib.conv2d_fwd_pl_f32,
+      rt.timed(self._label_pl(rt.lib, 'fwd'), self.flops, rt.lib.conv2d_fwd_pl_f32,
                rt.planes(t), rt.rec(t), self.C1, rt.v(self.w), self.w_layout, rt.v(self.bias), temb, self.temb_stride,
                rt.v(self.res), self.out_div, rt.v(self.y), self.N, self.H, self.W, self.Cout, self.KH, self.KW,
                self._wp(rt, 0), rt.ws, rt.ws_bytes, rt.stream)
@@ -441,7 +466,7 @@ class Conv(Op):
       lib.split_planes_f32(gy, self.N, self.Cout, self.OH * self.OW, rec, 256, rt.dypl, rt.stream)
       have |= 2
     if pl_dgrad:
-      rt.timed(self._kind(lib, 'dgrad') + 'p', self.flops, lib.conv2d_dgrad_pl_f32,
+      rt.timed(self._label_pl(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_pl_f32,
                rt.dypl, rec, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
                alpha, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self._wp(rt, 1), rt.ws, rt.ws_bytes, rt.stream)
@@ -454,7 +479,7 @@ class Conv(Op):
       if self._kind(lib, 'dgrad').endswith('.x2'):
         have |= 2
     if pl_wgrad:
-      rt.timed(self._kind(lib, 'wgrad') + 'p', self.flops, lib.conv2d_wgrad_pl_f32,
+      rt.timed(self._label_pl(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_pl_f32,
                rt.planes(self.x1), rt.rec(self.x1), rt.dypl, dy_rec, gw, alpha, rt.ws, rt.ws_bytes,
                self.N, self.H, self.W, self.C1, self.Cout, rt.stream)
     elif gw is not None:

@@ -169,6 +169,31 @@ def test_dy_producer_switch_off_gives_same_gradients(st, ref_lib, monkeypatch):
     assert (g1[k] - g0[k]).abs().max().item() <= 2e-5 * max(g0[k].abs().max().item(), 1e-6), k
 
 
+def test_input_gradient_only_backward_leaves_parameter_gradients_alone(st, ref_lib):
+  """torch.autograd.grad(out, x) -- the Hutchinson divergence of likelihood.py:38-47 -- must return the same input
+  gradient as a full backward and must neither compute nor accumulate parameter gradients (in the reference autograd
+  only walks the branches that were asked for)."""
+  import torch
+  cfg, cfg_cpu, sde, model, ref = cases.build_pair(st, cases.tiny_config(st, 'wide'), ref_lib)
+  model.eval()
+  x, t = torch.randn(2, 3, 16, 16), torch.rand(2) * 999
+  xa = x.clone().requires_grad_(True)
+  model.zero_grad()
+  model(xa, t).square().sum().backward()
+  gx_full = xa.grad.clone()
+  flat = model.module.engine().flat
+  assert float(flat.grad.abs().max()) > 0
+  flat.grad.zero_()
+  xb = x.clone().requires_grad_(True)
+  gx, = torch.autograd.grad(model(xb, t).square().sum(), xb)
+  assert float(flat.grad.abs().max()) == 0.0            # untouched
+  assert torch.equal(gx, gx_full)
+  # and a full backward afterwards still produces them
+  xc = x.clone().requires_grad_(True)
+  model(xc, t).square().sum().backward()
+  assert float(flat.grad.abs().max()) > 0
+
+
 def test_planes_switch_off_gives_same_answers(st, ref_lib, monkeypatch):
   """STK_PLANES=0 (every convolution on fp32 operands) against the default plan, on the checker: the restatement
   decodes planes exactly, so forward values agree to the split's 2^-22."""
