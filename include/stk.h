@@ -89,21 +89,27 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
                    float* dgamma, float* dbeta, float* ws,
                    int N, int HW, int G, int act, float drop_p,
                    unsigned long long seed, const unsigned long long* seed_dev, void* stream);
-/* stk_gn_bwd_f32 of a single-source layer whose input x1 is the output of a convolution (ResnetBlockBigGANpp: Conv_0 ->
- * + temb -> GroupNorm_1, models/layerspp.py:273-278), leaving behind what that convolution's backward would otherwise take
- * one more pass over dx1 for.  All computed from the FINAL dx1 values (after the dx1_beta accumulation):
- *   dx_sum  [N][C1][2]: {out_scale * sum_hw dx1[n,c,:], 0} -- the partial-sum format of stk_gn_param_grad_batch, so the
- *           convolution's bias gradient is one more entry (dbeta = its bias gradient, dgamma = NULL) of that fold;
+/* stk_gn_bwd_f32 that (a) adds a second gradient branch into dx1 on the way and (b) leaves behind what the backward of the
+ * convolution that PRODUCED x1 would otherwise take one more pass over dx1 for -- when this call is the last writer of
+ * dx1, dx1 is that convolution's output gradient (ResnetBlockBigGANpp: Conv_0 -> + temb -> GroupNorm_1; block output ->
+ * next block's GroupNorm_0, models/layerspp.py:256-287).
+ *   dx1_add [N, C1, HW] (may be NULL): dx1 = dx1_beta * dx1 + (GroupNorm gradient) + add_scale * dx1_add -- the identity
+ *           skip of the block this layer opens, out = (x + h) / sqrt 2: add = d(out), add_scale = 1 / sqrt 2.
+ * By-products, all computed from the FINAL dx1 values, each may be NULL:
+ *   dx_sum  [N][C1][2]: {s, s}, s = out_scale * sum_hw dx1[n,c,:] -- the partial-sum format of stk_gn_param_grad_batch, so
+ *           up to two bias gradients (a convolution's and its shortcut peer's) are one more entry of that fold;
  *   dtemb   [n*temb_stride + c] = out_scale * sum_hw dx1[n,c,:]  (the time-embedding projection's gradient, written);
- *   dx_amax [256]: a planes scale record of dx1 by atomic maximum -- the caller ZEROES it before the launch (stk_fill_f32),
- *           max(dx_amax[0..256)) = max |dx1| afterwards.
- * Each may be NULL.  Shapes: stk_gn_bwd_out_ok (the register-resident backward: H*W a power of two >= 16, groups of at
- * most 16384 elements); 16-byte aligned tensors. */
+ *   dx_amax [256]: a planes scale record of dx1 by atomic maximum -- the caller ZEROES it before the launch
+ *           (stk_fill_strided_f32), max(dx_amax[0..256)) = max |dx1| afterwards.
+ * Shapes: stk_gn_bwd_out_ok (the register-resident backward: H*W a power of two >= 16, groups of at most 16384
+ * elements); 16-byte aligned tensors. */
 int stk_gn_bwd_out_ok(int C1, int C2, int HW, int G);
-int stk_gn_bwd_out_f32(const float* dy, const float* x1, int C1, const float* gamma, const float* beta,
-                       const float* mean, const float* rstd, float* dx1, float dx1_beta,
+int stk_gn_bwd_out_f32(const float* dy, const float* x1, int C1, const float* x2, int C2,
+                       const float* gamma, const float* beta, const float* mean, const float* rstd,
+                       float* dx1, float dx1_beta, float* dx2, float dx2_beta,
                        float* dgamma, float* dbeta, float* ws, int N, int HW, int G, int act, float drop_p,
                        unsigned long long seed, const unsigned long long* seed_dev,
+                       const float* dx1_add, float add_scale,
                        float* dx_sum, float out_scale, float* dtemb, int temb_stride, float* dx_amax, void* stream);
 
 /* The affine-parameter gradients of MANY GroupNorm layers in one launch.  stk_gn_bwd_f32 with dgamma == dbeta == NULL
@@ -337,8 +343,11 @@ int stk_axpby_f32(const float* a, float alpha, const float* b, float beta, float
 int stk_add_div_f32(const float* a, const float* b, float div, float* out, long n, void* stream);
 /* out = a*x + b */
 int stk_affine_f32(const float* x, float a, float b, float* out, long n, void* stream);
-/* out[0..n) = v  (the engine zeroes the atomic-maximum scale records of stk_gn_bwd_out_f32 with it) */
+/* out[0..n) = v */
 int stk_fill_f32(float* out, float v, long n, void* stream);
+/* out[i*stride + j] = v for i < count, j < len  (the engine zeroes the |dy| thirds of all its convolutions' amax buffers
+ * -- the atomic-maximum records of stk_gn_bwd_out_f32 -- with one launch) */
+int stk_fill_strided_f32(float* out, float v, long count, long len, long stride, void* stream);
 /* mode 0: out[p,2y+i,2x+j] = alpha*in[p,y,x] (+ beta*out)   (naive_upsample_2d, in [planes,H,W])
  * mode 1: out[p,y,x] = alpha*mean_{i,j} in[p,2y+i,2x+j] (+ beta*out) (naive_downsample_2d, in [planes,H,W]) */
 int stk_resample_naive_f32(const float* in, float* out, long planes, int H, int W, int mode,

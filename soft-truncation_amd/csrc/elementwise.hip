@@ -312,6 +312,17 @@ int stk_affine_f32(const float* x, float a, float b, float* out, long n, void* s
   return launch_ew(n, stk_aligned16(x) && stk_aligned16(out), Affine{x, a, b, out}, S(stream));
 }
 
+__global__ __launch_bounds__(256) void fill_strided_kernel(float* __restrict__ out, float v, long total, long len, long stride) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) out[(i / len) * stride + i % len] = v;
+}
+int stk_fill_strided_f32(float* out, float v, long count, long len, long stride, void* stream) {
+  if (!out || count < 0 || len < 0 || stride < len) return STK_EINVAL;
+  if (count * len == 0) return STK_OK;
+  hipLaunchKernelGGL(fill_strided_kernel, dim3((unsigned)stk_ew_grid(count * len)), dim3(256), 0, S(stream), out, v, count * len, len, stride);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+
 int stk_fill_f32(float* out, float v, long n, void* stream) {
   if (!out || n < 0) return STK_EINVAL;
   return launch_ew(n, stk_aligned16(out), Fill{v, out}, S(stream));

@@ -34,7 +34,8 @@ struct GnArgs {
 
 // optional by-products of the flat backward kernel (stk_gn_bwd_out_f32); all NULL = none
 struct GnBwdOut {
-  float* sum; float* temb; int temb_stride; float scale; float* amax;
+  float* sum; float* temb; int temb_stride; float scale; float* amax;     // by-products of the final dx1 values
+  const float* add; float add_scale;                                      // dx1 += add_scale * add  ([N, C1, HW])
 };
 
 // Segment decomposition of group (n, g): channels [c0, c1) -> part in x1, part in x2.
@@ -416,11 +417,16 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
         const float4 old = *reinterpret_cast<const float4*>(op);
         r[0] += ob * old.x; r[1] += ob * old.y; r[2] += ob * old.z; r[3] += ob * old.w;
       }
+      if (want && out.add && c < a.C1) {
+        const float4 ad = *reinterpret_cast<const float4*>(out.add + (((long)n * a.C1 + c) << hw_log2) + off);
+        r[0] += out.add_scale * ad.x; r[1] += out.add_scale * ad.y; r[2] += out.add_scale * ad.z; r[3] += out.add_scale * ad.w;
+      }
       *reinterpret_cast<float4*>(op) = make_float4(r[0], r[1], r[2], r[3]);
     }
     if (want) {
-      float rs = (r[0] + r[1]) + (r[2] + r[3]);
-      amax_l = fmaxf(amax_l, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
+      const bool mine = c < a.C1;                           // by-products cover dx1 only
+      float rs = mine ? (r[0] + r[1]) + (r[2] + r[3]) : 0.f;
+      if (mine) amax_l = fmaxf(amax_l, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
       for (int o = 0; o < seglog; ++o) rs += __shfl_xor(rs, 1 << o);
       if (valid && (lane & ((1 << seglog) - 1)) == 0) s_part[i >> seglog] = rs;     // s_part is free after the barrier above
     }
@@ -432,10 +438,11 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
     }
     __syncthreads();
     for (int cl = threadIdx.x; cl < a.cpg; cl += T) {
+      if (c0 + cl >= a.C1) continue;
       float t = 0.f;
       for (int q = 0; q < spc; ++q) t += s_part[cl * spc + q];
       t *= out.scale;
-      if (out.sum) { out.sum[((long)n * C + c0 + cl) * 2] = t; out.sum[((long)n * C + c0 + cl) * 2 + 1] = 0.f; }
+      if (out.sum) { out.sum[((long)n * a.C1 + c0 + cl) * 2] = t; out.sum[((long)n * a.C1 + c0 + cl) * 2 + 1] = t; }
       if (out.temb) out.temb[(long)n * out.temb_stride + c0 + cl] = t;
     }
     if (out.amax && threadIdx.x == 0) {
@@ -927,7 +934,7 @@ static inline bool gn_bwd_flat_shape(int C, int HW, int G) {
   const long L = (long)(C / G) * HW;
   return L <= 16384 && C / G <= 512 && !gn_split_ok(HW, C / G);
 }
-int stk_gn_bwd_out_ok(int C1, int C2, int HW, int G) { return C2 == 0 && gn_bwd_flat_shape(C1, HW, G) ? 1 : 0; }
+int stk_gn_bwd_out_ok(int C1, int C2, int HW, int G) { return C1 > 0 && C2 >= 0 && gn_bwd_flat_shape(C1 + C2, HW, G) ? 1 : 0; }
 
 static int gn_bwd_impl(const float* dy, const float* x1, int C1, const float* x2, int C2, const float* gamma,
                        const float* beta, const float* mean, const float* rstd, float* dx1, float dx1_beta, float* dx2,
@@ -938,19 +945,22 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
                    const float* beta, const float* mean, const float* rstd, float* dx1, float dx1_beta, float* dx2,
                    float dx2_beta, float* dgamma, float* dbeta, float* ws, int N, int HW, int G, int act, float drop_p,
                    unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
-  const GnBwdOut none = {nullptr, nullptr, 0, 1.f, nullptr};
+  const GnBwdOut none = {nullptr, nullptr, 0, 1.f, nullptr, nullptr, 0.f};
   return gn_bwd_impl(dy, x1, C1, x2, C2, gamma, beta, mean, rstd, dx1, dx1_beta, dx2, dx2_beta, dgamma, dbeta, ws, N, HW, G, act,
                      drop_p, seed, seed_dev, stream, none);
 }
 
-int stk_gn_bwd_out_f32(const float* dy, const float* x1, int C1, const float* gamma, const float* beta, const float* mean,
-                       const float* rstd, float* dx1, float dx1_beta, float* dgamma, float* dbeta, float* ws, int N, int HW,
-                       int G, int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+int stk_gn_bwd_out_f32(const float* dy, const float* x1, int C1, const float* x2, int C2, const float* gamma,
+                       const float* beta, const float* mean, const float* rstd, float* dx1, float dx1_beta, float* dx2,
+                       float dx2_beta, float* dgamma, float* dbeta, float* ws, int N, int HW, int G, int act, float drop_p,
+                       unsigned long long seed, const unsigned long long* seed_dev, const float* dx1_add, float add_scale,
                        float* dx_sum, float out_scale, float* dtemb, int temb_stride, float* dx_amax, void* stream) {
-  if (!dx1 || !stk_gn_bwd_out_ok(C1, 0, HW, G) || (dtemb && temb_stride < C1)) return STK_EINVAL;
-  if (!(stk_aligned16(x1) && stk_aligned16(dy) && stk_aligned16(dx1))) return STK_EUNSUPPORTED;
-  const GnBwdOut out = {dx_sum, dtemb, temb_stride, out_scale, dx_amax};
-  return gn_bwd_impl(dy, x1, C1, nullptr, 0, gamma, beta, mean, rstd, dx1, dx1_beta, nullptr, 0.f, dgamma, dbeta, ws, N, HW, G,
+  if (!dx1 || !stk_gn_bwd_out_ok(C1, C2, HW, G) || (dtemb && temb_stride < C1) || (C2 > 0 && !x2)) return STK_EINVAL;
+  if (!(stk_aligned16(x1) && stk_aligned16(dy) && stk_aligned16(dx1) && (!x2 || stk_aligned16(x2)) &&
+        (!dx2 || stk_aligned16(dx2)) && (!dx1_add || stk_aligned16(dx1_add))))
+    return STK_EUNSUPPORTED;
+  const GnBwdOut out = {dx_sum, dtemb, temb_stride, out_scale, dx_amax, dx1_add, add_scale};
+  return gn_bwd_impl(dy, x1, C1, x2, C2, gamma, beta, mean, rstd, dx1, dx1_beta, dx2, dx2_beta, dgamma, dbeta, ws, N, HW, G,
                      act, drop_p, seed, seed_dev, stream, out);
 }
 
@@ -990,7 +1000,7 @@ static int gn_bwd_impl(const float* dy, const float* x1, int C1, const float* x2
     const int ipt = stk_cdiv(L4, T);
 #define STK_GN_FLAT(IPT)                                                                                          \
   do {                                                                                                            \
-    if (out.sum || out.temb || out.amax)                                                                          \
+    if (out.sum || out.temb || out.amax || out.add)                                                               \
       hipLaunchKernelGGL((gn_bwd_flat_kernel<IPT, true>), dim3(N * G), dim3(T), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, \
                          dx1_beta, dx2, dx2_beta, ws, hw_log2, out);                                               \
     else                                                                                                          \

@@ -191,6 +191,7 @@ class GroupNormAct(Op):
     # gradient IS this layer's dx1, so the backward kernel leaves the bias / time-embedding sums and the |dy| scale
     # record behind (stk_gn_bwd_out_f32) and the convolution's backward makes no pass of its own over dy.
     self.dy_cons = None
+    self.add_from = None      # Graph._plan_res_via: the convolution whose output gradient / out_div this layer adds into dx1
 
   def _p(self, rt):
     return self.drop_p if rt.training else 0.0
@@ -219,18 +220,27 @@ class GroupNormAct(Op):
       dgamma = dbeta = None
       ws = rt.gnpart + 4 * self.fold_off
       rt.defer_fold(self.fold_index)
-    if cons is not None:
-      assert rt.gn_table and self.fold_index is not None, 'the by-products of the GroupNorm backward ride on the batched folds'
-      dsum = dtemb = None
-      if cons.bias is not None and rt.g(cons.bias) is not None:
-        dsum = rt.gnpart + 4 * cons.bsum_off
-        rt.defer_fold(cons.bsum_index)
-      if cons.temb is not None and cons.temb.needs_grad:
-        dtemb = rt.g(cons.temb) + 4 * cons.temb_col
-      rt.lib.gn_bwd_out_f32(rt.g(self.y), rt.v(self.x1), self.C1, rt.v(self.gamma), rt.v(self.beta_t), rt.v(self.mean),
-                            rt.v(self.rstd), rt.g(self.x1), self.b(self.x1), dgamma, dbeta, ws, self.N, self.HW, self.G,
+    adder = self.add_from
+    if cons is not None or adder is not None:
+      dsum = dtemb = damax = add = None
+      out_scale = add_scale = 1.0
+      tstride = 0
+      if cons is not None:
+        assert rt.gn_table, 'the by-products of the GroupNorm backward ride on the batched folds'
+        out_scale = 1.0 / cons.out_div
+        if cons.bsum_index is not None and rt.param_grads:
+          dsum = rt.gnpart + 4 * cons.bsum_off
+          rt.defer_fold(cons.bsum_index)
+        if cons.temb is not None and cons.temb.needs_grad:
+          dtemb, tstride = rt.g(cons.temb) + 4 * cons.temb_col, cons.temb_stride
+        damax = rt.v(cons.dy_peer.amax if cons.dy_peer is not None else cons.amax) + 4 * 512
+      if adder is not None:
+        add, add_scale = rt.g(adder.y), 1.0 / adder.out_div
+      rt.lib.gn_bwd_out_f32(rt.g(self.y), rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
+                            rt.v(self.mean), rt.v(self.rstd), rt.g(self.x1), self.b(self.x1), rt.g(self.x2),
+                            self.b(self.x2) if self.x2 is not None else 0.0, dgamma, dbeta, ws, self.N, self.HW, self.G,
                             self.act, self._p(rt), (rt.seed + 0x9E3779B1 * self.op_id) & 0xFFFFFFFFFFFFFFFF, rt.seed_dev,
-                            dsum, 1.0 / cons.out_div, dtemb, cons.temb_stride, rt.v(cons.dyrec), rt.stream)
+                            add, add_scale, dsum, out_scale, dtemb, tstride, damax, rt.stream)
       return
     rt.lib.gn_bwd_f32(rt.g(self.y), rt.v(self.x1), self.C1, rt.v(self.x2), self.C2,
                       rt.v(self.gamma), rt.v(self.beta_t), rt.v(self.mean), rt.v(self.rstd),
@@ -265,7 +275,9 @@ class Conv(Op):
     self.y = g.new((N, Cout, OH, OW), name=name)
     # partial |x1|, |x2|, |dy| maxima of the split kernels (include/stk.h "amax"): written by this layer's forward /
     # data-gradient calls, reused by its weight gradient; lives with the activations, i.e. per forward context
-    self.amax = g.new((768,), needs_grad=False, name=name + '.amax')
+    # (all layers' buffers are one contiguous block, placed by Graph.finalize: one strided fill zeroes every |dy| third)
+    self.amax = Tensor((768,), 'act', None, False, name + '.amax')
+    g.conv_amax.append(self.amax)
     self.inputs = (x1, x2, res)
     # algorithmic FLOPs of one launch (1 MAC = 2 FLOP); identical for fwd, dgrad and wgrad
     self.flops = 2.0 * N * OH * OW * Cout * (C1 + C2) * KH * KW
@@ -337,9 +349,12 @@ class Conv(Op):
   # this layer's bias / time-embedding sums and |dy| record behind; dyrec = that record (zeroed once per backward),
   # bsum_off / bsum_index = the partial-sum slot and fold-table entry of the bias gradient
   dy_prod = None
-  dyrec = None
   bsum_off = None
   bsum_index = None
+  # Graph._plan_res_via: this layer's residual input `res` is the block input x of out = (x + h) / out_div, and x is also
+  # what the block's first GroupNorm normalises: that layer's backward adds d(out) / out_div into d(x) on the way
+  # (stk_gn_bwd_out_f32 dx1_add), so this layer's backward does not touch d(res)
+  res_via = None
 
   # planes (include/stk.h "Planes"): decided by Graph.finalize
   pl_fwd = False       # the forward call reads x1 as planes
@@ -375,7 +390,7 @@ class Conv(Op):
       g.dypl_bytes = max(g.dypl_bytes, _round_up(int(lib.planes_bytes(self.N, self.Cout, self.OH * self.OW)), 256))
 
   def plan_backward(self):
-    if self.dy_peer is not None:                 # d(res) is never written: do not count this op as a writer of it
+    if self.dy_peer is not None or self.res_via is not None:      # d(res) is not written here: do not count this op as a writer
       saved, self.inputs = self.inputs, (self.x1, self.x2)
       Op.plan_backward(self)
       self.inputs = saved
@@ -419,12 +434,17 @@ class Conv(Op):
     fuse_rec = (pl_dgrad or pl_wgrad) and self.Cout <= 256 and (dtemb is not None or gb is not None)
     res_grad = self.res is not None and self.res.needs_grad
     peer = self.dy_peer
+    if self.res_via is not None:
+      res_grad = False                           # the block's first GroupNorm adds d(out) / out_div into d(x) itself
     if self.dy_prod is not None:
-      # the GroupNorm backward that produced dy left the sums (bias: batched fold; time embedding: written) and the record
+      # the GroupNorm backward that wrote dy last left the sums (bias: batched fold; time embedding: written) and the
+      # record behind -- for the shortcut peer too, whose buffer then holds the one record both layers read
       gb = dtemb = None
       fuse_rec = False
       rec_done = True
-      dy_rec = rt.v(self.dyrec)
+      if peer is not None:
+        dy_rec = rt.v(peer.amax) + 4 * 512
+        res_grad = False
     elif src is not None:
       # the peer's pass over dy already left our bias gradient and our |dy| record behind
       gb = dtemb = None
@@ -833,18 +853,18 @@ class RowScale(Op):
 
 
 class ZeroRecords(Op):
-  """Last op of the plan, i.e. first of the backward: zeroes the block of |dy| scale records that the GroupNorm backward
-  kernels fill by atomic maximum (Graph._plan_dy_producers)."""
+  """Last op of the plan, i.e. first of the backward: zeroes the |dy| third of every convolution's amax buffer -- the scale
+  records that the GroupNorm backward kernels fill by atomic maximum (Graph._plan_dy_producers) -- in one launch."""
 
-  def __init__(self, block):
-    self.block = block
+  def __init__(self, block, count):
+    self.block, self.count = block, count
     self.y = block
 
   def forward(self, rt):
     pass
 
   def backward(self, rt):
-    rt.lib.fill_f32(rt.v(self.block), 0.0, self.block.numel, rt.stream)
+    rt.lib.fill_strided_f32(rt.v(self.block) + 4 * 512, 0.0, self.count, 256, 768, rt.stream)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -858,6 +878,7 @@ class Graph:
     self.lib = lib                    # the backend the plan is made for (ops may ask it which kernels take a shape)
     self.ops = []
     self.tensors = []
+    self.conv_amax = []               # the convolutions' 768-float amax buffers (offsets assigned by finalize)
     self.act_size = 0
     self.gact_size = 0
     self.const_chunks = []
@@ -950,6 +971,9 @@ class Graph:
   def finalize(self, output, lib):
     self.output = output
     output.external_grad = True
+    self.amax_block = self.new((768 * max(len(self.conv_amax), 1),), needs_grad=False, name='conv.amax')
+    for i, t in enumerate(self.conv_amax):
+      t.off = self.amax_block.off + 768 * i
     for t in self.tensors:
       if t.needs_grad:
         t.goff = self.gact_size
@@ -972,8 +996,10 @@ class Graph:
       self._plan_f32_copies(lib)
     self._plan_shared_dy(lib)
     fold_batch = os.environ.get('STK_GN_FOLD_BATCH', '1') != '0' and hasattr(lib, 'gn_param_grad_batch')
-    if fold_batch:
-      self._plan_dy_producers(lib)
+    if hasattr(lib, 'gn_bwd_out_f32'):
+      self._plan_res_via(lib)
+      if fold_batch:
+        self._plan_dy_producers(lib)
     # deferred parameter-gradient folds: a slot of [N][C][2] partial sums per GroupNorm layer (and per convolution bias
     # served by a GroupNorm backward), table entries (slot offset, dgamma offset, dbeta offset, N, C) in backward order
     # (STK_GN_FOLD_BATCH=0: every layer folds its own sums -- a debugging switch, results are bit-identical)
@@ -991,53 +1017,87 @@ class Graph:
                                             2 * op.N * (op.C1 + op.C2)))
           self.gn_folds.append((op.fold_off, op.gamma.goff if op.gamma.needs_grad else None,
                                 op.beta_t.goff if op.beta_t.needs_grad else None, op.N, op.C1 + op.C2))
-        if cons is not None and cons.bias is not None and cons.bias.needs_grad:
-          cons.bsum_off = self.gnpart_size
-          cons.bsum_index = len(self.gn_folds)
-          self.gnpart_size += _round_up(2 * cons.N * cons.Cout)
-          self.gn_folds.append((cons.bsum_off, None, cons.bias.goff, cons.N, cons.Cout))
+        if cons is not None:
+          # one entry, two targets: component 0 -> the convolution's bias gradient, component 1 -> its shortcut peer's
+          own = cons.bias.goff if cons.bias is not None and cons.bias.needs_grad else None
+          peer = cons.dy_peer
+          other = peer.bias.goff if peer is not None and peer.bias is not None and peer.bias.needs_grad else None
+          if own is not None or other is not None:
+            cons.bsum_off = self.gnpart_size
+            cons.bsum_index = len(self.gn_folds)
+            self.gnpart_size += _round_up(2 * cons.N * cons.Cout)
+            self.gn_folds.append((cons.bsum_off, other, own, cons.N, cons.Cout))
     for op in reversed(self.ops):
       op.plan_backward()
     return self
 
-  def _plan_dy_producers(self, lib):
-    """ResnetBlockBigGANpp: h = Conv_0(...) + temb; h = act(GroupNorm_1(h)) (layerspp.py:273-278).  Conv_0's output has ONE
-    reader, the GroupNorm, so d(Conv_0 out) is exactly that layer's dx1: its register-resident backward kernel sums the
-    values it is about to store per (sample, channel) and takes their maximum, and Conv_0's backward needs no pass over
-    dy for its bias / time-embedding gradients and its planes' scale record (it went: read dy for the sums and maxima,
-    then read it again to split)."""
-    if os.environ.get('STK_DY_PRODUCER', '1') == '0' or not hasattr(lib, 'gn_bwd_out_f32'):
-      return
-    readers = {}
+  def _grad_writers(self):
+    """act tensor id -> ops that write its gradient, in FORWARD order (so [0] is the last writer of the backward)."""
+    w = {}
     for op in self.ops:
-      for v in vars(op).values():
-        if isinstance(v, Tensor) and v.space == 'act' and v.producer is not op:
-          readers.setdefault(id(v), []).append(op)
-    served = []
+      ins = op.inputs
+      if isinstance(op, Conv) and (op.dy_peer is not None or op.res_via is not None):
+        ins = (op.x1, op.x2)
+      seen = set()
+      for t in ins:
+        if t is not None and t.space == 'act' and t.needs_grad and id(t) not in seen:
+          seen.add(id(t))
+          w.setdefault(id(t), []).append(op)
+    return w
+
+  def _plan_res_via(self, lib):
+    """ResnetBlockBigGANpp without a shortcut convolution: out = (x + Conv_1(h)) / sqrt 2 with h = ... GroupNorm_0(x) ...
+    (layerspp.py:256-287) is planned as Conv_1 with res = x.  d(x) receives d(out) / sqrt 2 from the skip and the
+    GroupNorm_0 gradient; instead of Conv_1's backward writing the first in a pass of its own (read d(out), read-modify-
+    write d(x)) the GroupNorm backward -- which writes d(x) anyway -- adds it on the way (stk_gn_bwd_out_f32 dx1_add)."""
+    if os.environ.get('STK_RES_VIA', '1') == '0':
+      return
+    index = {id(op): i for i, op in enumerate(self.ops)}
+    for op in self.ops:
+      if not isinstance(op, Conv) or op.res is None or not op.res.needs_grad or op.dy_peer is not None:
+        continue
+      r = op.res
+      if r.shape != op.y.shape or r is op.x1 or r is op.x2 or op.y is self.output:
+        continue
+      for gn in self.ops:
+        if (isinstance(gn, GroupNormAct) and gn.x1 is r and gn.add_from is None and index[id(gn)] < index[id(op)] and
+            int(lib.gn_bwd_out_ok(gn.C1, gn.C2, gn.HW, gn.G))):
+          gn.add_from, op.res_via = op, gn
+          break
+
+  def _plan_dy_producers(self, lib):
+    """Who writes a convolution's output gradient LAST?  For the 3x3 convolutions of a ResnetBlockBigGANpp it is a
+    GroupNorm backward: Conv_0's output is read only by GroupNorm_1 (layerspp.py:273-278), and a block's output (Conv_1's)
+    is first read by the next block's GroupNorm_0, whose backward therefore runs after every other contribution to
+    d(out) has been accumulated.  That register-resident kernel sums the final values it stores per (sample, channel) and
+    takes their maximum (stk_gn_bwd_out_f32), so the convolution's backward needs no pass over dy for its bias / time-
+    embedding gradients and its planes' scale record (it went: read dy for sums and maxima, read it again to split) --
+    nor does its shortcut peer (_plan_shared_dy), which shares the record and the fold entry."""
+    if os.environ.get('STK_DY_PRODUCER', '1') == '0':
+      return
+    writers = self._grad_writers()
     for op in self.ops:
       if not isinstance(op, Conv) or not (op.pl_dgrad or op.pl_wgrad) or op.Cout > 256:
         continue
-      if op.res is not None or op.dy_peer is not None or op.dy_from is not None or op.y is self.output:
+      if op.dy_from is not None or op.y is self.output or not op.y.needs_grad:
         continue
+      if op.res is not None and op.res.needs_grad and op.dy_peer is None and op.res_via is None:
+        continue                                   # its pass over dy also writes d(res): nothing to save
       if op.bias is None and (op.temb is None or not op.temb.needs_grad):
         continue
       if op.w.needs_grad and not op.pl_wgrad:      # the fp32-operand weight gradient looks for the record in op.amax
         continue
-      rd = readers.get(id(op.y), [])
-      if len(rd) != 1 or not isinstance(rd[0], GroupNormAct):
+      ws = writers.get(id(op.y), [])
+      if not ws or not isinstance(ws[0], GroupNormAct):
         continue
-      gn = rd[0]
-      if gn.x1 is not op.y or gn.x2 is not None or gn.dy_cons is not None or not op.y.needs_grad:
+      gn = ws[0]
+      if gn.x1 is not op.y or gn.x2 is op.y or gn.dy_cons is not None:
         continue
-      if not int(lib.gn_bwd_out_ok(gn.C1, 0, gn.HW, gn.G)):
+      if not int(lib.gn_bwd_out_ok(gn.C1, gn.C2, gn.HW, gn.G)):
         continue
       gn.dy_cons, op.dy_prod = op, gn
-      served.append(op)
-    if served:
-      block = self.new((256 * len(served),), needs_grad=False, name='dyrecs')
-      for i, op in enumerate(served):
-        op.dyrec = Tensor((256,), 'act', block.off + 256 * i, False, op.y.name + '.dyrec')
-      self.ops.append(ZeroRecords(block))
+    if any(isinstance(op, GroupNormAct) and op.dy_cons is not None for op in self.ops):
+      self.ops.append(ZeroRecords(self.amax_block, len(self.conv_amax)))
 
   def _plan_shared_dy(self, lib):
     """ResnetBlockBigGANpp with a shortcut convolution: out = (Conv_2(x) + Conv_1(h)) / sqrt 2 (layerspp.py:283-287) is

@@ -34,7 +34,7 @@ SIGNATURES = {
   'stk_gn_bwd_f32': [P, P, I, P, I, P, P, P, P, P, F, P, F, P, P, P, I, I, I, I, F, U64, P, S],
   'stk_gn_bwd_out_ok': [I, I, I, I],
   'stk_conv2d_pl_ksplit': [I, I, I, I, I, I, I, I, I],
-  'stk_gn_bwd_out_f32': [P, P, I, P, P, P, P, P, F, P, P, P, I, I, I, I, F, U64, P, P, F, P, I, P, S],
+  'stk_gn_bwd_out_f32': [P, P, I, P, I, P, P, P, P, P, F, P, F, P, P, P, I, I, I, I, F, U64, P, P, F, P, F, P, I, P, S],
   'stk_gn_param_grad_batch': [P, I, I, S],
   'stk_conv2d_variant': [I, I, I, I, I, I, I, I, I, I, I, I, I, I],
   'stk_conv2d_fwd_ws_bytes': [I, I, I, I, I, I, I, I, I, I],
@@ -78,6 +78,7 @@ SIGNATURES = {
   'stk_add_div_f32': [P, P, F, P, L, S],
   'stk_affine_f32': [P, F, F, P, L, S],
   'stk_fill_f32': [P, F, L, S],
+  'stk_fill_strided_f32': [P, F, L, L, L, S],
   'stk_resample_naive_f32': [P, P, L, I, I, I, F, F, S],
   'stk_rowscale_f32': [P, P, P, I, L, I, S],
   'stk_timestep_embedding_f32': [P, P, P, I, I, S],

@@ -140,12 +140,17 @@ def test_planes_plumbing_on_checker(st, ref_lib):
   # Conv_0 of a ResnetBlock: its output gradient is GroupNorm_1's dx1, whose backward leaves the bias / time-embedding
   # sums and the |dy| record behind (stk_gn_bwd_out_f32); the plan ends with the op that zeroes those records
   served = [op for op in convs if op.dy_prod is not None]
-  assert served and all(op.dy_prod.dy_cons is op and op.temb is not None and op.bsum_index is not None for op in served)
+  assert served and all(op.dy_prod.dy_cons is op and op.bsum_index is not None for op in served)
+  assert any(op.temb is not None for op in served)                 # Conv_0 -> GroupNorm_1
+  assert any(op.temb is None and op.res is not None for op in served)   # a block's output -> the next block's GroupNorm_0
+  assert any(op.dy_peer is not None for op in served)              # ... with a shortcut peer sharing record and fold entry
+  # identity skips: the block's first GroupNorm adds d(out) / sqrt 2 into d(x) (no pass of Conv_1's backward over d(res))
+  assert any(op.res_via is not None and op.res_via.add_from is op for op in convs)
   assert all(isinstance(pr.graph.ops[-1], G.ZeroRecords) for pr in progs)
 
 
 def test_dy_producer_switch_off_gives_same_gradients(st, ref_lib, monkeypatch):
-  """STK_DY_PRODUCER=0 (every convolution sums and measures its own dy) against the default plan, on the checker: the
+  """STK_DY_PRODUCER=0 STK_RES_VIA=0 (every convolution sums and measures its own dy and writes d(res)) against the default plan, on the checker: the
   same parameter gradients (bias gradients through the batched fold, time-embedding gradients written by the GroupNorm
   backward) to rounding."""
   import torch
@@ -161,12 +166,14 @@ def test_dy_producer_switch_off_gives_same_gradients(st, ref_lib, monkeypatch):
   torch.manual_seed(0)
   g1 = grads()
   monkeypatch.setenv('STK_DY_PRODUCER', '0')
+  monkeypatch.setenv('STK_RES_VIA', '0')
   model.module.engine().programs.clear()
   torch.manual_seed(0)
   g0 = grads()
   assert g0.keys() == g1.keys()
-  for k in g0:
-    assert (g1[k] - g0[k]).abs().max().item() <= 2e-5 * max(g0[k].abs().max().item(), 1e-6), k
+  top = max(v.abs().max().item() for v in g0.values())
+  for k in g0:    # (floor: gradients that are zero analytically -- attention's key bias -- are rounding noise in both plans)
+    assert (g1[k] - g0[k]).abs().max().item() <= 2e-5 * max(g0[k].abs().max().item(), 1e-4 * top), k
 
 
 def test_input_gradient_only_backward_leaves_parameter_gradients_alone(st, ref_lib):

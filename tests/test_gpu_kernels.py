@@ -255,48 +255,54 @@ def test_groupnorm(ref_lib, hip_lib, case):
 
 
 GN_OUT_CASES = [
-  # N, C, H, G, act, p, beta1
-  (4, 128, 32, 32, 1, 0.1, 0.0),     # the 32x32 layers: IPT 4
-  (3, 256, 16, 32, 1, 0.0, 0.0),
-  (5, 256, 4, 32, 1, 0.1, 1.0),      # 4x4 maps, accumulating into dx1: the by-products come from the FINAL values
-  (2, 96, 8, 24, 0, 0.0, 0.0),
+  # N, C1, C2, H, G, act, p, beta1, add
+  (4, 128, 0, 32, 32, 1, 0.1, 0.0, False),    # the 32x32 layers: IPT 4
+  (3, 256, 0, 16, 32, 1, 0.0, 0.0, True),     # + the identity skip's gradient added on the way
+  (5, 256, 0, 4, 32, 1, 0.1, 1.0, True),      # 4x4 maps, accumulating into dx1: the by-products come from the FINAL values
+  (2, 96, 0, 8, 24, 0, 0.0, 0.0, False),
+  (3, 128, 128, 16, 32, 1, 0.1, 1.0, False),  # two sources (up path): by-products of dx1 only
+  (2, 256, 128, 8, 32, 1, 0.0, 1.0, True),    # groups of 12 straddle the two sources
 ]
 
 
 @pytest.mark.parametrize('case', GN_OUT_CASES, ids=str)
 def test_groupnorm_backward_byproducts(ref_lib, hip_lib, case):
-  """stk_gn_bwd_out_f32: dx1 as stk_gn_bwd_f32, plus the per-(sample, channel) sums of dx1 (fold-slot format and the
-  strided time-embedding gradient) and the atomic-maximum scale record, against the oracle."""
-  N, C, H, G, act, p, b1 = case
-  HW = H * H
-  x1 = rnd(N, C, H, H, seed=1) * 2 + 0.5
+  """stk_gn_bwd_out_f32: dx1 / dx2 as stk_gn_bwd_f32 (+ the added branch), plus the per-(sample, channel) sums of dx1
+  (fold-slot format and the strided time-embedding gradient) and the atomic-maximum scale record, against the oracle."""
+  N, C1, C2, H, G, act, p, b1, with_add = case
+  C, HW = C1 + C2, H * H
+  x1 = rnd(N, C1, H, H, seed=1) * 2 + 0.5
+  x2 = rnd(N, C2, H, H, seed=2) - 0.3 if C2 else None
   gamma, beta = rnd(C, seed=3) + 1, rnd(C, seed=4)
   dy = rnd(N, C, H, H, seed=5) * torch.logspace(-3, 0, N)[:, None, None, None]
-  d1 = rnd(N, C, H, H, seed=6)
-  seed, stride, col = 0xABCDEF12345, 2 * C + 5, 3
-  assert int(hip_lib.gn_bwd_out_ok(C, 0, HW, G)) == 1 and int(ref_lib.gn_bwd_out_ok(C, 0, HW, G)) == 1
+  d1, d2 = rnd(N, C1, H, H, seed=6), (rnd(N, C2, H, H, seed=7) if C2 else None)
+  add = rnd(N, C1, H, H, seed=8) if with_add else None
+  seed, stride, col = 0xABCDEF12345, 2 * C1 + 5, 3
+  assert int(hip_lib.gn_bwd_out_ok(C1, C2, HW, G)) == 1 and int(ref_lib.gn_bwd_out_ok(C1, C2, HW, G)) == 1
 
   def fn(lib, to):
     dev = dev_of(lib)
     y, mean, rstd = to(torch.zeros(N, C, H, H)), to(torch.zeros(N * G)), to(torch.zeros(N * G))
     sdev = torch.tensor([17], dtype=torch.int64, device=dev)
-    a1, ga, be = to(x1), to(gamma), to(beta)
+    a1, a2, ga, be = to(x1), to(x2), to(gamma), to(beta)
     ws = to(torch.zeros(max(int(lib.gn_ws_bytes(N, C, HW, G)) // 4, 2 * N * C)))
-    call(lib, 'gn_fwd_f32', a1, C, None, 0, ga, be, y, mean, rstd, N, HW, G, 1e-6, act, p, seed, sdev, ws)
-    dx1 = to(d1.clone())
-    dsum, dtemb, rec = to(torch.full((N, C, 2), 7.0)), to(torch.full((N * stride,), 7.0)), to(torch.zeros(256))
-    call(lib, 'gn_bwd_out_f32', to(dy), a1, C, ga, be, mean, rstd, dx1, b1, None, None, ws, N, HW, G, act, p, seed, sdev,
-         dsum, 0.5, dtemb[col:], stride, rec)
+    call(lib, 'gn_fwd_f32', a1, C1, a2, C2, ga, be, y, mean, rstd, N, HW, G, 1e-6, act, p, seed, sdev, ws)
+    dx1, dx2 = to(d1.clone()), (to(d2.clone()) if C2 else None)
+    dsum, dtemb, rec = to(torch.full((N, C1, 2), 7.0)), to(torch.full((N * stride,), 7.0)), to(torch.zeros(256))
+    call(lib, 'gn_bwd_out_f32', to(dy), a1, C1, a2, C2, ga, be, mean, rstd, dx1, b1, dx2, 1.0, None, None, ws, N, HW, G, act, p,
+         seed, sdev, to(add), 0.75, dsum, 0.5, dtemb[col:], stride, rec)
     dtemb = dtemb.view(N, stride)
-    return {'dx1': dx1, 'sum': dsum[:, :, 0].contiguous(), 'zero': dsum[:, :, 1].contiguous(),
-            'temb': dtemb[:, col:col + C].contiguous(), 'untouched': dtemb[:, :col].contiguous(),
-            'amax': rec.max().reshape(1), 'fold': ws[:2 * N * C].clone()}
+    o = {'dx1': dx1, 'sum': dsum[:, :, 0].contiguous(), 'sum2': dsum[:, :, 1].contiguous(),
+         'temb': dtemb[:, col:col + C1].contiguous(), 'untouched': dtemb[:, :col].contiguous(),
+         'amax': rec.max().reshape(1), 'fold': ws[:2 * N * C].clone()}
+    if C2:
+      o['dx2'] = dx2
+    return o
 
   out = both(ref_lib, hip_lib, fn)
   compare(out, 2e-5, 'groupnorm by-products')
-  got = out[1] if isinstance(out, (tuple, list)) else None
-  if got is not None:
-    assert float(got['amax']) == float(got['dx1'].abs().max())            # the record is exact, not approximate
+  got = out[1]
+  assert float(got['amax']) == float(got['dx1'].abs().max())            # the record is exact, not approximate
 
 
 # ---------------------------------------------------------------------------------------------------
