@@ -15,10 +15,13 @@ Extra objects in that line:
   roofline      the dominant contraction kernel (by total time), timed with HIP events on the launch stream:
                 achieved = algorithmic FLOPs per launch / average launch duration, against the ceiling of the
                 matrix pipe for the arithmetic that kernel runs: 2500 / 3 = 833 TFLOP/s fp32-equivalent for the
-                fp16 two-way-split kernels (three fp16 MFMAs per fp32 product; labels .x2 / .x2p), 2500 / 6 for
+                fp16 two-way-split kernels (three fp16 MFMAs per fp32 product; labels .x2 / .x2p...), 2500 / 6 for
                 the bf16 three-way-split ones (.x3), 157.3 for the f32-input MFMA kernels (MI355X_MICROARCH.md).
-                `kernels` lists the other contraction kernels the same way; `traffic` comes from the newest
-                committed PMC summary (profiles/rNN_traffic.json).
+                One label = one kernel symbol of the rocprofv3 summaries (KERNEL_SYMBOL below): .x2p = LDS-DMA GEMM on
+                plane operands, .x2p.k = its K-split form on small maps (partial slabs + slab sum; the bracket covers
+                both launches), .x2p.w32/.w16/.w8/.w4 = the planes weight gradient per map width (bracket = kernel +
+                its slab reduce).  `kernels` lists the other contraction kernels the same way; `traffic` comes from
+                the newest committed PMC summary (profiles/rNN_traffic.json).
   parity_probe  the benched build checks itself: per-sample soft-truncation losses of one batch-8 step on the HIP
                 engine against the oracle RefNet on identical weights and noise (N = 1 only).
   cpu_baseline  the oracle's PyTorch-CPU restatement of the same training step (RefNet + torch Adam + EMA) and of
@@ -41,9 +44,10 @@ import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)": the f32-input MFMA kernels (t64 / t128)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md dense bf16 MFMA peak
-# The x3 kernels (1x1 / small-map weight gradients) issue six bf16 MFMAs per fp32 product (three-way operand split), the
-# x2 kernels (forward, data gradient, 3x3 weight gradient) three fp16 MFMAs (two-way split of power-of-two-scaled operands; fp16 and bf16 MFMAs run at
-# the same rate): the fp32-equivalent ceiling of the matrix pipe is the 16-bit peak / 6 resp. / 3.
+# The x2 kernels (forward, data gradient and weight gradient of the 3x3 and 1x1 layers) issue three fp16 MFMAs per fp32
+# product (two-way split of power-of-two-scaled operands), the x3 kernels (kept for shapes the x2 ones do not take) six
+# bf16 MFMAs (three-way split); fp16 and bf16 MFMAs run at the same rate: the fp32-equivalent ceiling of the matrix pipe
+# is the 16-bit peak / 3 resp. / 6.
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 
@@ -424,8 +428,8 @@ def main():
       'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'arithmetic': 'fp32 tensors and fp32 accumulation everywhere; the large convolutions evaluate each fp32 product '
                     'from split operands on the 16-bit matrix pipe: power-of-two-scaled '
-                    'operands as two fp16 terms, 3 MFMAs (forward, data gradient, 3x3 weight gradient); three bf16 terms, 6 MFMAs '
-                    '(1x1 and small-map weight gradients) -- with errors at '
+                    'operands as two fp16 terms, 3 MFMAs per product (forward, data gradient and weight gradient of the '
+                    '3x3 and 1x1 layers) -- with errors at '
                     'the fp32 rounding level (arithmetic_check; parity-tested against the double-precision oracle at '
                     'the same tolerance as the f32-input MFMA path)',
       'config': {'workload': desc, 'per_gpu_batch': per_gpu_batch, 'global_batch': global_batch,
