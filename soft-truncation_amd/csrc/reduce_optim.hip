@@ -91,19 +91,6 @@ __global__ __launch_bounds__(256) void rowsum_block_kernel(const float* __restri
 // in flight per wave), writes the per-(n,c) sums when the caller wants them (time-embedding gradient) and the sixteen
 // per-wave totals meet in LDS in a fixed order.  One launch instead of rowsum + colsum (the second one was ~6 us of
 // pure launch latency, 144 times per training step).
-__device__ __forceinline__ float row_sum(const float* __restrict__ p, int HW, int lane, bool vec) {
-  float s = 0.f;
-  if (vec) {
-    const float4* p4 = reinterpret_cast<const float4*>(p);
-    for (int i = lane; i < (HW >> 2); i += 64) {
-      const float4 v = p4[i];
-      s += (v.x + v.y) + (v.z + v.w);
-    }
-  } else {
-    for (int i = lane; i < HW; i += 64) s += p[i];
-  }
-  return s;
-}
 // AMAX: also track max |dy| of the channel (the sums need every element anyway) and leave it in amax[c] -- a planes scale
 // record of the gradient tensor (include/stk.h "Planes") with one entry per channel, zero-filled up to 256 entries, so
 // the data-gradient call that follows needs no |dy| pass of its own.
