@@ -477,8 +477,8 @@ class Conv(Op):
     have = 1 if self._kind(lib, 'fwd').endswith('.x2') else 0
     if self.pl_fwd and not self.x_rec_own:
       have = 0                                   # x1's record lives with another layer: the weight gradient measures
-    if src is not None:
-      have |= 2                                  # the peer wrote our |dy| record
+    if src is not None or self.dy_prod is not None:
+      have |= 2                                  # the peer / the GroupNorm backward wrote our |dy| record
     if pl_dgrad or pl_wgrad:
       rec = dy_rec
       if not rec_done:
@@ -492,7 +492,8 @@ class Conv(Op):
                alpha, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self._wp(rt, 1), rt.ws, rt.ws_bytes, rt.stream)
       have |= 2
     elif g1 is not None or g2 is not None:
-      rt.timed(self._kind(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_rec_f32 if src is not None else lib.conv2d_dgrad_wp_f32,
+      rt.timed(self._kind(lib, 'dgrad'), self.flops,
+               lib.conv2d_dgrad_rec_f32 if (src is not None or self.dy_prod is not None) else lib.conv2d_dgrad_wp_f32,
                gy, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
                alpha, *self._dims(), self._wp(rt, 1), rt.v(self.amax), rt.ws, rt.ws_bytes, rt.stream)
@@ -1077,7 +1078,11 @@ class Graph:
       return
     writers = self._grad_writers()
     for op in self.ops:
-      if not isinstance(op, Conv) or not (op.pl_dgrad or op.pl_wgrad) or op.Cout > 256:
+      if not isinstance(op, Conv) or op.Cout > 256:
+        continue
+      # consumers: the plane-operand 3x3 layers, and the fp32-operand layers on the two-way split (NIN_3 of the attention
+      # blocks), whose data / weight gradient calls take the record in their own amax buffer (stk_conv2d_dgrad_rec_f32)
+      if not (op.pl_dgrad or op.pl_wgrad) and not (op.dy_peer is None and op._kind(lib, 'dgrad').endswith('.x2')):
         continue
       if op.dy_from is not None or op.y is self.output or not op.y.needs_grad:
         continue
@@ -1085,8 +1090,8 @@ class Graph:
         continue                                   # its pass over dy also writes d(res): nothing to save
       if op.bias is None and (op.temb is None or not op.temb.needs_grad):
         continue
-      if op.w.needs_grad and not op.pl_wgrad:      # the fp32-operand weight gradient looks for the record in op.amax
-        continue
+      if op.pl_dgrad and op.w.needs_grad and not op.pl_wgrad and op.dy_peer is not None:
+        continue                                   # an fp32-operand weight gradient looks for the record in op.amax, not the peer's
       ws = writers.get(id(op.y), [])
       if not ws or not isinstance(ws[0], GroupNormAct):
         continue
