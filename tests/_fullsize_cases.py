@@ -214,6 +214,17 @@ def baseline_config0(st, lib):
     progs = list(model.module.engine().programs.values())
     assert any(p.wp_counts[0] >= 80 and p.wp_counts[1] > p.wp_counts[0] for p in progs), \
         [p.wp_counts for p in progs]          # prepared-weight arena: ~90 forward blocks at batch 8 + the dgrad blocks
+    # the training plan: GroupNorm backward kernels serve (nearly) every 3x3 convolution's backward with its bias /
+    # time-embedding sums and |dy| record, shortcut peers included, and add the identity skips' gradients themselves
+    from importlib import import_module
+    G = import_module('soft-truncation_amd.engine.graph')
+    train = [p for p in progs if any(isinstance(op, G.ZeroRecords) for op in p.graph.ops)]
+    assert train, 'no program planned the GroupNorm-backward by-products'
+    convs = [op for op in train[0].graph.ops if isinstance(op, G.Conv)]
+    out['dy_served'] = sum(op.dy_prod is not None for op in convs)
+    out['res_via'] = sum(op.res_via is not None for op in convs)
+    assert out['dy_served'] >= 60 and out['res_via'] >= 15 and any(op.dy_prod is not None and op.dy_peer is not None for op in convs), \
+        (out['dy_served'], out['res_via'])
   return out
 
 
