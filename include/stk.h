@@ -238,6 +238,14 @@ int stk_gn_fwd_pl_f32(const float* x1, int C1, const float* x2, int C2, const fl
                       void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
                       float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream);
 int stk_gn_fwd_pl_fused(int C1, int C2, int HW, int G);
+/* stk_gn_fwd_pl_f32 on a one-pass shape (stk_gn_fwd_pl_fused) that also leaves the planes scale records of its SOURCE
+ * tensors behind -- for the ResnetBlock's 1x1 shortcut convolution, which reads the same tensors as fp32 operands of the
+ * split kernels (stk_conv2d_fwd_rec_f32): xmax1[0..256) / xmax2[0..256) receive max |x1| / max |x2| by atomic maximum;
+ * the caller zeroes them before the launch (stk_fill_strided_f32).  xmax2 may be NULL when C2 == 0. */
+int stk_gn_fwd_pl_max_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
+                          void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
+                          float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws,
+                          float* xmax1, float* xmax2, void* stream);
 long stk_planes_bytes(int N, int C, int HW);
 int stk_amax_partial_f32(const float* x, long n, float* part, void* stream);
 int stk_split_planes_f32(const float* x, int N, int C, int HW, const float* amax, int namax, void* planes, void* stream);
@@ -284,6 +292,12 @@ int stk_bias_grad_amax_res_f32(const float* dy, int N, int C, int HW, float alph
 int stk_bias_grad_amax_dual_f32(const float* dy, int N, int C, int HW, float alpha,
                                 float* dtemb, int temb_stride, float* dbias, float* amax,
                                 float* dbias2, float* amax2, float* ws, void* stream);
+/* stk_conv2d_fwd_wp_f32 whose amax[0..256) / amax[256..512) already hold the scale records of x1 / x2
+ * (stk_gn_fwd_pl_max_f32): the call makes no |x| pass of its own. */
+int stk_conv2d_fwd_rec_f32(const float* x1, int C1, const float* x2, int C2, const float* w, int w_layout,
+                           const float* bias, const float* temb, int temb_stride, const float* res, float out_div,
+                           float* y, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad,
+                           const void* wp, float* amax, void* ws, long ws_bytes, void* stream);
 int stk_conv2d_dgrad_rec_f32(const float* dy, const float* w, int w_layout,
                              float* dx1, int C1, float beta1, float* dx2, int C2, float beta2,
                              float alpha, int N, int H, int W, int Cout, int OH, int OW,

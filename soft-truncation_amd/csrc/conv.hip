@@ -936,7 +936,7 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
     if (amax) xpart = amax + (dgrad ? 2 * x2::NPART : 0);
     if (planes) {
       xpart = const_cast<float*>(planes_amax);      // the scale record the planes were written with
-    } else if (!(amax_valid && amax && S2 == 0)) {   // amax_valid: the caller's record already holds this operand's maxima
+    } else if (!(amax_valid && amax)) {   // amax_valid: the caller's record already holds this operand's maxima (both sources)
       hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s1, (long)p.N * S1 * p.HW, xpart);
       if (S2 > 0)
         hipLaunchKernelGGL(x2::amax_partial_kernel, dim3(x2::NPART), dim3(x2::AMAX_THREADS), 0, s, s2, (long)p.N * S2 * p.HW,
@@ -1142,10 +1142,31 @@ inline WgradPlan wgrad_plan(int Cin, int N, int Cout, int OH, int OW, int KH, in
 
 extern "C" {
 
+static int fwd_impl(const float* x1, int C1, const float* x2, int C2, const float* w, int w_layout,
+                    const float* bias, const float* temb, int temb_stride, const float* res, float out_div,
+                    float* y, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad,
+                    const void* wp, float* amax, void* ws, long ws_bytes, void* stream, bool x_rec_valid);
+
 int stk_conv2d_fwd_wp_f32(const float* x1, int C1, const float* x2, int C2, const float* w, int w_layout,
                           const float* bias, const float* temb, int temb_stride, const float* res, float out_div,
                           float* y, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad,
                           const void* wp, float* amax, void* ws, long ws_bytes, void* stream) {
+  return fwd_impl(x1, C1, x2, C2, w, w_layout, bias, temb, temb_stride, res, out_div, y, N, H, W, Cout, OH, OW, KH, KW, stride,
+                  pad, wp, amax, ws, ws_bytes, stream, false);
+}
+/* ... with the |x1| / |x2| scale records already in amax[0..256) / amax[256..512) (stk_gn_fwd_pl_max_f32): no |x| pass */
+int stk_conv2d_fwd_rec_f32(const float* x1, int C1, const float* x2, int C2, const float* w, int w_layout,
+                           const float* bias, const float* temb, int temb_stride, const float* res, float out_div,
+                           float* y, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad,
+                           const void* wp, float* amax, void* ws, long ws_bytes, void* stream) {
+  if (!amax) return STK_EINVAL;
+  return fwd_impl(x1, C1, x2, C2, w, w_layout, bias, temb, temb_stride, res, out_div, y, N, H, W, Cout, OH, OW, KH, KW, stride,
+                  pad, wp, amax, ws, ws_bytes, stream, true);
+}
+static int fwd_impl(const float* x1, int C1, const float* x2, int C2, const float* w, int w_layout,
+                    const float* bias, const float* temb, int temb_stride, const float* res, float out_div,
+                    float* y, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW, int stride, int pad,
+                    const void* wp, float* amax, void* ws, long ws_bytes, void* stream, bool x_rec_valid) {
   if (!x1 || !w || !y || (C2 > 0 && !x2) || out_div == 0.f || (w_layout != 0 && w_layout != 1) ||
       (w_layout == 1 && (KH != 1 || KW != 1)))
     return STK_EINVAL;
@@ -1178,7 +1199,7 @@ int stk_conv2d_fwd_wp_f32(const float* x1, int C1, const float* x2, int C2, cons
   }
   const X3Plan xr = x3_plan(p, p.Cin, C1, C2, Cout, Ng);
   if (ws && xr.ok && ws_bytes >= x3_ws_bytes(xr, Cout, p.Cin, p.taps))
-    return launch_x3<EpFwd>(p, xr, x1, C1, x2, C2, Cout, Ng, 0, ws, s, wp, amax);
+    return launch_x3<EpFwd>(p, xr, x1, C1, x2, C2, Cout, Ng, 0, ws, s, wp, amax, nullptr, nullptr, x_rec_valid);
   if (wp) return STK_EINVAL;      // prepared weights exist only for the shapes stk_conv2d_wp_bytes reports
   if (p.taps == 9) {
     using CB = Cfg<128, 128, 36>; using CS = Cfg<64, 64, 36>;

@@ -692,8 +692,10 @@ template <int PASSES>
 __global__ __launch_bounds__(1024) void gn_fwd_pl_kernel(GnArgs a, float* __restrict__ y, unsigned char* __restrict__ planes,
                                                          long plane_stride, float* __restrict__ rec,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                         float eps, float sqrt_lm1) {
+                                                         float eps, float sqrt_lm1, float* __restrict__ xmax1,
+                                                         float* __restrict__ xmax2) {
   __shared__ float red[16 * 4 * 4];       // [wave][q][lo sum, lo sumsq, hi sum, hi sumsq]
+  __shared__ float xm[16];                // per-wave max |x| (xmax by-product)
   __shared__ float gst[8 * 2];            // [group in block][mean, rstd]
   __shared__ float bnd[32];
   const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
@@ -735,7 +737,25 @@ __global__ __launch_bounds__(1024) void gn_fwd_pl_kernel(GnArgs a, float* __rest
 #pragma unroll
     for (int i = 0; i < 4; ++i) red[(wave * 4 + lane) * 4 + i] = s[i];
   }
+  if (xmax1) {
+    // by-product for the block's 1x1 shortcut convolution, which reads the same source tensors as fp32 operands of the
+    // split kernels: max |x| of this block, by atomic maximum into the 256-slot scale record of its source (zeroed by the
+    // caller; non-negative floats order like their bit patterns)
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[k][j]));
+    m = wave_max(m);
+    if (lane == 0) xm[wave] = m;
+  }
   __syncthreads();
+  if (xmax1 && tid == 0) {
+    float m = 0.f;
+    for (int w = 0; w < nw; ++w) m = fmaxf(m, xm[w]);
+    float* rec = c0 < a.C1 ? xmax1 : xmax2;
+    if (rec) atomicMax(reinterpret_cast<unsigned*>(rec) + (blockIdx.x & 255), __float_as_uint(m));
+  }
   if (tid < gb) {
     // pieces of group `tid`, in a fixed order: (q', half) with (8 q' + 4 half) / cpg == tid, over all waves
     float s0 = 0.f, s1 = 0.f;
@@ -887,9 +907,33 @@ int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float
 
 /* = stk_gn_fwd_f32 (y may be NULL when no consumer reads the fp32 copy) + stk_gn_bound_f32 (rec) +
  * stk_split_planes_f32 (planes), in one pass over x where the shape allows (gn_pl_fused_ok), else as those three. */
+static int gn_fwd_pl_impl(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
+                          void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
+                          float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream,
+                          float* xmax1, float* xmax2);
+
 int stk_gn_fwd_pl_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
                       void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
                       float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream) {
+  return gn_fwd_pl_impl(x1, C1, x2, C2, gamma, beta, y, planes, rec, mean, rstd, N, HW, G, eps, act, drop_p, seed, seed_dev, ws,
+                        stream, nullptr, nullptr);
+}
+
+/* stk_gn_fwd_pl_f32 on a shape the one-pass kernel takes (stk_gn_fwd_pl_fused) that also leaves the scale records of its
+ * SOURCE tensors behind: xmax1[0..256) / xmax2[0..256) receive max |x1| / max |x2| by atomic maximum (caller-zeroed). */
+int stk_gn_fwd_pl_max_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
+                          void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
+                          float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws,
+                          float* xmax1, float* xmax2, void* stream) {
+  if (!xmax1 || (C2 > 0 && !xmax2) || !gn_pl_fused_ok(C1, C2, HW, G)) return STK_EINVAL;
+  return gn_fwd_pl_impl(x1, C1, x2, C2, gamma, beta, y, planes, rec, mean, rstd, N, HW, G, eps, act, drop_p, seed, seed_dev, ws,
+                        stream, xmax1, xmax2);
+}
+
+static int gn_fwd_pl_impl(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
+                          void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
+                          float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream,
+                          float* xmax1, float* xmax2) {
   const int C = C1 + C2;
   if (!x1 || !gamma || !beta || !planes || !rec || !mean || !rstd || N <= 0 || HW <= 0 || G <= 0 || C1 <= 0 || C2 < 0 ||
       C % G || (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f)
@@ -911,7 +955,7 @@ int stk_gn_fwd_pl_f32(const float* x1, int C1, const float* x2, int C2, const fl
     const dim3 grid((unsigned)(N * (C / 32)));
 #define STK_GN_PL(P)                                                                                               \
   hipLaunchKernelGGL((gn_fwd_pl_kernel<P>), grid, dim3(T), 0, (hipStream_t)stream, a, y, static_cast<unsigned char*>(planes), \
-                     plane_stride, rec, mean, rstd, eps, sq)
+                     plane_stride, rec, mean, rstd, eps, sq, xmax1, xmax2)
     if (passes == 1) STK_GN_PL(1); else if (passes == 2) STK_GN_PL(2); else if (passes == 4) STK_GN_PL(4); else if (passes == 8) STK_GN_PL(8); else return STK_EUNSUPPORTED;
 #undef STK_GN_PL
     STK_CHECK_LAUNCH();

@@ -192,6 +192,9 @@ class GroupNormAct(Op):
     # record behind (stk_gn_bwd_out_f32) and the convolution's backward makes no pass of its own over dy.
     self.dy_cons = None
     self.add_from = None      # Graph._plan_res_via: the convolution whose output gradient / out_div this layer adds into dx1
+    # Graph._plan_x_records: the block's 1x1 shortcut convolution reads this layer's SOURCE tensors as fp32 operands of the
+    # split kernels; the one-pass forward leaves their |x| scale records in that convolution's amax buffer
+    self.xmax_for = None
 
   def _p(self, rt):
     return self.drop_p if rt.training else 0.0
@@ -204,6 +207,13 @@ class GroupNormAct(Op):
       # (one pass over x for the shapes the library fuses); the scale is the a-priori bound of the affine parameters.
       # The fp32 copy is written only if somebody reads it (the fused shapes accept y = NULL).
       need_f32 = y.f32_fwd or (rt.with_backward and y.f32_bwd) or not self.fused
+      cv = self.xmax_for
+      if cv is not None:
+        rt.lib.gn_fwd_pl_max_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
+                                 rt.v(y) if need_f32 else None, rt.planes(y), rt.rec(y), rt.v(self.mean), rt.v(self.rstd),
+                                 self.N, self.HW, self.G, self.eps, self.act, self._p(rt), seed, rt.seed_dev, rt.ws,
+                                 rt.v(cv.amax), rt.v(cv.amax) + 4 * 256 if self.x2 is not None else None, rt.stream)
+        return
       rt.lib.gn_fwd_pl_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
                            rt.v(y) if need_f32 else None, rt.planes(y), rt.rec(y), rt.v(self.mean), rt.v(self.rstd), self.N, self.HW, self.G,
                            self.eps, self.act, self._p(rt), seed, rt.seed_dev, rt.ws, rt.stream)
@@ -355,6 +365,7 @@ class Conv(Op):
   # what the block's first GroupNorm normalises: that layer's backward adds d(out) / out_div into d(x) on the way
   # (stk_gn_bwd_out_f32 dx1_add), so this layer's backward does not touch d(res)
   res_via = None
+  x_from = None        # Graph._plan_x_records: the GroupNorm whose forward leaves this layer's |x1| / |x2| records behind
 
   # planes (include/stk.h "Planes"): decided by Graph.finalize
   pl_fwd = False       # the forward call reads x1 as planes
@@ -408,7 +419,8 @@ class Conv(Op):
                rt.v(self.res), self.out_div, rt.v(self.y), self.N, self.H, self.W, self.Cout, self.KH, self.KW,
                self._wp(rt, 0), rt.ws, rt.ws_bytes, rt.stream)
       return
-    rt.timed(self._kind(rt.lib, 'fwd'), self.flops, rt.lib.conv2d_fwd_wp_f32,
+    rt.timed(self._kind(rt.lib, 'fwd'), self.flops,
+             rt.lib.conv2d_fwd_rec_f32 if self.x_from is not None else rt.lib.conv2d_fwd_wp_f32,
              rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.w), self.w_layout,
              rt.v(self.bias), temb, self.temb_stride, rt.v(self.res), self.out_div,
              rt.v(self.y), *self._dims(), self._wp(rt, 0), rt.v(self.amax), rt.ws, rt.ws_bytes, rt.stream)
@@ -853,6 +865,21 @@ class RowScale(Op):
     return 4 * self.x.numel
 
 
+class ZeroXRecords(Op):
+  """First op of the plan: zeroes the |x1| / |x2| thirds of every convolution's amax buffer -- the records the GroupNorm
+  forward kernels fill by atomic maximum (Graph._plan_x_records); every other user writes its record after this."""
+
+  def __init__(self, block, count):
+    self.block, self.count = block, count
+    self.y = block
+
+  def forward(self, rt):
+    rt.lib.fill_strided_f32(rt.v(self.block), 0.0, self.count, 512, 768, rt.stream)
+
+  def backward(self, rt):
+    pass
+
+
 class ZeroRecords(Op):
   """Last op of the plan, i.e. first of the backward: zeroes the |dy| third of every convolution's amax buffer -- the scale
   records that the GroupNorm backward kernels fill by atomic maximum (Graph._plan_dy_producers) -- in one launch."""
@@ -995,6 +1022,7 @@ class Graph:
         if isinstance(op, Conv):
           op.plan_planes(self, lib)
       self._plan_f32_copies(lib)
+      self._plan_x_records(lib)
     self._plan_shared_dy(lib)
     fold_batch = os.environ.get('STK_GN_FOLD_BATCH', '1') != '0' and hasattr(lib, 'gn_param_grad_batch')
     if hasattr(lib, 'gn_bwd_out_f32'):
@@ -1031,6 +1059,27 @@ class Graph:
     for op in reversed(self.ops):
       op.plan_backward()
     return self
+
+  def _plan_x_records(self, lib):
+    """ResnetBlockBigGANpp with a shortcut: GroupNorm_0 and the 1x1 Conv_2 read the same (two-source) block input
+    (layerspp.py:256, 283).  Conv_2 takes it as fp32 operands of the split kernel and would measure |x1|, |x2| first (two
+    passes); GroupNorm_0's one-pass forward -- which runs first and holds those values in registers -- leaves the maxima
+    in Conv_2's amax buffer instead (stk_gn_fwd_pl_max_f32 / stk_conv2d_fwd_rec_f32; the weight gradient reuses them)."""
+    if os.environ.get('STK_X_RECORDS', '1') == '0' or not hasattr(lib, 'gn_fwd_pl_max_f32'):
+      return
+    index = {id(op): i for i, op in enumerate(self.ops)}
+    found = False
+    for op in self.ops:
+      if not isinstance(op, Conv) or op.pl_fwd or op.x_from is not None or not op._kind(lib, 'fwd').endswith('.x2'):
+        continue
+      for gn in self.ops:
+        if (isinstance(gn, GroupNormAct) and gn.x1 is op.x1 and gn.x2 is op.x2 and gn.fused and gn.y.pl_maker is gn and
+            gn.xmax_for is None and index[id(gn)] < index[id(op)]):
+          gn.xmax_for, op.x_from = op, gn
+          found = True
+          break
+    if found:
+      self.ops.insert(0, ZeroXRecords(self.amax_block, len(self.conv_amax)))
 
   def _grad_writers(self):
     """act tensor id -> ops that write its gradient, in FORWARD order (so [0] is the last writer of the backward)."""

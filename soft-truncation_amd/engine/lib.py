@@ -45,6 +45,7 @@ SIGNATURES = {
   'stk_conv2d_wp_desc': [I, P, I, I, I, I, I, P, P],
   'stk_conv2d_wprep_batch': [P, I, L, S],
   'stk_conv2d_fwd_wp_f32': [P, I, P, I, P, I, P, P, I, P, F, P, I, I, I, I, I, I, I, I, I, I, P, P, P, L, S],
+  'stk_conv2d_fwd_rec_f32': [P, I, P, I, P, I, P, P, I, P, F, P, I, I, I, I, I, I, I, I, I, I, P, P, P, L, S],
   'stk_conv2d_dgrad_wp_f32': [P, P, I, P, I, F, P, I, F, F, I, I, I, I, I, I, I, I, I, I, P, P, P, L, S],
   'stk_conv2d_dgrad_rec_f32': [P, P, I, P, I, F, P, I, F, F, I, I, I, I, I, I, I, I, I, I, P, P, P, L, S],
   'stk_conv2d_wgrad_ws_bytes': [I, I, I, I, I, I, I, I],
@@ -53,6 +54,7 @@ SIGNATURES = {
   'stk_gn_bound_f32': [P, P, I, I, I, F, P, S],
   'stk_gn_fwd_pl_f32': [P, I, P, I, P, P, P, P, P, P, P, I, I, I, F, I, F, U64, P, P, S],
   'stk_gn_fwd_pl_fused': [I, I, I, I],
+  'stk_gn_fwd_pl_max_f32': [P, I, P, I, P, P, P, P, P, P, P, I, I, I, F, I, F, U64, P, P, P, P, S],
   'stk_planes_bytes': [I, I, I],
   'stk_amax_partial_f32': [P, L, P, S],
   'stk_split_planes_f32': [P, I, I, I, P, I, P, S],

@@ -237,6 +237,48 @@ def test_gn_forward_to_planes(ref_lib, hip_lib, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case', [(4, 128, 128, 32, 128), (3, 256, 0, 16, 256), (6, 256, 256, 4, 256), (2, 128, 0, 8, 256)], ids=str)
+def test_gn_forward_leaves_source_records_for_the_shortcut(ref_lib, hip_lib, case):
+  """stk_gn_fwd_pl_max_f32: the planes of stk_gn_fwd_pl_f32 bit for bit, plus max |x1| / max |x2| in caller-zeroed
+  records (exact); stk_conv2d_fwd_rec_f32 on those records == stk_conv2d_fwd_wp_f32 measuring them itself, bit for bit
+  (the 1x1 shortcut convolution of a ResnetBlock reads the block input the GroupNorm has just read)."""
+  N, C1, C2, H, Cout = case
+  C, HW, G = C1 + C2, H * H, 32
+  x1 = rnd(N, C1, H, H, seed=1) * torch.logspace(-2, 1, N)[:, None, None, None]
+  x2 = rnd(N, C2, H, H, seed=2) * 3 if C2 else None
+  gamma, beta = rnd(C, seed=3) * 0.5 + 1.0, rnd(C, seed=4) * 0.2
+  w, bias = rnd(Cout, C, 1, 1, seed=5) * 0.05, rnd(Cout, seed=6)
+  for lib in (ref_lib, hip_lib):
+    d = dev_of(lib)
+    to = lambda t: None if t is None else t.to(d)
+    assert int(lib.gn_fwd_pl_fused(C1, C2, HW, G)) == 1
+    mean, rstd = torch.zeros(N * G, device=d), torch.zeros(N * G, device=d)
+    rec, rec2 = torch.zeros(256, device=d), torch.zeros(256, device=d)
+    pl = torch.zeros(int(lib.planes_bytes(N, C, HW)), dtype=torch.uint8, device=d)
+    pl2 = torch.zeros_like(pl)
+    ws = torch.zeros(int(lib.gn_ws_bytes(N, C, HW, G)) // 4 + 64, device=d)
+    amax = torch.zeros(768, device=d)
+    call(lib, 'gn_fwd_pl_f32', to(x1), C1, to(x2), C2, to(gamma), to(beta), None, pl, rec, mean, rstd, N, HW, G, 1e-6, 1,
+         0.0, 1, None, ws)
+    call(lib, 'gn_fwd_pl_max_f32', to(x1), C1, to(x2), C2, to(gamma), to(beta), None, pl2, rec2, mean, rstd, N, HW, G, 1e-6, 1,
+         0.0, 1, None, ws, amax, amax[256:] if C2 else None)
+    assert torch.equal(pl, pl2) and torch.equal(rec, rec2)
+    assert float(amax[:256].max()) == float(x1.abs().max())
+    if C2:
+      assert float(amax[256:512].max()) == float(x2.abs().max())
+    assert float(amax[512:].abs().max()) == 0.0
+    # the shortcut convolution on those records
+    dims = (N, H, H, Cout, H, H, 1, 1, 1, 0)
+    fb = int(lib.conv2d_fwd_ws_bytes(C1, C2, N, H, H, Cout, 1, 1, 1, 0))
+    cws = torch.zeros(fb // 4 + 64, device=d)
+    y_rec, y_own = torch.zeros(N, Cout, H, H, device=d), torch.zeros(N, Cout, H, H, device=d)
+    own = torch.zeros(768, device=d)
+    call(lib, 'conv2d_fwd_rec_f32', to(x1), C1, to(x2), C2, to(w), 0, to(bias), None, 0, None, 1.0, y_rec, *dims, None, amax, cws, fb)
+    call(lib, 'conv2d_fwd_wp_f32', to(x1), C1, to(x2), C2, to(w), 0, to(bias), None, 0, None, 1.0, y_own, *dims, None, own, cws, fb)
+    assert torch.equal(y_rec, y_own)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('case', [(8, 128, 1024), (5, 256, 64), (3, 96, 256), (2, 64, 4096)], ids=str)
 def test_bias_grad_with_scale_record(ref_lib, hip_lib, case):
   """stk_bias_grad_amax_f32: the bias / time-embedding gradients of stk_bias_grad_f32 plus the per-channel |dy| maxima
