@@ -452,7 +452,7 @@ def main():
         traffic, traffic_src = traffic_of(dom)
         out['roofline'] = {'bound': 'mfma', 'achieved': a['tflops'], 'peak': kernel_peak(dom), 'unit': 'TFLOP/s',
                            'frac': a['tflops'] / kernel_peak(dom), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
-                           'traffic_source': traffic_src, 'kernel': dom,
+                           'traffic_source': traffic_src, 'kernel': dom, 'symbol': KERNEL_SYMBOL.get(dom),
                            'peak_note': ('bf16 MFMA dense peak / 6 products per fp32 product' if dom.endswith('.x3')
                                          else 'fp16 MFMA dense peak / 3 products per fp32 product' if kernel_peak(dom) == PEAK_X2_TFLOPS
                                          else 'f32-input MFMA peak'),

@@ -17,7 +17,7 @@ def tiny_config(st, family, dropout=0.0, device='cpu'):
     cfg = st.configs.tiny(st.configs.celeba_uncsnpp_st(), dropout=dropout)
   elif family == 've':      # NCSN++ 256-style: fourier, FIR, input_skip / output_skip, VE SDE
     cfg = st.configs.tiny(st.configs.celebahq_uncsnpp_st(), ch_mult=(1, 1, 2), dropout=dropout)
-  elif family == 'wide':    # DDPM++ with enough channels (96 / 192) for the bf16-split conv kernels, their K-split and
+  elif family == 'wide':    # DDPM++ with enough channels (96 / 192) for the split (fp16 two-way) conv kernels, their K-split and
     # few-tile variants and the prepared-weight path; the other families stay on the f32-input kernels
     cfg = st.configs.tiny(st.configs.cifar10_ddpmpp_nll_st(), nf=96, ch_mult=(1, 2), num_res_blocks=1, image_size=16,
                           attn_resolutions=(8,), dropout=dropout)

@@ -66,7 +66,7 @@ def test_golden_sampler_registry(st, hip_lib):
 
 
 def test_forward_backward_wide(st, hip_lib):
-  """96 / 192 channels, batch 96: the bf16-split kernels (direct, K-split, few-tile), the 1x1 split layers and the
+  """96 / 192 channels, batch 96: the split-operand kernels (direct, K-split, few-tile), the 1x1 split layers and the
   prepared-weight path inside the engine, against the oracle RefNet."""
   cases.forward_backward(st, hip_lib, 'wide', B=96)
   ex_variants = {int(hip_lib.conv2d_variant(d, 96, 0, 96, 16, 16, 96, 16, 16, 3, 3, 1, 1, 0)) for d in (0, 1, 2)}
