@@ -22,3 +22,11 @@ for a, b in list(zip(adam, adam[1:]))[-5:]:
   print(f'step: wall {wall / 1e6:.3f} ms  busy {busy / 1e6:.3f} ms  idle {(wall - busy) / 1e6:.3f} ms  kernels {len(w) - 1}')
   for g in gaps[:8]:
     print(f'    {g[0] / 1e3:8.1f} us between {g[1]}  ->  {g[2]}')
+
+# context of the largest gap of the last step: the kernels around it with their start offsets
+a, b = adam[-2], adam[-1]
+w = ev[a:b + 1]
+gi = max(range(len(w) - 1), key=lambda i: w[i + 1][0] - w[i][1])
+print('around the largest gap of the last step (start offset us, duration us, kernel):')
+for e in w[max(0, gi - 8):gi + 6]:
+  print(f'    {(e[0] - w[gi][1]) / 1e3:10.1f} {(e[1] - e[0]) / 1e3:8.1f}  {e[2]}')
