@@ -34,6 +34,8 @@ def _timed_sync(self):
   t0 = time.perf_counter()
   r = _orig_sync(self)
   acc['evsync'] += time.perf_counter() - t0
+  acc['drained'] = acc.get('drained', 0) + int(torch.cuda.current_stream().query())      # is the whole queue done already?
+  acc['syncs'] = acc.get('syncs', 0) + 1
   return r
 
 
@@ -55,7 +57,7 @@ batch = st.datasets.synthetic_batch(cfg, B).to(device)
 for _ in range(5):
   step_fn(state, batch)
 torch.cuda.synchronize()
-acc.update(fwd=0.0, bwd=0.0, evsync=0.0)
+acc.update(fwd=0.0, bwd=0.0, evsync=0.0, drained=0, syncs=0)
 host = 0.0
 t_all = time.perf_counter()
 for _ in range(steps):
@@ -65,4 +67,5 @@ for _ in range(steps):
 torch.cuda.synchronize()
 wall = time.perf_counter() - t_all
 print(f'steps {steps}: wall {wall / steps * 1e3:.2f} ms/step; host inside step_fn {host / steps * 1e3:.2f} ms/step, of which inside the '
-      f'forward replay {acc["fwd"] / steps * 1e3:.2f}, the backward replay {acc["bwd"] / steps * 1e3:.2f}, waiting for the loss copy {acc["evsync"] / steps * 1e3:.2f}')
+      f'forward replay {acc["fwd"] / steps * 1e3:.2f}, the backward replay {acc["bwd"] / steps * 1e3:.2f}, waiting for the loss copy {acc["evsync"] / steps * 1e3:.2f}; '
+      f'stream already idle when that wait returned: {acc["drained"]} of {acc["syncs"]} times')
