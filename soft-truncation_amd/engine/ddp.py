@@ -136,6 +136,22 @@ def arm_overlap(model, bucket_mb=None):
   return x
 
 
+def disarm_overlap(model):
+  """Drop whatever :func:`arm_overlap` left armed for `model` (a step that raised before ``sync_gradients``): the
+  executor's hook is cleared and outstanding handles are waited for, so the next step starts clean."""
+  net = getattr(model, 'module', model)
+  engine = getattr(net, 'engine', None)
+  if engine is None:
+    return
+  ex = engine()
+  ex.grad_hook = None
+  x = _armed.pop(id(ex.flat), None) if ex.flat is not None else None
+  if x is not None:
+    for h in x.handles:
+      h.wait()
+    x.handles, x.covered = [], []
+
+
 def sync_gradients(optimizer, params=None, bucket_mb=64.0):
   """Average gradients across ranks before clipping (no-op in a single process).
 

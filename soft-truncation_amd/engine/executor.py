@@ -22,6 +22,7 @@ import contextlib
 import ctypes
 import os
 import warnings
+import weakref
 
 import numpy as np
 import torch
@@ -55,7 +56,7 @@ class _GnFoldDesc(ctypes.Structure):       # StkGnFoldDesc of include/stk.h
 
 class Context:
   """Buffers of one forward call, kept until its backward has run."""
-  __slots__ = ('prog', 'act', 'gact', 'rt', 'released', 'seed_t', 'graphs', 'uses', 'pl')
+  __slots__ = ('prog', 'act', 'gact', 'rt', 'released', 'seed_t', 'graphs', 'uses', 'pl', '__weakref__')
 
   def __init__(self, prog):
     self.prog = prog
@@ -210,6 +211,7 @@ class _NetFn(torch.autograd.Function):
     # grad mode is OFF inside autograd.Function.forward: say explicitly that a backward will follow
     out, c = ex.run_forward(x, emb_in, sigma, training, need_xgrad, with_backward=True, flat=ex.flat)
     ctx.ex, ctx.c, ctx.need_xgrad = ex, c, need_xgrad
+    ex._awaiting.add(c)       # a backward of this evaluation may still come (dropped with the autograd graph otherwise)
     return out
 
   @staticmethod
@@ -249,6 +251,11 @@ class Executor:
     # into segments and calls grad_hook(lo, hi) as soon as a bucket [lo, hi) of the flat gradient buffer is final
     self.grad_hook = None
     self.grad_bucket_elems = 16 << 20
+    # network evaluations made under grad mode whose backward has not run yet (weak: an evaluation whose autograd graph
+    # is dropped without a backward disappears by itself).  A step that evaluates the network more than once per loss
+    # (training.mixed, the reconstruction term: losses.py:134-164, 295-320) runs one engine backward per evaluation inside
+    # ONE .backward(); buckets may only leave with the last of them.
+    self._awaiting = weakref.WeakSet()
 
   # -- parameters ---------------------------------------------------------------------------------
   def set_backend(self, backend):
@@ -256,7 +263,7 @@ class Executor:
     self.programs.clear()
 
   def ensure_flat(self):
-    if self.flat is not None and self.flat.quick_ok():      # sentinel check; the full walk below every 64th call
+    if self.flat is not None and self.flat.is_bound():      # every parameter, raw addresses only (~150 us)
       return self.flat
     params = list(self.model.parameters())
     device = params[0].device
@@ -385,6 +392,10 @@ class Executor:
   def run_forward(self, x, emb_in, sigma, training, need_xgrad, with_backward=False, flat=None):
     if flat is None:                      # apply() has just checked the layout: one walk over the ~570 parameters per call
       flat = self.ensure_flat()
+    with stk_lib.device_guard(flat.device):
+      return self._run_forward(x, emb_in, sigma, training, need_xgrad, with_backward, flat)
+
+  def _run_forward(self, x, emb_in, sigma, training, need_xgrad, with_backward, flat):
     B, _, H, W = x.shape
     prog = self.program(B, H, W, need_xgrad)
     c = prog.acquire()
@@ -420,15 +431,25 @@ class Executor:
     return out, c
 
   def run_backward(self, c, gout, param_grads=True):
+    with stk_lib.device_guard(self.flat.device):
+      return self._run_backward(c, gout, param_grads)
+
+  def _run_backward(self, c, gout, param_grads):
     prog, g, rt = c.prog, c.prog.graph, c.rt
     rt.param_grads = param_grads
     flat = self.flat
+    self._awaiting.discard(c)
     if c.gact is None:
       c.gact = _arena(g.gact_size, prog.device)
     o = g.output
     c.gact[o.goff:o.goff + o.numel].view(o.shape).copy_(gout)
     done = False
     hook = self.grad_hook if param_grads else None      # nothing to exchange after an input-gradient-only backward
+    if hook is not None and len(self._awaiting) > 0:
+      # another evaluation of this step still owes its backward (it accumulates into the same flat buffer): a bucket
+      # handed over now would be reduced before that contribution arrives.  Plain backward; the LAST pending one hands
+      # the buckets over (or OverlappedExchange.finish() reduces what nobody handed over).
+      hook = None
     if hook is not None:
       # overlapped exchange: segment by segment, handing finished buckets to the hook (which starts their all-reduce
       # on the communicator's stream, ordered behind the launches made so far)
@@ -442,7 +463,7 @@ class Executor:
       order = list(reversed(g.ops))
       begin = 0
       for end, ranges in segs:
-        if end > begin:
+        if end > begin and any(op.bwd_launches() for op in order[begin:end]):      # a span without launches is skipped
           if not (graphs and self._replay(c, 'bwd', rt.training, (begin, end))):
             if graphs:            # capture failed half way: finish eagerly with a consistent runtime
               graphs = False

@@ -165,6 +165,13 @@ class Op:
   def ws_bytes(self, lib):
     return 0
 
+  def bwd_launches(self):
+    """False when this op's backward is known at plan time to launch nothing (the executor does not capture / replay
+    a backward segment made of such ops only)."""
+    xs = [t for t in self.inputs if t is not None]
+    return not xs or any(t.needs_grad for t in xs) or any(
+      isinstance(v, Tensor) and v.space == 'param' and v.needs_grad for v in vars(self).values())
+
 
 # ------------------------------------------------------------------------------------------------
 # ops
@@ -612,6 +619,9 @@ class TimestepEmbedding(Op):
   def backward(self, rt):
     pass
 
+  def bwd_launches(self):
+    return False
+
 
 class FourierEmbedding(Op):
   """GaussianFourierProjection (models/layerspp.py:45-54); W is frozen (requires_grad=False)."""
@@ -626,6 +636,9 @@ class FourierEmbedding(Op):
 
   def backward(self, rt):
     pass
+
+  def bwd_launches(self):
+    return False
 
 
 class Affine(Op):
@@ -878,6 +891,9 @@ class ZeroXRecords(Op):
 
   def backward(self, rt):
     pass
+
+  def bwd_launches(self):
+    return False
 
 
 class ZeroRecords(Op):

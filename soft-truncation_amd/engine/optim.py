@@ -43,7 +43,7 @@ class FusedAdam(torch.optim.Optimizer):
 
   def _bind(self):
     params = self.param_groups[0]['params']
-    flat = flat_of(params)
+    flat = flat_of(params, full=self._flat is None)      # every parameter at construction, a sample per step
     if flat is None:
       raise RuntimeError('FusedAdam needs parameters backed by engine.flat.FlatParams '
                          '(create the model with models.utils.create_model)')
@@ -74,7 +74,7 @@ class FusedAdam(torch.optim.Optimizer):
   def zero_grad(self, set_to_none=False):
     """Zero the flat gradient buffer in place (the `.grad` views must stay bound)."""
     flat = self._bind()
-    if not flat.quick_ok():
+    if not flat.grads_bound():       # e.g. one `p.grad = None`, or torch's zero_grad(set_to_none=True) on the model
       flat.rebind_grads()
     flat.grad.zero_()
 

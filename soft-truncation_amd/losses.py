@@ -208,18 +208,22 @@ def get_step_fn(config, sde, train, optimize_fn=None):
 
   def step_fn(state, batch):
     model, optimizer = state['model'], state['optimizer']
-    if train:
-      optimizer.zero_grad()
-      n, parts = batch.shape[0], config.optim.num_micro_batch
-      per = n // parts
-      out_per = per // 2 if mixed else per
-      losses_ = torch.zeros(n // 2 if mixed else n)
-      t_min = sde.get_t_min(config)
-      pinned, copied = None, None
+    if not train:
+      # the reference has no evaluation branch either: its `return losses_` raises exactly this (losses.py:279-293)
+      raise UnboundLocalError("local variable 'losses_' referenced before assignment")
+    optimizer.zero_grad()
+    n, parts = batch.shape[0], config.optim.num_micro_batch
+    per = n // parts
+    out_per = per // 2 if mixed else per
+    losses_ = torch.zeros(n // 2 if mixed else n)
+    t_min = sde.get_t_min(config)
+    pinned, copied = None, None
+    try:
       for k in range(parts):
         losses = micro_losses(model, batch[per * k: per * (k + 1)], t_min)
         if k == parts - 1 and OVERLAP_EXCHANGE:
-          # multi-GPU: buckets of the flat gradient buffer are all-reduced as the last backward finishes them
+          # multi-GPU: buckets of the flat gradient buffer are all-reduced as the last backward finishes them (with
+          # several network evaluations per loss -- training.mixed -- as the LAST of their backwards does)
           ddp.arm_overlap(model)
         if losses.is_cuda and ASYNC_LOSS_COPY:
           # The reference's `losses.cpu()` (losses.py:288) after the backward makes the host wait for the whole backward
@@ -227,22 +231,25 @@ def get_step_fn(config, sde, train, optimize_fn=None):
           # exist before the backward starts, so copy them to pinned memory asynchronously NOW (in stream order: after
           # the loss kernels, before the backward) and wait for that copy -- not for the backward -- when returning.
           if pinned is None:
-            pinned = staging.get(losses_.numel())
+            key = (losses_.numel(), losses.device)
+            pinned = staging.get(key)
             if pinned is None:
-              pinned = staging[losses_.numel()] = torch.empty(losses_.numel(), dtype=torch.float32).pin_memory()
+              pinned = staging[key] = torch.empty(losses_.numel(), dtype=torch.float32).pin_memory()
             copied = torch.cuda.Event()
           pinned[out_per * k: out_per * (k + 1)].copy_(losses.detach(), non_blocking=True)
-          copied.record()
+          copied.record(torch.cuda.current_stream(losses.device))     # the stream the copy was issued on
           torch.mean(losses).backward(retain_graph=True)
         else:
           torch.mean(losses).backward(retain_graph=True)
           losses_[out_per * k: out_per * (k + 1)] = losses.cpu().detach()
       optimize_fn(optimizer, model.parameters(), step=state['step'])
-      state['step'] += 1
-      state['ema'].update(model.parameters())
-      if pinned is not None:
-        copied.synchronize()
-        losses_.copy_(pinned)
+    finally:
+      ddp.disarm_overlap(model)      # no-op after optimize_fn; a step that raised must not leave its hook armed
+    state['step'] += 1
+    state['ema'].update(model.parameters())
+    if pinned is not None:
+      copied.synchronize()
+      losses_.copy_(pinned)
     return losses_
 
   return step_fn

@@ -14,7 +14,6 @@ import math
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 def get_act(config):
@@ -32,66 +31,85 @@ def get_act(config):
   raise NotImplementedError('activation function does not exist!')
 
 
-def variance_scaling(scale, mode, distribution, in_axis=1, out_axis=0, dtype=torch.float32, device='cpu'):
-  """JAX-style variance-scaling initializer (models/layers.py:54-85)."""
+# fan used as the denominator of the variance, per `mode` (models/layers.py:68-76)
+_FAN = {'fan_in': lambda fi, fo: fi, 'fan_out': lambda fi, fo: fo, 'fan_avg': lambda fi, fo: (fi + fo) / 2}
 
-  def _compute_fans(shape):
-    receptive_field_size = np.prod(shape) / shape[in_axis] / shape[out_axis]
-    return shape[in_axis] * receptive_field_size, shape[out_axis] * receptive_field_size
+
+def _fans(shape, in_axis, out_axis):
+  """(fan_in, fan_out) of a weight of `shape`: the axis length times the receptive field (every other axis)."""
+  field = np.prod(shape) / shape[in_axis] / shape[out_axis]
+  return shape[in_axis] * field, shape[out_axis] * field
+
+
+def scaled_draw_(out, variance, distribution):
+  """Fill `out` with zero-mean draws of the given variance from torch's global generator.  The draws and the fp32
+  arithmetic are those of the reference's initializer (models/layers.py:77-83: `randn * sqrt(var)`,
+  `(rand * 2 - 1) * sqrt(3 var)`), so a model built under the same seed has bit-identical weights
+  (tests/test_ref_live.py)."""
+  if distribution == 'normal':
+    return out.normal_().mul_(float(np.sqrt(variance)))
+  if distribution == 'uniform':
+    return out.uniform_().mul_(2.).sub_(1.).mul_(float(np.sqrt(3 * variance)))
+  raise ValueError("invalid distribution for variance scaling initializer")
+
+
+def variance_scaling(scale, mode, distribution, in_axis=1, out_axis=0, dtype=torch.float32, device='cpu'):
+  """``init(shape) -> tensor`` with variance ``scale / fan`` (the reference's JAX-style initializer factory,
+  models/layers.py:54-85; same signature, same error messages for unknown modes / distributions)."""
+  if mode not in _FAN:
+    pick_fan = None
+  else:
+    pick_fan = _FAN[mode]
 
   def init(shape, dtype=dtype, device=device):
-    fan_in, fan_out = _compute_fans(shape)
-    if mode == "fan_in":
-      denominator = fan_in
-    elif mode == "fan_out":
-      denominator = fan_out
-    elif mode == "fan_avg":
-      denominator = (fan_in + fan_out) / 2
-    else:
+    if pick_fan is None:
       raise ValueError("invalid mode for variance scaling initializer: {}".format(mode))
-    variance = scale / denominator
-    if distribution == "normal":
-      return torch.randn(*shape, dtype=dtype, device=device) * np.sqrt(variance)
-    if distribution == "uniform":
-      return (torch.rand(*shape, dtype=dtype, device=device) * 2. - 1.) * np.sqrt(3 * variance)
-    raise ValueError("invalid distribution for variance scaling initializer")
+    fan = pick_fan(*_fans(shape, in_axis, out_axis))
+    return scaled_draw_(torch.empty(*shape, dtype=dtype, device=device), scale / fan, distribution)
 
   return init
 
 
 def default_init(scale=1.):
   """DDPM initialisation: fan-avg uniform; ``scale == 0`` means 1e-10 (models/layers.py:88-91)."""
-  scale = 1e-10 if scale == 0 else scale
-  return variance_scaling(scale, 'fan_avg', 'uniform')
+  return variance_scaling(scale if scale != 0 else 1e-10, 'fan_avg', 'uniform')
+
+
+def _ddpm_conv(kernel, in_planes, out_planes, init_scale, **conv_kw):
+  # nn.Conv2d's own initialisation runs first and consumes the generator exactly as in the reference; then the DDPM one
+  conv = nn.Conv2d(in_planes, out_planes, kernel_size=kernel, **conv_kw)
+  conv.weight.data = default_init(init_scale)(conv.weight.shape)
+  if conv.bias is not None:
+    conv.bias.data.zero_()
+  return conv
 
 
 def ddpm_conv1x1(in_planes, out_planes, stride=1, bias=True, init_scale=1., padding=0):
-  conv = nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, padding=padding, bias=bias)
-  conv.weight.data = default_init(init_scale)(conv.weight.data.shape)
-  nn.init.zeros_(conv.bias)
-  return conv
+  """1x1 convolution with DDPM initialisation (models/layers.py:100-105)."""
+  return _ddpm_conv(1, in_planes, out_planes, init_scale, stride=stride, padding=padding, bias=bias)
 
 
 def ddpm_conv3x3(in_planes, out_planes, stride=1, bias=True, dilation=1, init_scale=1., padding=1):
-  conv = nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=padding,
-                   dilation=dilation, bias=bias)
-  conv.weight.data = default_init(init_scale)(conv.weight.data.shape)
-  nn.init.zeros_(conv.bias)
-  return conv
+  """3x3 convolution with DDPM initialisation (models/layers.py:118-124)."""
+  return _ddpm_conv(3, in_planes, out_planes, init_scale, stride=stride, padding=padding, dilation=dilation, bias=bias)
+
+
+def positional_frequencies(half_dim, max_positions=10000, device=None):
+  """f_j = exp(-j ln(max_positions) / (half_dim - 1)), evaluated in fp32 by torch.exp on an fp32 ramp -- the table the
+  reference builds on every call (models/layers.py:519-521) and the one ``engine.graph.TimestepEmbedding`` uploads."""
+  step = math.log(max_positions) / (half_dim - 1)
+  return torch.exp(torch.arange(half_dim, dtype=torch.float32, device=device) * -step)
 
 
 def get_timestep_embedding(timesteps, embedding_dim, max_positions=10000):
-  """Host-side statement of the sinusoidal embedding (models/layers.py:515-529).  Inside the
+  """Host-side statement of the sinusoidal embedding [sin(t f), cos(t f)] (models/layers.py:515-529).  Inside the
   network the same values are produced by ``stk_timestep_embedding_f32``."""
-  assert len(timesteps.shape) == 1
-  half_dim = embedding_dim // 2
-  emb = math.log(max_positions) / (half_dim - 1)
-  emb = torch.exp(torch.arange(half_dim, dtype=torch.float32, device=timesteps.device) * -emb)
-  emb = timesteps.float()[:, None] * emb[None, :]
-  emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
-  if embedding_dim % 2 == 1:
-    emb = F.pad(emb, (0, 1), mode='constant')
-  assert emb.shape == (timesteps.shape[0], embedding_dim)
+  assert timesteps.dim() == 1
+  half = embedding_dim // 2
+  angle = timesteps.float()[:, None] * positional_frequencies(half, max_positions, timesteps.device)[None, :]
+  emb = angle.new_zeros(timesteps.shape[0], embedding_dim)      # an odd embedding_dim keeps a zero last column
+  emb[:, :half] = torch.sin(angle)
+  emb[:, half:2 * half] = torch.cos(angle)
   return emb
 
 

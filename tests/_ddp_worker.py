@@ -44,10 +44,11 @@ def sharded_rng(seed, rank, world):
     torch.rand, torch.randn_like = saved
 
 
-def build(st, lib, family='vp'):
+def build(st, lib, family='vp', mixed=False):
   from _model_util import randomize_, tiny_config
   cfg = tiny_config(st, family)
   cfg.optim.warmup = 2
+  cfg.training.mixed = bool(mixed)      # two network evaluations (and two engine backwards) per loss: losses.py:295-320
   sde = st.sde_lib.get_sde(cfg, None)
   net = st.models.ncsnpp.NCSNpp(cfg, sde)
   net.set_backend(lib)
@@ -63,8 +64,8 @@ def build(st, lib, family='vp'):
   return cfg, state, step_fn
 
 
-def run_steps(st, lib, rank, world, steps, global_batch):
-  cfg, state, step_fn = build(st, lib)
+def run_steps(st, lib, rank, world, steps, global_batch, mixed=False):
+  cfg, state, step_fn = build(st, lib, mixed=mixed)
   st.engine.ddp.seed_everything(123)          # numpy shared -> the same t_min on every rank
   losses = []
   for i in range(steps):
@@ -103,6 +104,20 @@ def worker(rank, world, port, outdir):
   dist.all_reduce = real
   assert n_overlapped >= 2 * 3, n_overlapped            # >= 3 buckets per step went out from inside the backward
   assert torch.equal(params, params_b) and torch.equal(shadow, shadow_b) and torch.equal(losses, losses_b)
+  # 3) training.mixed (the reference's ddpmpp_*_st_deepest configs): every loss evaluates the network twice, so ONE
+  #    .backward() runs two engine backwards into the same flat buffer.  Buckets may only leave with the last of them:
+  #    overlapped == plain, bit for bit, and buckets still went out from inside the backward.
+  st.losses.OVERLAP_EXCHANGE = True
+  dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), real(*a, **k))[1]
+  del calls[:]
+  m_losses, m_params, m_shadow = run_steps(st, lib, rank, world, steps=2, global_batch=8, mixed=True)
+  n_mixed = len(calls)
+  st.losses.OVERLAP_EXCHANGE = False
+  m_losses_b, m_params_b, m_shadow_b = run_steps(st, lib, rank, world, steps=2, global_batch=8, mixed=True)
+  dist.all_reduce = real
+  st.losses.OVERLAP_EXCHANGE = True
+  assert n_mixed >= 2 * 3, n_mixed
+  assert torch.equal(m_params, m_params_b) and torch.equal(m_shadow, m_shadow_b) and torch.equal(m_losses, m_losses_b)
   torch.save({'losses': losses, 'params': params, 'shadow': shadow, 'buckets': n_overlapped},
              os.path.join(outdir, f'rank{rank}.pt'))
   dist.barrier()

@@ -283,3 +283,65 @@ def test_shortcut_convolution_shares_the_block_output_gradient(st, ref_lib, monk
   top = max(p.grad.abs().max().item() for p in model.parameters())
   for a, p in zip(shared, model.parameters()):
     assert (a - p.grad).abs().max().item() <= 1e-5 * max(p.grad.abs().max().item(), 1e-4 * top)
+
+
+def test_rebinding_one_middle_parameter_is_noticed_on_the_next_call(st, ref_lib):
+  """engine/flat.py: every network evaluation and every zero_grad() checks ALL parameters against the flat buffers (raw
+  addresses), so a single `p.data = ...` / `p.grad = None` on a parameter in the middle of the model -- legal against the
+  reference -- takes effect on the very next call instead of training on a stale buffer."""
+  import torch
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, 'vp'), ref_lib)
+  x = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(1))
+  t = torch.rand(2, generator=torch.Generator().manual_seed(2)) * 999
+  ex = model.module.engine()
+  with torch.no_grad():
+    y0 = model(x, t).clone()
+  flat0 = ex.flat
+  params = [p for p in model.parameters() if p.requires_grad]
+  mid = params[len(params) // 2]
+  assert mid is not flat0.module_order[0] and mid is not flat0.module_order[-1]
+  # 1) rebinding the data of ONE parameter: the next evaluation must use the new values (here: a new layout is built)
+  mid.data = mid.data.clone() * 3.0 + 0.5
+  with torch.no_grad():
+    y1 = model(x, t)
+  assert ex.flat is not flat0 and ex.flat.is_bound()
+  assert (y1 - y0).abs().max().item() > 1e-4
+  ref_p = dict(ref.named_parameters())
+  name = [k for k, p in model.named_parameters() if p is mid][0]
+  with torch.no_grad():
+    ref_p[name.replace('.', '__').replace('module__', 'module.', 1)].copy_(mid.data)
+    yr = ref(x, t)
+  assert (y1 - yr).abs().max().item() <= 2e-5 * max(yr.abs().max().item(), 1.0)
+  # 2) dropping the gradient of ONE parameter: the next backward still lands in the flat gradient buffer, and the
+  #    parameter sees it
+  flat1 = ex.flat
+  model(x, t).sum().backward()
+  mid.grad = None
+  assert not flat1.is_bound()
+  model(x, t).sum().backward()
+  assert ex.flat is flat1 and flat1.is_bound()
+  assert mid.grad is not None and mid.grad.data_ptr() == flat1.view_of(flat1.grad, mid).data_ptr()
+  assert mid.grad.abs().max().item() > 0
+  # 3) the optimizer's zero_grad notices it as well
+  opt = st.losses.get_optimizer(cfg, model.parameters())
+  opt._backend = ref_lib
+  mid.grad = None
+  opt.zero_grad()
+  assert flat1.is_bound() and float(flat1.grad.abs().max()) == 0.0
+
+
+def test_flat_of_rejects_partial_and_foreign_lists(st, ref_lib):
+  import importlib
+  import torch
+  flat_mod = importlib.import_module('soft-truncation_amd.engine.flat')
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, 'vp'), ref_lib)
+  params = list(model.parameters())
+  assert flat_mod.flat_of(params) is model.module.engine().flat
+  assert flat_mod.flat_of(params[:-3]) is None                                   # a partial list
+  assert flat_mod.flat_of(params[:-1] + [torch.nn.Parameter(torch.zeros(3))]) is None   # a plain tensor mixed in
+  cfg2, _, _, other, _ = build_pair(st, tiny_config(st, 'vp'), ref_lib, seed=1)
+  mixed = list(params)
+  mixed[5] = list(other.parameters())[5]
+  assert flat_mod.flat_of(mixed) is None                                         # a parameter of another buffer
+  with pytest.raises(Exception):
+    st.engine.optim.FusedAdam(mixed, backend=ref_lib)._bind()

@@ -32,3 +32,25 @@ def test_full_ncsnpp_celebahq256(st, hip_lib):
   if not full.SHRINK and hip_lib.is_device:
     v = out['variants']
     assert any(k.endswith('.thin') for k in v) and any(k.endswith('.x2') for k in v), v
+
+
+@pytest.mark.parametrize('cfg_name', ['cifar10_ddpmpp_nll_st', 'imagenet32_ddpmpp_st'])
+def test_benched_batch_128_equals_sixteen_batch_8_runs(st, hip_lib, cfg_name):
+  """BASELINE configs[1] / configs[3] at the benched per-GPU batch (128): sample for sample equal to sixteen batch-8 runs,
+  chunk 0 equal to the oracle, and the plan really is the benched one (plane GEMMs, K-split small maps, all four
+  weight-gradient tilings, more than one slab)."""
+  out = full.benched_batch_vs_chunks(st, hip_lib, cfg_name)
+  print(cfg_name, 'batch-128 parity:', {k: (f'{v:.2e}' if isinstance(v, float) else v) for k, v in out.items()})
+
+
+def test_full_uncsnpp_celeba64_train_step(st, hip_lib):
+  """BASELINE configs[2] net: two full `step_fn` calls at batch 2 (RVE loss, sum reduction, FIR resampling, Adam, EMA)."""
+  out = full.full_train_step(st, hip_lib, 'celeba_uncsnpp_st', B=2)
+  print('UNCSN++ 64 step parity:', {k: (f'{v:.2e}' if isinstance(v, float) else v) for k, v in out.items()})
+
+
+def test_full_ncsnpp_celebahq256_pc_iteration(st, hip_lib):
+  """BASELINE configs[4] sampler leg: one reverse_diffusion + langevin iteration of the 256x256 NCSN++ at batch 1."""
+  out = full.full_pc_iteration(st, hip_lib, 'celebahq_uncsnpp_st', B=1, shrink_kw=dict(ch_mult=(1, 1, 2)))
+  print('NCSN++ 256 PC iteration parity:', {k: (f'{v:.2e}' if isinstance(v, float) else v) for k, v in out.items()})
+  assert out['predictor'] == 'ReverseDiffusionPredictor' and out['corrector'] == 'LangevinCorrector'

@@ -127,3 +127,25 @@ def test_product_fails_loudly_without_gpu_tensors(st, hip_lib):
     net(torch.zeros(1, 3, 16, 16), torch.zeros(1))
   with pytest.raises(RuntimeError, match='HIP'):
     st.op.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the test boxes have one)')
+def test_model_on_second_device_while_first_is_current(st, hip_lib):
+  """engine/lib.device_guard: every launch of the executor (forward, backward, weight preparation, graph capture) is
+  made with the model's device current -- a model on cuda:1 driven from a process whose current device is cuda:0 runs
+  on cuda:1's stream with cuda:1's pointers (the reference's DataParallel replica threads rely on the same)."""
+  from _model_util import build_pair, rel_err, tiny_config
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, 'vp'), hip_lib)
+  net = model.module.to('cuda:1')
+  x = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(1))
+  t = torch.rand(2, generator=torch.Generator().manual_seed(2)) * 999
+  assert torch.cuda.current_device() == 0
+  for _ in range(3):                                    # eager, capture, replay
+    xg = x.to('cuda:1').requires_grad_(True)
+    y = model(xg, t.to('cuda:1'))
+    y.sum().backward()
+  xr = x.clone().requires_grad_(True)
+  yr = ref(xr, t)
+  yr.sum().backward()
+  assert y.device.index == 1 and rel_err(y, yr) <= 2e-4 and rel_err(xg.grad, xr.grad) <= 2e-4
+  assert net.engine().flat.device.index == 1

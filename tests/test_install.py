@@ -30,5 +30,5 @@ def test_install_drives_a_run_lib_shaped_loop_on_the_checker(tmp_path):
 
 
 @pytest.mark.gpu
-def test_install_drives_a_run_lib_shaped_loop_on_hip(tmp_path):
+def test_install_drives_a_run_lib_shaped_loop_on_hip(tmp_path, hip_lib):      # hip_lib: skips without a GPU
   assert _drive(tmp_path, 'hip')['backend'] == 'hip-gfx950'
