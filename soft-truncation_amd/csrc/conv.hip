@@ -979,7 +979,11 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
     }
 #undef STK_PL_ABL
 #define STK_PL_LAUNCH(E, TAPS)                                                                                    \
-  if (pl::kernel_choice() == 3 || pl::kernel_choice() == 4) {                                                     \
+  if (pl::kernel_choice() == 5) {                                                                                 \
+    /* LDS-DMA staging with two LDS buffers: one barrier per chunk */                                             \
+    hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 128, E, 2>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, \
+                       r.chunks_per_split, xpart, nx);                                                            \
+  } else if (pl::kernel_choice() == 3 || pl::kernel_choice() == 4) {                                              \
     /* LDS-DMA staging (conv_x2d.h); 128 x 256 tiles when that still fills the chip and a tile stays in one image */ \
     const bool wide = pl::kernel_choice() == 3 && r.splits == 1 && p.HW % 256 == 0 && (long)tm * stk_cdiv((int)Ng, 256) >= 384; \
     if (wide) {                                                                                                   \

@@ -40,14 +40,19 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* 
 // the lockstep of the two workgroups of a CU -- 132 -> 142 us on the 128 -> 128 layer.  Reading ALL fragments of a chunk
 // before its first MFMA, so that the tile is free and the next chunk's DMA in flight for 48 instead of 24 MFMAs: 250
 // VGPRs, the training step 43.9 -> 44.5 ms.)
-template <int TAPS, int TN, class EP>
+//
+// NBUF = 2 (round 3): two LDS images of the tile pair.  The DMA of chunk c + 1 is issued right after the barrier that
+// opens chunk c, into the buffer chunk c - 1 was read from, so it has ALL 24 MFMAs of the chunk (and the partner
+// workgroup's) to land instead of the second half's 12, and the mid-chunk barrier goes: one barrier per chunk.
+// 2 x 32 KB x 2 workgroups per CU = 128 KB of the 160 KB.
+template <int TAPS, int TN, class EP, int NBUF = 1>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M, int Nn, int tiles_m, int tiles_n,
                                                       int nchunks_total, int chunks_per_split,
                                                       const float* __restrict__ xpart, int nxpart) {
   using G = Geo<TN>;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS];
-  unsigned char* As = lds;
-  unsigned char* Bs = lds + G::A_BYTES;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS * NBUF];
+  unsigned char* const As = lds;
+  unsigned char* const Bs = lds + G::A_BYTES;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float sx = x2::pow2_scale_of(x2::block_amax(xpart, nxpart, reinterpret_cast<float*>(lds)));
@@ -92,9 +97,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M,
       }
     }
   }
-  auto stage = [&](int c) {
+  auto stage = [&](int c, int buf = 0) {
     const int cc = TAPS == 9 ? c / 9 : c, tap = c - cc * TAPS;           // scalar
     const unsigned a_soff = (unsigned)c * a_chunk2;
+    unsigned char* const As = lds + buf * G::LDS;
+    unsigned char* const Bs = As + G::A_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -130,13 +137,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M,
   const unsigned char* b_rd = Bs + (wn0 + fc) * 64;
   const int ko0 = ((0 + fk) ^ fsw) * 16, ko1 = ((2 + fk) ^ fsw) * 16;     // slot of k segment (2 kk + fk)
 
-#define STK_D_FRAGS(KO)                                                                                   \
+#define STK_D_FRAGS_AT(KO, OFF)                                                                           \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                          \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
-      a[i][s] = *reinterpret_cast<const halfx8*>(a_rd + s * G::A_PLANE + i * 32 * 64 + (KO));              \
+      a[i][s] = *reinterpret_cast<const halfx8*>(a_rd + (OFF) + s * G::A_PLANE + i * 32 * 64 + (KO));      \
     _Pragma("unroll") for (int j = 0; j < G::NJ; ++j)                                                       \
-      b[j][s] = *reinterpret_cast<const halfx8*>(b_rd + s * G::B_PLANE + j * 32 * 64 + (KO));              \
+      b[j][s] = *reinterpret_cast<const halfx8*>(b_rd + (OFF) + s * G::B_PLANE + j * 32 * 64 + (KO));      \
   }
+#define STK_D_FRAGS(KO) STK_D_FRAGS_AT(KO, 0)
   // three products per tile, the two cross terms first (fixed accumulation order)
   constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};
 #define STK_D_MFMAS                                                                                        \
@@ -147,18 +155,34 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M,
 
   halfx8 a[2][2], b[G::NJ][2];
   stage(c_begin);
-  for (int c = c_begin; c <= c_last; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk c has landed ...
-    __syncthreads();                                   // ... and so has everybody else's
-    STK_D_FRAGS(ko0)
-    STK_D_MFMAS
-    STK_D_FRAGS(ko1)
-    __syncthreads();                                   // nobody reads the tile any more (the barrier waits lgkmcnt(0))
-    if (c < c_last) stage(c + 1);                      // chunk c + 1 streams in under the second half's MFMAs
-    STK_D_MFMAS
+  if constexpr (NBUF == 2) {
+    int cur = 0;
+    for (int c = c_begin; c <= c_last; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk c has landed ...
+      __syncthreads();                                   // ... so has everybody else's, and nobody reads chunk c - 1 any more
+      if (c < c_last) stage(c + 1, cur ^ 1);             // chunk c + 1 streams into the other buffer under this chunk's MFMAs
+      const int off = cur * G::LDS;
+      STK_D_FRAGS_AT(ko0, off)
+      STK_D_MFMAS
+      STK_D_FRAGS_AT(ko1, off)
+      STK_D_MFMAS
+      cur ^= 1;
+    }
+  } else {
+    for (int c = c_begin; c <= c_last; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of chunk c has landed ...
+      __syncthreads();                                   // ... and so has everybody else's
+      STK_D_FRAGS(ko0)
+      STK_D_MFMAS
+      STK_D_FRAGS(ko1)
+      __syncthreads();                                   // nobody reads the tile any more (the barrier waits lgkmcnt(0))
+      if (c < c_last) stage(c + 1);                      // chunk c + 1 streams in under the second half's MFMAs
+      STK_D_MFMAS
+    }
   }
 #undef STK_D_MFMAS
 #undef STK_D_FRAGS
+#undef STK_D_FRAGS_AT
 
   ep.stage(lds, tid);
   ep.init(p, 0, zs);
