@@ -128,6 +128,10 @@ def parse():
   ap.add_argument('--cpu-batch', type=int, default=8)
   ap.add_argument('--cpu-steps', type=int, default=5)
   ap.add_argument('--sampler-steps', type=int, default=6, help='PC-sampler iterations timed after the training steps (0 = skip)')
+  ap.add_argument('--no-exchange-proxy', action='store_true',
+                  help='N = 1 only: skip the second timed run with the gradient exchange forced on in a one-rank RCCL group')
+  ap.add_argument('--force-exchange', action='store_true',
+                  help='N = 1: run the WHOLE benchmark (the reported value too) with the exchange forced on')
   return ap.parse_args()
 
 
@@ -302,6 +306,47 @@ def pipe_probe(device):
   return 2.0 * 4096 ** 3 * 20 / (s.elapsed_time(e) * 1e-3) / 1e12
 
 
+def exchange_proxy(st, step_fn, state, batch, steps, device, init_group=True):
+  """The fixed cost of the multi-GPU step on ONE GPU: the same step with the gradient exchange forced on in an RCCL
+  process group of one rank -- backward replayed as one hipGraph per bucket segment, every 64 MB bucket of the flat gradient
+  buffer all-reduced asynchronously on the communicator's stream as its last writer finishes, one wait and the division
+  by the world size before clip / Adam (engine/ddp.py).  The all-reduce itself is the identity with one rank; what is
+  measured is everything around it, which every rank of an N-GPU run pays on top of the wire time."""
+  ddp = st.engine.ddp
+  made = False
+  if init_group and not dist.is_initialized():
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{free_port()}', rank=0, world_size=1, device_id=device)
+    made = True
+  calls = []
+  real = dist.all_reduce
+
+  def counting(*a, **k):
+    calls.append(a[0].numel())
+    return real(*a, **k)
+
+  ddp.FORCE_SINGLE_RANK = True
+  dist.all_reduce = counting
+  try:
+    for _ in range(4):                     # first forced step runs the segments eagerly, the second captures them
+      step_fn(state, batch)
+    torch.cuda.synchronize()
+    del calls[:]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      step_fn(state, batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+  finally:
+    dist.all_reduce = real
+    ddp.FORCE_SINGLE_RANK = False
+    if made:
+      dist.destroy_process_group()
+  per_step = len(calls) // max(steps, 1)
+  return {'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'all_reduces_per_step': per_step,
+          'bucket_MB': [round(4 * n / 2 ** 20, 1) for n in calls[:per_step]],
+          'backend': 'nccl (RCCL), world_size 1', 'overlapped': bool(st.losses.OVERLAP_EXCHANGE)}
+
+
 def free_port():
   import socket
   s = socket.socket()
@@ -322,7 +367,7 @@ def relaunch(args):
   return subprocess.call(cmd, env=env)
 
 
-def launch_check(world, rank, local_rank):
+def launch_check(world, rank, local_rank, out=sys.stdout):
   """The multi-process plumbing alone: process group up, every rank counted, rank 0 prints one JSON line."""
   on_gpu = torch.cuda.is_available()
   if on_gpu:
@@ -338,15 +383,26 @@ def launch_check(world, rank, local_rank):
     n = int(t.item())
     dist.barrier()
   if rank == 0:
-    print(json.dumps({'launch_check': True, 'n_gpus': world, 'ranks_counted': n, 'backend': backend}), flush=True)
+    out.write(json.dumps({'launch_check': True, 'n_gpus': world, 'ranks_counted': n, 'backend': backend}) + '\n')
+    out.flush()
   if world > 1:
     dist.destroy_process_group()
+
+
+def quiet_stdout():
+  """ONE JSON line on stdout: libraries print banners there (RCCL's version block at communicator creation, flushed at
+  exit, i.e. after the line).  Point file descriptor 1 at stderr for the whole run and return a handle on the real one."""
+  sys.stdout.flush()
+  real = os.fdopen(os.dup(1), 'w')
+  os.dup2(2, 1)
+  return real
 
 
 def main():
   args = parse()
   if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
     sys.exit(relaunch(args))
+  real_stdout = quiet_stdout()
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -356,7 +412,7 @@ def main():
   if args.gpus != world and rank == 0:
     print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}', file=sys.stderr)
   if args.launch_check:
-    return launch_check(world, rank, local_rank)
+    return launch_check(world, rank, local_rank, real_stdout)
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
   if world > 1:
@@ -373,6 +429,9 @@ def main():
     desc += ' with model.fir=True'
   st.engine.ddp.seed_everything(cfg.seed)                  # numpy shared (t_min), torch per rank
 
+  if args.force_exchange and world == 1:
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{free_port()}', rank=0, world_size=1, device_id=device)
+    st.engine.ddp.FORCE_SINGLE_RANK = True
   sde = st.sde_lib.get_sde(cfg, None)
   score_model = st.models.utils.create_model(cfg, sde)     # random-init weights of the named architecture
   score_model.module.engine().ensure_flat()
@@ -399,6 +458,14 @@ def main():
     losses_ = step_fn(state, batch)
   sync()
   elapsed = time.perf_counter() - t0
+  proxy = None
+  if world == 1 and not args.no_exchange_proxy and not args.force_exchange:
+    try:
+      proxy = exchange_proxy(st, step_fn, state, batch, args.steps, device)
+      proxy['ms_per_step_without'] = 1e3 * elapsed / args.steps
+      proxy['delta_ms'] = proxy['ms_per_step'] - proxy['ms_per_step_without']
+    except Exception as e:                 # reported, never fatal
+      proxy = {'error': repr(e)[:300]}
   # Kernel durations for the roofline object: the timed steps replay hipGraphs, and HIP events cannot be
   # recorded inside a replayed graph, so the same step is run `--prof-steps` more times right here with eager
   # launches, every contraction launch bracketed by events on the launch stream.
@@ -436,6 +503,10 @@ def main():
                  'parallelism': f'dp{world}', 'loss_mean': float(losses_.mean()),
                  'hipgraph_replays': score_model.module.engine().graph_replays},
     }
+    if proxy is not None:
+      out['exchange_proxy'] = proxy
+    if args.force_exchange and world == 1:
+      out['config']['exchange'] = 'forced on in a one-rank RCCL group (--force-exchange)'
     step_tflops = TRAIN_FLOPS_PER_IMG[cfg_name] * ips / world / 1e12
     out['step_roofline'] = {'bound': 'mfma', 'achieved': step_tflops, 'peak': PEAK_X2_TFLOPS,
                             'unit': 'TFLOP/s', 'frac': step_tflops / PEAK_X2_TFLOPS,
@@ -495,8 +566,9 @@ def main():
         out['parity_probe'] = parity_probe(st, cfg_name, device)
       except Exception as e:
         out['parity_probe'] = {'error': repr(e)[:300]}
-    print(json.dumps(out), flush=True)
-  if world > 1:
+    real_stdout.write(json.dumps(out) + '\n')
+    real_stdout.flush()
+  if world > 1 or (args.force_exchange and dist.is_initialized()):
     dist.destroy_process_group()
 
 

@@ -979,10 +979,30 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
     }
 #undef STK_PL_ABL
 #define STK_PL_LAUNCH(E, TAPS)                                                                                    \
-  if (pl::kernel_choice() == 5) {                                                                                 \
+  if (pl::kernel_choice() >= 32 && pl::kernel_choice() < 40 && TAPS == 9) {                                       \
+    /* ablation builds of the LDS-DMA kernel (benchmarks only) */                                                 \
+    switch (pl::kernel_choice() - 32) {                                                                           \
+      case 1: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
+      case 2: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 2>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
+      case 3: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 3>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
+      case 4: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 4>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
+      case 7: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 7>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
+      default: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 0>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
+    }                                                                                                             \
+  } else if (pl::kernel_choice() == 5) {                                                                                 \
     /* LDS-DMA staging with two LDS buffers: one barrier per chunk */                                             \
     hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 128, E, 2>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, \
                        r.chunks_per_split, xpart, nx);                                                            \
+  } else if (pl::kernel_choice() == 4 && x2d::halo_ok(p, TAPS, r.splits)) {                                       \
+    /* one halo tile of the activations per channel group serves the nine taps */                                 \
+    if (p.W == 32 && x2d::halo_mode() == 2)                                                                       \
+      hipLaunchKernelGGL((x2d::gemm_halo_kernel<32, E, 2>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
+    else if (p.W == 32)                                                                                           \
+      hipLaunchKernelGGL((x2d::gemm_halo_kernel<32, E, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
+    else if (x2d::halo_mode() == 2)                                                                               \
+      hipLaunchKernelGGL((x2d::gemm_halo_kernel<16, E, 2>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
+    else                                                                                                          \
+      hipLaunchKernelGGL((x2d::gemm_halo_kernel<16, E, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
   } else if (pl::kernel_choice() == 3 || pl::kernel_choice() == 4) {                                              \
     /* LDS-DMA staging (conv_x2d.h); 128 x 256 tiles when that still fills the chip and a tile stays in one image */ \
     const bool wide = pl::kernel_choice() == 3 && r.splits == 1 && p.HW % 256 == 0 && (long)tm * stk_cdiv((int)Ng, 256) >= 384; \

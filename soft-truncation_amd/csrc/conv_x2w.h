@@ -203,7 +203,9 @@ inline Plan plan(int N, int H, int W, int Cin, int Cout) {
   // two workgroups per CU; >= 8 chunks per workgroup; and a cap on the slab traffic (every split writes, and the
   // reduce reads, 9 Cout Cin floats): STK_WGRAD_SLAB_MB, default 128 (A/B on one box: 16 MB 55.7 ms per step, 32 MB 48.0, 64 MB 46.3, 128 MB 46.1 -- the parallelism of the K split is worth more than its slab traffic)
   static const long cap_mb = [] { const char* e = getenv("STK_WGRAD_SLAB_MB"); return e ? atol(e) : 128L; }();
-  long splits = stk_cdiv(512, tiles);
+  // at most 512 workgroups = ONE round of two per CU (rounding the quotient up gave 516 for 12 tiles: a second round of four
+  // workgroups, 441 us instead of ~330 on the 384 -> 128 layer at 32 x 32)
+  long splits = tiles >= 512 ? 1 : 512 / tiles;
   if (splits > nch / 8) splits = nch / 8;
   const long cap = (cap_mb << 20) / (9L * Cout * Cin * 4);
   if (splits > cap) splits = cap;

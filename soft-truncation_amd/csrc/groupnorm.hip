@@ -91,6 +91,24 @@ __device__ __forceinline__ float silu_f(float u) {
 #endif
 }
 
+// sigmoid(u) = 1 / (1 + exp(-u)) with the same exponential and the same refined reciprocal as silu_f (backward pass:
+// the libm expf + IEEE division cost ~25 VALU instructions per element of a kernel that has ~20 others).
+__device__ __forceinline__ float sigmoid_f(float u) {
+#ifdef STK_SILU_LIBM
+  return 1.f / (1.f + expf(-u));
+#else
+  const float NL2E_HI = -1.44269502162933349609375f, NL2E_LO = -1.925963033500011e-8f;
+  const float t = u * NL2E_HI;
+  float r = __fmaf_rn(u, NL2E_HI, -t);
+  r = __fmaf_rn(u, NL2E_LO, r);
+  const float p = __builtin_amdgcn_exp2f(t);
+  const float e = fminf(__fmaf_rn(p, r * 0.693147182464599609375f, p), 3.0e38f);
+  const float d = 1.f + e;
+  float rc = __builtin_amdgcn_rcpf(d);
+  return __fmaf_rn(rc, __fmaf_rn(-d, rc, 1.f), rc);     // one Newton step: <= 1 ulp of 1 / d
+#endif
+}
+
 // ---- forward ------------------------------------------------------------------------------------
 // Register-resident forward for groups of up to 16384 elements (every group of the 32x32 / 64x64 networks): a thread
 // keeps its <= 4 float4 of the group, so the group is read ONCE (the looping kernel below reads it for the statistics
@@ -246,7 +264,7 @@ __device__ __forceinline__ float gn_du(const GnArgs& a, float xv, float dyv, flo
   if (a.drop_p > 0.f) go = stk_keep(seed, flat, a.drop_thr) ? go * a.keep_scale : 0.f;
   if (a.act) {
     const float u = ga * xhat + be;
-    const float sg = 1.f / (1.f + expf(-u));
+    const float sg = sigmoid_f(u);
     go = go * (sg * (1.f + u * (1.f - sg)));
   }
   return go;

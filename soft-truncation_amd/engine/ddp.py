@@ -22,8 +22,16 @@ import torch
 import torch.distributed as dist
 
 
+# STK_DDP_FORCE=1: run the exchange (segmented backward, bucket all-reduces, averaging) in a process group of ONE rank
+# too -- the fixed per-step cost every rank of a multi-GPU run pays, measurable on a single GPU (bench.py --force-exchange)
+FORCE_SINGLE_RANK = False
+
+
 def is_distributed():
-  return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+  import os
+  if not (dist.is_available() and dist.is_initialized()):
+    return False
+  return dist.get_world_size() > 1 or FORCE_SINGLE_RANK or os.environ.get('STK_DDP_FORCE', '0') == '1'
 
 
 def world_size():

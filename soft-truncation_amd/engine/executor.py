@@ -54,6 +54,36 @@ class _GnFoldDesc(ctypes.Structure):       # StkGnFoldDesc of include/stk.h
               ('N', ctypes.c_int), ('C', ctypes.c_int)]
 
 
+class SideStream:
+  """A second HIP stream for the weight gradients of a backward pass (STK_WGRAD_STREAM=0: off).  Works the same way in
+  eager launches and inside a hipGraph capture, where the event pairs become the fork / join edges of the graph."""
+
+  def __init__(self, device):
+    self.device = device
+    self.stream = torch.cuda.Stream(device)
+    self.last = None
+
+  def begin(self):
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(self.device))
+    self.stream.wait_event(ev)
+    return self.stream.cuda_stream
+
+  def end(self):
+    ev = torch.cuda.Event()
+    ev.record(self.stream)
+    self.last = ev
+    return ev
+
+  def main_waits(self, ev):
+    torch.cuda.current_stream(self.device).wait_event(ev)
+
+  def join(self):
+    if self.last is not None:
+      self.main_waits(self.last)
+      self.last = None
+
+
 class Context:
   """Buffers of one forward call, kept until its backward has run."""
   __slots__ = ('prog', 'act', 'gact', 'rt', 'released', 'seed_t', 'graphs', 'uses', 'pl', '__weakref__')
@@ -87,6 +117,7 @@ class Program:
       const[off:off + arr.size] = torch.from_numpy(arr)
     self.const = const.to(device)
     self.ws = _arena(graph.ws_bytes // 4, device)
+    self.ws2 = None              # workspace of the side stream (weight gradients), allocated on first use
     self.free = []
     # prepared weights (include/stk.h): arena + device-resident descriptor table, built on first use.
     # Table order: all forward blocks, then all data-gradient blocks, so a no-grad call prepares a prefix.
@@ -246,6 +277,15 @@ class Executor:
     # STK_WP=0: every conv call prepares its own weights (the plain C-ABI calls) instead of one batched launch per
     # forward; a debugging switch, results are bit-identical
     self.use_wp = os.environ.get('STK_WP', '1') != '0'
+    # STK_WGRAD_STREAM=0: the weight gradients of a backward run on the main stream, behind their layer's data gradient
+    self.use_side = os.environ.get('STK_WGRAD_STREAM', '1') != '0'
+    self._side = None
+    # The backward of a training step is launched eagerly when its weight gradients go to the side stream: a hipGraph with
+    # the same fork / join structure runs its branches no faster than one stream (A/B on one box: graph 40.37 ms per step
+    # with or without the side branch, eager launches with it 39.72), and the host stays ~30 ms ahead of the GPU anyway.
+    # STK_BWD_GRAPH=1 replays the backward as a hipGraph again (the forward always is one).
+    self.bwd_graphs = os.environ.get('STK_BWD_GRAPH', '0' if self.use_side else '1') != '0'
+
     self._frozen = 0
     # gradient exchange overlapped with the backward (engine/ddp.py): when set, run_backward cuts its launch sequence
     # into segments and calls grad_hook(lo, hi) as soon as a bucket [lo, hi) of the flat gradient buffer is final
@@ -350,6 +390,12 @@ class Executor:
     if c.pl is not None:
       rt.pl = c.pl.data_ptr()
       rt.dypl = rt.pl + prog.graph.pl_bytes
+      if with_backward and self.use_side and self.lib.is_device and getattr(prog.graph, 'own_dypl', False):
+        if self._side is None or self._side.device != flat.device:
+          self._side = SideStream(flat.device)
+        if prog.ws2 is None:
+          prog.ws2 = _arena(prog.graph.ws_bytes // 4, prog.device)
+        rt.side, rt.ws2 = self._side, prog.ws2.data_ptr()
     if with_backward and prog.gn_table is not None:
       rt.gnpart, rt.gn_table, rt.gn_maxc = prog.gnpart.data_ptr(), prog.gn_table.data_ptr(), prog.gn_maxc
     return rt
@@ -376,10 +422,12 @@ class Executor:
             for op in reversed(ops):
               op.backward(rt)
             rt.flush_folds()
+            rt.join_side()
           else:
             for op in list(reversed(ops))[span[0]:span[1]]:
               op.backward(rt)
             rt.flush_folds()
+            rt.join_side()
       except Exception as e:   # capture is an optimisation: report, disable, run eagerly
         warnings.warn(f'hipGraph capture failed ({e!r}); continuing with eager launches')
         self.use_graphs = False
@@ -454,7 +502,7 @@ class Executor:
       # overlapped exchange: segment by segment, handing finished buckets to the hook (which starts their all-reduce
       # on the communicator's stream, ordered behind the launches made so far)
       segs = prog.backward_segments(flat.n_train, self.grad_bucket_elems)
-      graphs = self._graphs_on() and rt.seed_dev is not None
+      graphs = self._graphs_on() and rt.seed_dev is not None and self.bwd_graphs
       if not graphs:
         rt.gbase['act'] = c.gact.data_ptr()
         rt.gbase['param'] = flat.grad.data_ptr()
@@ -473,11 +521,12 @@ class Executor:
             for op in order[begin:end]:
               op.backward(rt)
             rt.flush_folds()
+            rt.join_side()
         begin = end
         for lo, hi in ranges:
           hook(lo, hi)
       done = True
-    elif self._graphs_on() and rt.seed_dev is not None:
+    elif self._graphs_on() and rt.seed_dev is not None and (self.bwd_graphs or not param_grads or rt.side is None):
       done = self._replay(c, 'bwd', rt.training, param_grads=param_grads)
     if not done:
       rt.gbase['act'] = c.gact.data_ptr()
@@ -487,6 +536,7 @@ class Executor:
       for op in reversed(g.ops):
         op.backward(rt)
       rt.flush_folds()
+      rt.join_side()
     gx = None
     xin = g.inputs['x']
     if xin.needs_grad:

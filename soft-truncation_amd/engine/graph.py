@@ -87,6 +87,23 @@ class Runtime:
     self.gn_maxc = 0
     self._fold_lo = None
     self._fold_hi = None
+    # weight gradients on a second stream (engine/executor.SideStream; None = everything on `stream`): they are
+    # matrix-pipe-bound and independent of the data-gradient chain, whose GroupNorm backward / planes passes are HBM-bound.
+    # `ws2` = the side stream's own workspace.  Every convolution then owns the planes of its output gradient
+    # (Conv.dypl_off) instead of sharing one scratch buffer: a shared buffer would make the main chain wait for the side
+    # stream before every split pass, and inside a hipGraph each such cross-stream edge costs 15-30 us.
+    self.side = None
+    self.ws2 = 0
+
+  def side_launch(self, fn, *args):
+    """fn(*args, side stream), ordered behind everything launched on the main stream so far."""
+    s = self.side.begin()
+    fn(*args, s)
+    self.side.end()
+
+  def join_side(self):
+    if self.side is not None:
+      self.side.join()
 
   def defer_fold(self, index):
     """A GroupNorm backward left its per-(sample, channel) sums behind; entry `index` of the table folds them."""
@@ -375,6 +392,7 @@ class Conv(Op):
   x_from = None        # Graph._plan_x_records: the GroupNorm whose forward leaves this layer's |x1| / |x2| records behind
 
   # planes (include/stk.h "Planes"): decided by Graph.finalize
+  dypl_off = None      # byte offset of this layer's own dy planes in the planes arena (side-stream weight gradients)
   pl_fwd = False       # the forward call reads x1 as planes
   pl_dgrad = False     # the data-gradient call reads dy as planes (made here, into the context's scratch)
   pl_wgrad = False     # the weight-gradient call reads x1 AND dy as planes (3x3 layers whose forward does)
@@ -405,7 +423,11 @@ class Conv(Op):
         int(lib.conv2d_wgrad_pl_ok(self.N, self.H, self.W, self.C1, self.Cout))):
       self.pl_wgrad = True
     if self.pl_dgrad or self.pl_wgrad:
-      g.dypl_bytes = max(g.dypl_bytes, _round_up(int(lib.planes_bytes(self.N, self.Cout, self.OH * self.OW)), 256))
+      nb = _round_up(int(lib.planes_bytes(self.N, self.Cout, self.OH * self.OW)), 256)
+      g.dypl_bytes = max(g.dypl_bytes, nb)
+      if self.pl_wgrad and g.own_dypl:
+        self.dypl_off = g.pl_bytes
+        g.pl_bytes += nb
 
   def plan_backward(self):
     if self.dy_peer is not None or self.res_via is not None:      # d(res) is not written here: do not count this op as a writer
@@ -502,11 +524,12 @@ class Conv(Op):
       rec = dy_rec
       if not rec_done:
         lib.amax_partial_f32(gy, self.y.numel, rec, rt.stream)
-      lib.split_planes_f32(gy, self.N, self.Cout, self.OH * self.OW, rec, 256, rt.dypl, rt.stream)
+      dypl = rt.pl + self.dypl_off if self.dypl_off is not None else rt.dypl
+      lib.split_planes_f32(gy, self.N, self.Cout, self.OH * self.OW, rec, 256, dypl, rt.stream)
       have |= 2
     if pl_dgrad:
       rt.timed(self._label_pl(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_pl_f32,
-               rt.dypl, rec, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
+               dypl, rec, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
                alpha, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self._wp(rt, 1), rt.ws, rt.ws_bytes, rt.stream)
       have |= 2
@@ -518,9 +541,12 @@ class Conv(Op):
                alpha, *self._dims(), self._wp(rt, 1), rt.v(self.amax), rt.ws, rt.ws_bytes, rt.stream)
       if self._kind(lib, 'dgrad').endswith('.x2'):
         have |= 2
-    if pl_wgrad:
+    if pl_wgrad and rt.side is not None and rt.prof is None and self.dypl_off is not None:
+      rt.side_launch(lib.conv2d_wgrad_pl_f32, rt.planes(self.x1), rt.rec(self.x1), dypl, dy_rec, gw, alpha, rt.ws2,
+                     rt.ws_bytes, self.N, self.H, self.W, self.C1, self.Cout)
+    elif pl_wgrad:
       rt.timed(self._label_pl(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_pl_f32,
-               rt.planes(self.x1), rt.rec(self.x1), rt.dypl, dy_rec, gw, alpha, rt.ws, rt.ws_bytes,
+               rt.planes(self.x1), rt.rec(self.x1), dypl, dy_rec, gw, alpha, rt.ws, rt.ws_bytes,
                self.N, self.H, self.W, self.C1, self.Cout, rt.stream)
     elif gw is not None:
       rt.timed(self._kind(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_amax_f32,
@@ -1033,6 +1059,8 @@ class Graph:
     # takes fp32 operands -- a debugging switch)
     self.pl_bytes = 0
     self.dypl_bytes = 0
+    # weight gradients on a side stream (engine/executor.py): every such layer keeps the planes of its output gradient
+    self.own_dypl = os.environ.get('STK_WGRAD_STREAM', '1') != '0' and bool(getattr(lib, 'is_device', False))
     if os.environ.get('STK_PLANES', '1') != '0' and hasattr(lib, 'conv2d_pl_ok'):
       for op in self.ops:
         if isinstance(op, Conv):

@@ -26,11 +26,11 @@ class ShardedDraws:
 
   def rand(self, *size, device=None, **kw):
     n = size[0]
-    return self._cut(torch.empty(n * self.world, *size[1:]).uniform_(generator=self.g), n)
+    return self._cut(torch.empty(n * self.world, *size[1:]).uniform_(generator=self.g), n).to(device or 'cpu')
 
   def randn_like(self, x, **kw):
     n = x.shape[0]
-    return self._cut(torch.empty(n * self.world, *x.shape[1:]).normal_(generator=self.g), n)
+    return self._cut(torch.empty(n * self.world, *x.shape[1:]).normal_(generator=self.g), n).to(x.device)
 
 
 @contextlib.contextmanager
@@ -44,14 +44,15 @@ def sharded_rng(seed, rank, world):
     torch.rand, torch.randn_like = saved
 
 
-def build(st, lib, family='vp', mixed=False):
+def build(st, lib, family='vp', mixed=False, device='cpu'):
   from _model_util import randomize_, tiny_config
-  cfg = tiny_config(st, family)
+  cfg = tiny_config(st, family, device=device)
   cfg.optim.warmup = 2
   cfg.training.mixed = bool(mixed)      # two network evaluations (and two engine backwards) per loss: losses.py:295-320
   sde = st.sde_lib.get_sde(cfg, None)
   net = st.models.ncsnpp.NCSNpp(cfg, sde)
   net.set_backend(lib)
+  net = net.to(cfg.device)
   randomize_(net, 0)
   model = st.models.utils.DataParallel(net)
   net.engine().ensure_flat()
@@ -64,17 +65,19 @@ def build(st, lib, family='vp', mixed=False):
   return cfg, state, step_fn
 
 
-def run_steps(st, lib, rank, world, steps, global_batch, mixed=False):
-  cfg, state, step_fn = build(st, lib, mixed=mixed)
+def run_steps(st, lib, rank, world, steps, global_batch, mixed=False, family='vp', device='cpu'):
+  cfg, state, step_fn = build(st, lib, family=family, mixed=mixed, device=device)
   st.engine.ddp.seed_everything(123)          # numpy shared -> the same t_min on every rank
   losses = []
   for i in range(steps):
     full = st.datasets.synthetic_batch(cfg, global_batch, generator=torch.Generator().manual_seed(100 + i))
     local = st.engine.ddp.shard_batch(full) if world > 1 else full
     with sharded_rng(50 + i, rank, world):
-      losses.append(step_fn(state, local))
-  flat = state['model'].module.engine().flat
-  return torch.cat(losses), flat.data[:flat.n_train].clone(), state['ema']._shadow.clone()
+      losses.append(step_fn(state, local.to(cfg.device)))
+  ex = state['model'].module.engine()
+  flat = ex.flat
+  run_steps.graph_replays = ex.graph_replays
+  return torch.cat(losses), flat.data[:flat.n_train].detach().cpu().clone(), state['ema']._shadow.detach().cpu().clone()
 
 
 def worker(rank, world, port, outdir):
@@ -119,6 +122,48 @@ def worker(rank, world, port, outdir):
   assert n_mixed >= 2 * 3, n_mixed
   assert torch.equal(m_params, m_params_b) and torch.equal(m_shadow, m_shadow_b) and torch.equal(m_losses, m_losses_b)
   torch.save({'losses': losses, 'params': params, 'shadow': shadow, 'buckets': n_overlapped},
+             os.path.join(outdir, f'rank{rank}.pt'))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def gpu_worker(rank, world, port, outdir, family='wide', steps=4, global_batch=8):
+  """One rank of a world_size-2 job whose ranks SHARE cuda:0 (the test boxes have one GPU): gloo process group (RCCL
+  cannot put two ranks on one device), the product's HIP engine, gradient buckets all-reduced from inside a backward that
+  is replayed as one hipGraph per bucket segment.  The exchange-after-backward run of the same steps must agree bit for
+  bit; the parent test compares with one process on the whole batch."""
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  os.environ['STK_DDP_BUCKET_MB'] = '6'                 # several buckets for the few-M-parameter model
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  import soft_truncation_amd as st
+  lib = st.engine.lib.load()                             # libstk.so; raises if it is missing
+  assert lib.is_device
+  calls = []
+  real = dist.all_reduce
+  dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), real(*a, **k))[1]
+  assert st.losses.OVERLAP_EXCHANGE
+  # (a) default engine: forward hipGraph, backward launched eagerly segment by segment with the weight gradients on the
+  #     side stream (engine/executor.py)
+  losses, params, shadow = run_steps(st, lib, rank, world, steps, global_batch, family=family, device='cuda:0')
+  n_overlapped, replays = len(calls), run_steps.graph_replays
+  # (b) the same with the backward replayed as one hipGraph per bucket segment
+  os.environ['STK_BWD_GRAPH'] = '1'
+  del calls[:]
+  losses_g, params_g, shadow_g = run_steps(st, lib, rank, world, steps, global_batch, family=family, device='cuda:0')
+  n_graph, replays_g = len(calls), run_steps.graph_replays
+  del os.environ['STK_BWD_GRAPH']
+  # (c) exchange after the backward
+  st.losses.OVERLAP_EXCHANGE = False
+  del calls[:]
+  losses_b, params_b, shadow_b = run_steps(st, lib, rank, world, steps, global_batch, family=family, device='cuda:0')
+  dist.all_reduce = real
+  assert n_overlapped >= steps * 3 and n_graph >= steps * 3, (n_overlapped, n_graph)   # >= 3 buckets per step left from inside the backward
+  assert replays >= steps - 2, replays                  # the forward graph
+  assert replays_g >= (steps - 2) * 4, replays_g        # forward + >= 3 backward segments, captured at step 2, replayed after
+  assert torch.equal(params, params_b) and torch.equal(shadow, shadow_b) and torch.equal(losses, losses_b)
+  assert torch.equal(params, params_g) and torch.equal(shadow, shadow_g) and torch.equal(losses, losses_g)
+  torch.save({'losses': losses, 'params': params, 'shadow': shadow, 'buckets': n_overlapped, 'replays': replays},
              os.path.join(outdir, f'rank{rank}.pt'))
   dist.barrier()
   dist.destroy_process_group()

@@ -1,6 +1,8 @@
 """GPU parity tests at the model level: NCSNpp on the HIP engine (libstk.so, gfx950) against the oracle
 RefNet on the host, through the reference's own interfaces (models.utils, losses.get_step_fn,
 sampling.get_sampling_fn)."""
+import os
+
 import pytest
 import torch
 
@@ -115,6 +117,38 @@ def test_train_steps_with_rccl_process_group(st, hip_lib, monkeypatch):
     assert len(calls) >= 4                      # one bucket per step for the tiny model
   finally:
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_match_single_process(st, hip_lib, tmp_path):
+  """The overlapped gradient exchange on the REAL kernels: two processes share cuda:0 (gloo process
+  group), each trains on its half of the global batch with the HIP engine -- backward replayed as one hipGraph per bucket
+  segment, buckets all-reduced between the segments.  Checks: overlapped == exchange-after-backward bit for bit (inside
+  the workers); replicas identical; parameters / EMA / losses equal to ONE process on the whole batch (same noise)."""
+  import socket
+  import torch.multiprocessing as mp
+  import _ddp_worker as W
+  if os.environ.get('STK_SELFCHECK'):
+    pytest.skip('needs the HIP library')
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  world, steps, gb = 2, 4, 8
+  ctx = mp.get_context('spawn')
+  procs = [ctx.Process(target=W.gpu_worker, args=(r, world, port, str(tmp_path), 'wide', steps, gb)) for r in range(world)]
+  for p in procs:
+    p.start()
+  for p in procs:
+    p.join(800)
+    assert p.exitcode == 0, f'rank exited with {p.exitcode}'
+  got = [torch.load(os.path.join(str(tmp_path), f'rank{r}.pt')) for r in range(world)]
+  assert torch.equal(got[0]['params'], got[1]['params']) and torch.equal(got[0]['shadow'], got[1]['shadow'])
+  losses, params, shadow = W.run_steps(st, hip_lib, 0, 1, steps, gb, family='wide', device='cuda:0')
+  per = gb // world
+  for i in range(steps):
+    both = torch.cat([got[r]['losses'][per * i:per * (i + 1)] for r in range(world)])
+    assert torch.allclose(both, losses[gb * i:gb * (i + 1)], rtol=2e-4, atol=0)
+  lr = 2e-4
+  assert (got[0]['params'] - params).abs().max().item() <= 0.05 * lr * steps
+  assert (got[0]['shadow'] - shadow).abs().max().item() <= 0.05 * lr * steps
 
 
 def test_product_fails_loudly_without_gpu_tensors(st, hip_lib):
