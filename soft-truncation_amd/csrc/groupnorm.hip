@@ -345,7 +345,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
                                                           const float* __restrict__ rstd_in, float* __restrict__ dx1,
                                                           float beta1, float* __restrict__ dx2, float beta2,
                                                           float* __restrict__ ws, int hw_log2, GnBwdOut out) {
-  __shared__ float s_part[2048], s_ch[1024];
+  __shared__ float s_part[2048], s_ch[1024], s_mx[16];
   const int T = blockDim.x;
   const int ng = blockIdx.x;
   const int n = ng / a.G, g = ng - n * a.G;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
   if (want) {
     {
       const float m = wave_max(amax_l);
-      if (lane == 0) s_ch[threadIdx.x >> 6] = m;          // s_ch was last read before the store loop above
+      if (lane == 0) s_mx[threadIdx.x >> 6] = m;          // (not s_ch: another wave may still be reading its group sums)
     }
     __syncthreads();
     for (int cl = threadIdx.x; cl < a.cpg; cl += T) {
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
       // ONE atomic per workgroup (4096 workgroups on 256 slots: 16 per address; one per wave measured no gain over the
       // separate pass).  Non-negative floats order like their bit patterns: an integer max is exact and order-independent
       float m = 0.f;
-      for (int w = 0; w < (T >> 6); ++w) m = fmaxf(m, s_ch[w]);
+      for (int w = 0; w < (T >> 6); ++w) m = fmaxf(m, s_mx[w]);
       atomicMax(reinterpret_cast<unsigned*>(out.amax) + (blockIdx.x & 255), __float_as_uint(m));
     }
   }

@@ -21,6 +21,13 @@ import os
 import numpy as np
 
 SQRT2 = float(np.float32(np.sqrt(2.)))
+# A/B switches of the side stream (engine/executor.SideStream): shortcut convolutions' backward / fp32-operand weight gradients
+_SIDE_SHORTCUT = os.environ.get('STK_SIDE_SHORTCUT', '1') != '0'
+_SIDE_WGRAD1 = os.environ.get('STK_SIDE_WGRAD1', '1') != '0'
+_SIDE_W1_FILTER = None      # debugging: predicate on the Conv op
+_SIDE_DELAY = int(os.environ.get('STK_SIDE_DELAY', '0'))
+_SIDE_DELAY_FILTER = None
+_SIDE_FAKE = False
 _ALIGN = 64  # floats (256 B) -- keeps every buffer float4-aligned
 
 
@@ -94,14 +101,53 @@ class Runtime:
     # stream before every split pass, and inside a hipGraph each such cross-stream edge costs 15-30 us.
     self.side = None
     self.ws2 = 0
+    self.pending = {}            # id(activation tensor) -> event of the side-stream work that wrote its gradient
+    self._cur = None
 
   def side_launch(self, fn, *args):
     """fn(*args, side stream), ordered behind everything launched on the main stream so far."""
     s = self.side.begin()
-    fn(*args, s)
+    if _SIDE_DELAY and (_SIDE_DELAY_FILTER is None or _SIDE_DELAY_FILTER(self._cur)):   # debugging: hold the side stream back
+      import torch
+      with torch.cuda.stream(self.side.stream):
+        torch.cuda._sleep(_SIDE_DELAY)
+    if _SIDE_FAKE:                                        # debugging: the real work stays on the main stream (args carry ws2: fine)
+      fn(*args, self.stream)
+    else:
+      fn(*args, s)
     self.side.end()
 
+  def run_on_side(self, writes, fn):
+    """Run fn() with `stream` / `ws` pointing at the side stream and its workspace (behind everything launched on the main
+    stream so far).  `writes` = the activation tensors whose GRADIENTS fn writes: the next main-stream op that touches one
+    of them waits for fn first (guard)."""
+    side = self.side
+    s = side.begin()
+    saved = (self.stream, self.ws)
+    self.stream, self.ws, self.side = s, self.ws2, None
+    try:
+      fn()
+    finally:
+      self.stream, self.ws = saved
+      self.side = side
+    ev = side.end()
+    for t in writes:
+      if t is not None:
+        self.pending[id(t)] = ev
+
+  def guard(self, op):
+    """Called before op.backward on the main stream: wait for side-stream work that wrote a gradient this op reads or
+    accumulates into."""
+    if not self.pending:
+      return
+    for t in tuple(op.inputs) + (getattr(op, 'y', None),):
+      if t is not None:
+        ev = self.pending.pop(id(t), None)
+        if ev is not None:
+          self.side.main_waits(ev)
+
   def join_side(self):
+    self.pending.clear()
     if self.side is not None:
       self.side.join()
 
@@ -455,6 +501,13 @@ class Conv(Op):
              rt.v(self.y), *self._dims(), self._wp(rt, 0), rt.v(self.amax), rt.ws, rt.ws_bytes, rt.stream)
 
   def backward(self, rt):
+    if self.dy_from is not None and rt.side is not None and rt.prof is None and _SIDE_SHORTCUT:
+      # a shortcut convolution differentiates from its peer's (final) output gradient and only meets the main chain again
+      # where the block's first GroupNorm accumulates into d(x): its HBM-bound 1x1 passes run beside the main chain's GEMMs
+      return rt.run_on_side((self.x1, self.x2), lambda: self._backward(rt))
+    return self._backward(rt)
+
+  def _backward(self, rt):
     gy = rt.g(self.y)
     alpha = 1.0 / self.out_div
     lib = rt.lib
@@ -541,6 +594,7 @@ class Conv(Op):
                alpha, *self._dims(), self._wp(rt, 1), rt.v(self.amax), rt.ws, rt.ws_bytes, rt.stream)
       if self._kind(lib, 'dgrad').endswith('.x2'):
         have |= 2
+    rt._cur = self.y.name
     if pl_wgrad and rt.side is not None and rt.prof is None and self.dypl_off is not None:
       rt.side_launch(lib.conv2d_wgrad_pl_f32, rt.planes(self.x1), rt.rec(self.x1), dypl, dy_rec, gw, alpha, rt.ws2,
                      rt.ws_bytes, self.N, self.H, self.W, self.C1, self.Cout)
@@ -548,6 +602,10 @@ class Conv(Op):
       rt.timed(self._label_pl(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_pl_f32,
                rt.planes(self.x1), rt.rec(self.x1), dypl, dy_rec, gw, alpha, rt.ws, rt.ws_bytes,
                self.N, self.H, self.W, self.C1, self.Cout, rt.stream)
+    elif gw is not None and rt.side is not None and rt.prof is None and _SIDE_WGRAD1 and (_SIDE_W1_FILTER is None or _SIDE_W1_FILTER(self)):
+      # a weight gradient is a leaf of the backward: x, dy and this layer's own records in, dw out
+      rt.side_launch(lib.conv2d_wgrad_amax_f32, rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, gy, gw, self.w_layout, alpha,
+                     rt.ws2, rt.ws_bytes, *self._dims(), rt.v(self.amax), have)
     elif gw is not None:
       rt.timed(self._kind(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_amax_f32,
                rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, gy, gw, self.w_layout, alpha,

@@ -500,3 +500,40 @@ def full_pc_iteration(st, lib, cfg_name, B, shrink_kw=None, t0=0.6):
   for k in ('corrector_x', 'corrector_x_mean', 'pc_x', 'pc_x_mean'):
     assert out[k] <= TOL, f'{cfg_name}: {k} mismatch {out[k]:.3e}'
   return out
+
+
+def full_two_streams(st, lib, cfg_name, B=128, reps=3):
+  """The benched program (full DDPM++, batch 128): the default backward -- weight gradients and shortcut convolutions on
+  the side stream -- gives the one-stream backward's gradients bit for bit, `reps` times in a row."""
+  if SHRINK:
+    B = 16
+  cfg, cfg_cpu, sde, model, ref = build_full(st, cfg_name, lib)
+  ex = model.module.engine()
+  dev = cfg.device
+  H = cfg.data.image_size
+  g = torch.Generator().manual_seed(3)
+  x = torch.randn(B, 3, H, H, generator=g).to(dev)
+  t = (torch.rand(B, generator=g) * 999).to(dev)
+  go = torch.randn(B, 3, H, H, generator=g).to(dev)
+  model.train()                      # dropout is 0 in build_full: the training-mode graph without random masks
+
+  def run(side):
+    ex.use_side = side
+    model.zero_grad()
+    flat = ex.ensure_flat()
+    xg = x.clone().requires_grad_(True)
+    (model(xg, t) * go).sum().backward()
+    torch.cuda.synchronize()
+    return flat.grad[:flat.n_train].clone(), xg.grad.clone()
+
+  was = ex.use_side
+  try:
+    base = run(False)
+    out = {'n_train': int(base[0].numel()), 'side_stream': bool(was)}
+    if was:
+      for i in range(reps):
+        got = run(True)
+        assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), f'two-stream backward {i} differs from the one-stream one'
+  finally:
+    ex.use_side = was
+  return out

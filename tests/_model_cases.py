@@ -9,6 +9,7 @@ CPU path; the kernels are exact-fp32 MFMA, so the tests hold a tighter 2e-4.
 import copy
 
 import numpy as np
+import pytest
 import torch
 
 from _model_util import build_pair, grads_close, make_state, patched_rng, rel_err, tiny_config
@@ -414,3 +415,49 @@ def golden_sampler_registry_product(st, lib):
     net.set_backend(lib)
     return cfg, st.models.utils.DataParallel(net.to(dev).eval())
   return golden_sampler_registry(st, make, TOL)
+
+
+def two_streams_deterministic(st, lib, B=96, delays=(150000, 600000, 2000000)):
+  """The backward with its weight gradients / shortcut convolutions on the side stream (engine/executor.SideStream) must
+  give the gradients of the one-stream backward BIT FOR BIT, whatever the relative timing of the two streams: every side
+  launch site in turn is held back by a spin kernel (torch.cuda._sleep) of three lengths.  This is the watch on the
+  packed-fp32 hazard of csrc/Makefile (profiles/r03_side_stream_race.txt: 3-97 of 112 such runs diverged before)."""
+  from importlib import import_module
+  G = import_module('soft-truncation_amd.engine.graph')
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, 'wide'), lib)
+  ex = model.module.engine()
+  if not ex.use_side:
+    pytest.skip('side stream switched off (STK_WGRAD_STREAM=0)')
+  dev = cfg.device
+  x, t, cond = _inputs(cfg, sde, B)
+  go = torch.randn(B, *x.shape[1:], generator=torch.Generator().manual_seed(5)).to(dev)
+  model.eval()
+
+  def run(side):
+    ex.use_side = side
+    model.zero_grad()
+    xg = x.clone().to(dev).requires_grad_(True)
+    (model(xg, cond.to(dev)) * go).sum().backward()
+    torch.cuda.synchronize()
+    return [p.grad.detach().clone() for p in model.parameters()] + [xg.grad.clone()]
+
+  saved = (G._SIDE_DELAY, G._SIDE_DELAY_FILTER)
+  try:
+    base = run(False)
+    sites = []
+    G._SIDE_DELAY, G._SIDE_DELAY_FILTER = 1, (lambda n: (sites.append(n), False)[1])
+    run(True)
+    sites = list(dict.fromkeys(sites))
+    assert len(sites) >= 10, sites
+    runs = bad = 0
+    for delay in delays:
+      for site in sites:
+        G._SIDE_DELAY, G._SIDE_DELAY_FILTER = delay, (lambda n, site=site: n == site)
+        got = run(True)
+        runs += 1
+        bad += any(not torch.equal(a, b) for a, b in zip(got, base))
+    assert bad == 0, f'{bad} of {runs} two-stream backward passes differ from the one-stream result'
+  finally:
+    G._SIDE_DELAY, G._SIDE_DELAY_FILTER = saved
+    ex.use_side = True
+  return runs

