@@ -995,7 +995,9 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
                        r.chunks_per_split, xpart, nx);                                                            \
   } else if (pl::kernel_choice() == 4 && x2d::halo_ok(p, TAPS, r.splits)) {                                       \
     /* one halo tile of the activations per channel group serves the nine taps */                                 \
-    if (p.W == 32 && x2d::halo_mode() == 2)                                                                       \
+    if (p.W == 64)                                                                                                \
+      hipLaunchKernelGGL((x2d::gemm_halo_kernel<64, E, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
+    else if (p.W == 32 && x2d::halo_mode() == 2)                                                                  \
       hipLaunchKernelGGL((x2d::gemm_halo_kernel<32, E, 2>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
     else if (p.W == 32)                                                                                           \
       hipLaunchKernelGGL((x2d::gemm_halo_kernel<32, E, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \

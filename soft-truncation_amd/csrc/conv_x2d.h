@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M,
 // from the buffer range check -- and the nine taps read their fragments from it at row offsets dy (W + 2) + dx:
 // 26 instead of 72 B-side DMA instructions per group and workgroup (W = 32), issued one per wave and chunk into the
 // OTHER of two B buffers while the current group computes.  A (weights) is staged per chunk as before.
-// Shapes: W = 16 or 32 (two workgroups per CU: 16 KB + 2 x 26 KB), maps of whole tiles (H W % 128 == 0), no K split.
+// Shapes: W = 16, 32 or (NB = 1) 64, maps of whole tiles (H W % 128 == 0), no K split.
 // NB = 2: two B buffers, the next group's tile streams in one piece per wave and chunk (two workgroups per CU);
 // NB = 1: one B buffer, refilled in a burst behind the last tap's fragment reads (three workgroups per CU cover the wait).
 template <int W, class EP, int NB>
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(ConvP p, x3::Src q, i
   constexpr int TN = 128, R = TN / W, TP = W + 2, HR = (R + 2) * TP, NI = (HR + 15) / 16, HRP = NI * 16;
   constexpr int A_PLANE = 128 * 64, A_BYTES = 2 * A_PLANE, B_PLANE = HRP * 64, B_BYTES = 2 * B_PLANE;
   constexpr int NK = (NI + 3) / 4;                                        // B instructions per wave and plane
-  static_assert(2 * NK <= 8, "the B pieces of a group are issued one per chunk over taps 0..7");
+  static_assert(NB == 1 || 2 * NK <= 8, "the B pieces of a group are issued one per chunk over taps 0..7");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[A_BYTES + NB * B_BYTES];
   unsigned char* const As = lds;
   unsigned char* const Bs = lds + A_BYTES;
@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(ConvP p, x3::Src q, i
 // shapes of the halo kernel: 3x3 on 16- or 32-wide maps made of whole 128-pixel tiles, no K split (STK_X2D_HALO=0: off)
 inline int halo_mode() { static const int v = [] { const char* e = getenv("STK_X2D_HALO"); return e ? atoi(e) : 1; }(); return v; }
 inline bool halo_ok(const ConvP& p, int taps, int splits) {
-  return halo_mode() != 0 && taps == 9 && splits == 1 && (p.W == 16 || p.W == 32) && p.HW % 128 == 0 && p.H * p.W == p.HW;
+  return halo_mode() != 0 && taps == 9 && splits == 1 && (p.W == 16 || p.W == 32 || (p.W == 64 && halo_mode() == 1)) &&
+         p.HW % 128 == 0 && p.H * p.W == p.HW;
 }
 
 }  // namespace x2d

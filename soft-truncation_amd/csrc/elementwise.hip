@@ -7,6 +7,10 @@
 // 8 blocks per CU and grid-stride the rest.
 #include "common.h"
 
+// A product that must be ROUNDED before it is used (torch evaluates a * x + b as two kernels): HIP's __fmul_rn is a plain
+// product the compiler may contract into an fma; an empty asm on the value is an optimisation barrier it cannot see through.
+__device__ __forceinline__ float rounded(float v) { asm volatile("" : "+v"(v)); return v; }
+
 namespace {
 
 template <int V> struct Vec;
@@ -159,10 +163,10 @@ struct Perturb {    // out = a[n]*x + s[n]*z  (losses.py:118-119)
     if (a) {
       const float av = a[n];
 #pragma unroll
-      for (int j = 0; j < V; ++j) xv.v[j] = av * xv.v[j] + sv * zv.v[j];
+      for (int j = 0; j < V; ++j) xv.v[j] = rounded(av * xv.v[j]) + rounded(sv * zv.v[j]);   // torch: mean + std * z, three roundings
     } else {
 #pragma unroll
-      for (int j = 0; j < V; ++j) xv.v[j] = xv.v[j] + sv * zv.v[j];
+      for (int j = 0; j < V; ++j) xv.v[j] = xv.v[j] + rounded(sv * zv.v[j]);
     }
     xv.store(out, i);
   }
@@ -268,9 +272,10 @@ __global__ __launch_bounds__(256) void sm_loss_fwd_kernel(const float* __restric
   const float* zz = z + (long)n * inner;
   float acc[1] = {0.f};
   for (long i = threadIdx.x; i < inner; i += 256) {
-    float score = vp ? -o[i] / sd : o[i];
-    float r = mode == 0 ? score * sd + zz[i] : score + zz[i] / sd;
-    acc[0] += r * r;
+    // the reference's element-wise sequence, every operation rounded on its own (losses.py:122-132; models/utils.py:160)
+    const float score = vp ? -o[i] / sd : o[i];
+    const float r = mode == 0 ? rounded(score * sd) + zz[i] : score + zz[i] / sd;
+    acc[0] += rounded(r * r);
   }
   block_sum<1>(acc, red);
   if (threadIdx.x == 0) {

@@ -26,7 +26,7 @@ from .engine import ddp
 from .engine.flat import flat_of
 from .engine.optim import FusedAdam
 from .models import utils as mutils
-from .sde_lib import VESDE, VPSDE
+from .sde_lib import VESDE, VPSDE, reciprocal_VESDE
 
 
 def _wide(v):
@@ -81,6 +81,54 @@ def optimization_manager(config):
   return optimize_fn
 
 
+# STK_FUSED_LOSS=0: the loss arithmetic around the network as the reference's torch expressions (~35 small launches per
+# evaluation and as many in its backward) instead of three kernels (A/B switch; results agree to the last bits)
+FUSED_LOSS = os.environ.get('STK_FUSED_LOSS', '1') != '0'
+
+
+class _ScoreMatching(torch.autograd.Function):
+  """losses[n] = wgt[n] * reduce((score * std + z)^2) with score = -net / std (VP) or net -- the tail of the reference's
+  loss_fn (losses.py:122-132 behind models/utils.py:160) as ONE kernel per direction (stk_sm_loss_*) on the raw network
+  output, every element-wise operation rounded as torch rounds it."""
+
+  @staticmethod
+  def forward(ctx, net, z, std, wgt, lib, neg_over_std, reduce_mean):
+    from .engine import lib as stk_lib
+    net, z, std, wgt = net.contiguous(), z.contiguous(), std.contiguous(), wgt.contiguous()
+    B, inner = net.shape[0], net[0].numel()
+    losses = torch.empty(B, dtype=torch.float32, device=net.device)
+    with stk_lib.device_guard(net.device):
+      lib.sm_loss_fwd_f32(net.data_ptr(), z.data_ptr(), std.data_ptr(), wgt.data_ptr(), losses.data_ptr(), B, inner,
+                          int(neg_over_std), 0, int(reduce_mean), stk_lib.stream_ptr(net.device))
+    ctx.save_for_backward(net, z, std, wgt)
+    ctx.args = (lib, B, inner, int(neg_over_std), int(reduce_mean))
+    return losses
+
+  @staticmethod
+  def backward(ctx, dloss):
+    from .engine import lib as stk_lib
+    net, z, std, wgt = ctx.saved_tensors
+    lib, B, inner, vp, rm = ctx.args
+    dnet = torch.empty_like(net)
+    dloss = dloss.contiguous()
+    with stk_lib.device_guard(net.device):
+      lib.sm_loss_bwd_f32(net.data_ptr(), z.data_ptr(), std.data_ptr(), wgt.data_ptr(), dloss.data_ptr(), dnet.data_ptr(),
+                          B, inner, vp, 0, rm, stk_lib.stream_ptr(net.device))
+    return dnet, None, None, None, None, None, None
+
+
+def _engine_lib(model, batch):
+  """The kernel library of a score network that runs on the engine, when `batch` lives where that library computes."""
+  net = getattr(model, 'module', model)
+  engine = getattr(net, 'engine', None)
+  if engine is None:
+    return None
+  lib = engine().lib
+  if lib.is_device != batch.is_cuda or batch.dtype != torch.float32 or not hasattr(lib, 'sm_loss_fwd_f32'):
+    return None
+  return lib
+
+
 def get_sde_loss_fn(config, sde, train, variance='scoreflow'):
   """Soft-truncation weighted denoising score matching for a continuous SDE (losses.py:61-168):
   ``loss_fn(model, batch, importance_sampling, t_min=None) -> [B]``."""
@@ -109,10 +157,34 @@ def get_sde_loss_fn(config, sde, train, variance='scoreflow'):
       assert losses.shape == term.shape
     return term / np.prod(list(batch.shape[1:])) if tr.reduce_mean else term
 
+  def fused_losses(lib, raw_fn, neg_over_std, batch, t, Z):
+    """The same values from three kernels: x_t = mean + std z (stk_perturb_f32, bit-identical to the torch expression),
+    the network, the weighted squared residual per sample (stk_sm_loss_fwd_f32 / _bwd_f32)."""
+    from .engine import lib as stk_lib
+    B = batch.shape[0]
+    z = torch.randn_like(batch)
+    ones = torch.ones((B, 1, 1, 1), dtype=batch.dtype, device=batch.device)
+    coeff, std = sde.marginal_prob(ones, t)                    # mean = coeff * x: [B,1,1,1] coefficients, [B] std
+    std = std.to(torch.float32).contiguous()
+    x = batch.contiguous()
+    xt = torch.empty_like(x)
+    a = None if isinstance(sde, (VESDE, reciprocal_VESDE)) else coeff.reshape(B).to(torch.float32).contiguous()
+    with stk_lib.device_guard(x.device):
+      lib.perturb_f32(x.data_ptr(), z.data_ptr(), a.data_ptr() if a is not None else None, std.data_ptr(), xt.data_ptr(),
+                      B, x[0].numel(), stk_lib.stream_ptr(x.device))
+    net = raw_fn(xt, t)
+    wgt = (0.5 * Z) * torch.ones(B, dtype=torch.float32, device=x.device)
+    return _ScoreMatching.apply(net, z, std, wgt, lib, neg_over_std, bool(tr.reduce_mean))
+
   def loss_fn(model, batch, importance_sampling, t_min=None):
     if t_min is None:
       t_min = sde.get_t_min(config)
     t, Z = sde.get_diffusion_time(config, batch.shape[0], batch.device, t_min, importance_sampling=importance_sampling)
+    if FUSED_LOSS and not tr.reconstruction_loss and (tr.importance_sampling or not tr.likelihood_weighting):
+      lib = _engine_lib(model, batch)
+      raw_fn, neg_over_std = mutils.get_raw_fn(config, sde, model, train=train, continuous=tr.continuous) if lib is not None else (None, None)
+      if raw_fn is not None:
+        return fused_losses(lib, raw_fn, neg_over_std, batch, t, Z)
     score_fn = mutils.get_score_fn(config, sde, model, train=train, continuous=tr.continuous)
     z = torch.randn_like(batch)
     mean, std = sde.marginal_prob(batch, t)

@@ -142,6 +142,22 @@ def _ve_score_fn(sde, model_fn, continuous):
   return score_fn
 
 
+def get_raw_fn(config, sde, model, train=False, continuous=False):
+  """The pieces of :func:`get_score_fn` for callers that fuse what follows the network (losses.py's fused loss path):
+  ``raw_fn(x, t) -> network output`` with exactly the conditioning labels `get_score_fn` computes, and ``neg_over_std``:
+  whether the score is ``-output / std(t)`` (VP family with ``training.ddpm_score``) or the output itself.  Returns
+  ``(None, None)`` for the combinations it does not cover (discrete ladders)."""
+  model_fn = get_model_fn(model, train=train)
+  if isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE)):
+    if not (continuous or isinstance(sde, sde_lib.subVPSDE)):
+      return None, None
+    return (lambda x, t: model_fn(x, _vp_time_labels(config, sde, t))), bool(config.training.ddpm_score)
+  if isinstance(sde, (sde_lib.VESDE, sde_lib.reciprocal_VESDE)) and continuous:
+    tiny = lambda x: torch.zeros((x.shape[0], 1, 1, 1), dtype=x.dtype, device=x.device)
+    return (lambda x, t: model_fn(x, sde.marginal_prob(tiny(x), t)[1])), False      # labels = sigma(t)
+  return None, None
+
+
 def get_score_fn(config, sde, model, train=False, continuous=False):
   """Turn the raw network into a score function s(x, t) (models/utils.py:128-190).
 

@@ -461,3 +461,49 @@ def two_streams_deterministic(st, lib, B=96, delays=(150000, 600000, 2000000)):
     G._SIDE_DELAY, G._SIDE_DELAY_FILTER = saved
     ex.use_side = True
   return runs
+
+
+def fused_loss_matches_torch(st, lib, family):
+  """losses.get_sde_loss_fn: the three-kernel path (stk_perturb / network / stk_sm_loss) against the reference's torch
+  expressions on the SAME engine, noise and times: x_t bit-identical, per-sample losses to 1e-6, gradients to 1e-5."""
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, family), lib)
+  dev = cfg.device
+  B = 6
+  batch = st.datasets.synthetic_batch(cfg_cpu, B, generator=torch.Generator().manual_seed(3)).to(dev)
+  loss_fn = st.losses.get_sde_loss_fn(cfg, sde, train=True)
+  out = {}
+  saved = st.losses.FUSED_LOSS
+  try:
+    for fused in (True, False):
+      st.losses.FUSED_LOSS = fused
+      model.zero_grad()
+      np.random.seed(0)
+      with patched_rng(17):
+        losses = loss_fn(model, batch, importance_sampling=cfg.training.importance_sampling, t_min=1e-3)
+      torch.mean(losses).backward()
+      out[fused] = (losses.detach().cpu().double(), [p.grad.detach().cpu().double().clone() for p in model.parameters() if p.grad is not None])
+  finally:
+    st.losses.FUSED_LOSS = saved
+  (lf, gf), (lt, gt) = out[True], out[False]
+  e_loss = float(((lf - lt).abs() / lt.abs()).max())
+  scale = max(float(g.abs().max()) for g in gt)
+  e_grad = max(float((a - b).abs().max()) for a, b in zip(gf, gt)) / scale
+  assert e_loss <= 1e-6 and e_grad <= 1e-5, (e_loss, e_grad)
+  # the perturbation kernel against the torch expression, bit for bit (device tensors on the HIP library)
+  g = torch.Generator().manual_seed(5)
+  x = torch.randn(B, 3, 16, 16, generator=g).to(dev)
+  z = torch.randn(B, 3, 16, 16, generator=g).to(dev)
+  a = torch.rand(B, generator=g).to(dev)
+  s_ = (torch.rand(B, generator=g) * 3).to(dev)
+  from _util import call
+  got = torch.empty_like(x)
+  call(lib, 'perturb_f32', x, z, a, s_, got, B, x[0].numel())
+  want = a[:, None, None, None] * x + s_[:, None, None, None] * z
+  got_ve = torch.empty_like(x)
+  call(lib, 'perturb_f32', x, z, None, s_, got_ve, B, x[0].numel())
+  want_ve = x + s_[:, None, None, None] * z
+  if lib.is_device:
+    assert torch.equal(got, want) and torch.equal(got_ve, want_ve)
+  else:
+    assert (got - want).abs().max().item() <= 1e-6 and (got_ve - want_ve).abs().max().item() <= 1e-6
+  return e_loss, e_grad

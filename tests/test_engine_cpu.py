@@ -345,3 +345,10 @@ def test_flat_of_rejects_partial_and_foreign_lists(st, ref_lib):
   assert flat_mod.flat_of(mixed) is None                                         # a parameter of another buffer
   with pytest.raises(Exception):
     st.engine.optim.FusedAdam(mixed, backend=ref_lib)._bind()
+
+
+def test_fused_loss_path_on_the_checker(st, ref_lib):
+  """losses.get_sde_loss_fn's three-kernel path on the CPU checker against the torch expressions (VP and VE)."""
+  import _model_cases as cases
+  for family in ('vp', 've'):
+    cases.fused_loss_matches_torch(st, ref_lib, family)

@@ -151,6 +151,12 @@ def test_two_ranks_on_one_gpu_match_single_process(st, hip_lib, tmp_path):
   assert (got[0]['shadow'] - shadow).abs().max().item() <= 0.05 * lr * steps
 
 
+@pytest.mark.parametrize('family', ['vp', 've'])
+def test_fused_loss_path(st, hip_lib, family):
+  """The default (three-kernel) loss path equals the reference's torch expressions on the same engine."""
+  print('fused loss path:', cases.fused_loss_matches_torch(st, hip_lib, family))
+
+
 def test_two_streams_are_deterministic(st, hip_lib):
   """Weight gradients on the side stream: bit-identical to the one-stream backward under ~80 timing perturbations."""
   if os.environ.get('STK_SELFCHECK'):
