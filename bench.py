@@ -18,8 +18,8 @@ Extra objects in that line:
                 fp16 two-way-split kernels (three fp16 MFMAs per fp32 product; labels .x2 / .x2p...), 2500 / 6 for
                 the bf16 three-way-split ones (.x3), 157.3 for the f32-input MFMA kernels (MI355X_MICROARCH.md).
                 One label = one kernel symbol of the rocprofv3 summaries (KERNEL_SYMBOL below): .x2p = LDS-DMA GEMM on
-                plane operands, .x2p.k = its K-split form on small maps (partial slabs + slab sum; the bracket covers
-                both launches), .x2p.w32/.w16/.w8/.w4 = the planes weight gradient per map width (bracket = kernel +
+                plane operands, .x2p.h16/.h32/.h64 = its halo-tile form on the 16/32/64-wide maps, .x2p.k = its K-split
+                form on small maps (partial slabs + slab sum; the bracket covers both launches), .x2p.w32/.w16/.w8/.w4 = the planes weight gradient per map width (bracket = kernel +
                 its slab reduce).  `kernels` lists the other contraction kernels the same way; `traffic` comes from
                 the newest committed PMC summary (profiles/rNN_traffic.json).
   parity_probe  the benched build checks itself: per-sample soft-truncation losses of one batch-8 step on the HIP
@@ -62,11 +62,15 @@ KERNEL_SYMBOL = {
   'conv1x1.wgrad.x2': 'x2::wgemm_kernel<x2::RowsU<false, false>, x2::RowsU<true, true>, EpWgrad, true>',
   # plane operands (round 2): LDS-DMA staged forward / data gradient ('.k' = the K-split form of the small maps: EpSlab
   # partial tiles + a slab-sum launch), transpose-read weight gradient (one symbol per map width)
-  'conv3x3.fwd.x2p': 'x2d::gemm_kernel<9, 128, EpFwd>',
-  'conv3x3.dgrad.x2p': 'x2d::gemm_kernel<9, 128, EpDgrad>',
-  'conv3x3.fwd.x2p.k': 'x2d::gemm_kernel<9, 128, EpSlab>',
-  'conv3x3.dgrad.x2p.k': 'x2d::gemm_kernel<9, 128, EpSlab>',
-  'conv1x1.fwd.x2p': 'x2d::gemm_kernel<1, 128, EpFwd>',
+  'conv3x3.fwd.x2p': 'x2d::gemm_kernel<9, 128, EpFwd, 1, 0>',
+  'conv3x3.dgrad.x2p': 'x2d::gemm_kernel<9, 128, EpDgrad, 1, 0>',
+  'conv3x3.fwd.x2p.k': 'x2d::gemm_kernel<9, 128, EpSlab, 1, 0>',
+  'conv3x3.dgrad.x2p.k': 'x2d::gemm_kernel<9, 128, EpSlab, 1, 0>',
+  'conv1x1.fwd.x2p': 'x2d::gemm_kernel<1, 128, EpFwd, 1, 0>',
+  # round 3: the halo-tile GEMM (one staged halo tile of the activations per channel group serves the nine taps)
+  'conv3x3.fwd.x2p.h16': 'x2d::gemm_halo_kernel<16, EpFwd, 1>', 'conv3x3.dgrad.x2p.h16': 'x2d::gemm_halo_kernel<16, EpDgrad, 1>',
+  'conv3x3.fwd.x2p.h32': 'x2d::gemm_halo_kernel<32, EpFwd, 1>', 'conv3x3.dgrad.x2p.h32': 'x2d::gemm_halo_kernel<32, EpDgrad, 1>',
+  'conv3x3.fwd.x2p.h64': 'x2d::gemm_halo_kernel<64, EpFwd, 1>', 'conv3x3.dgrad.x2p.h64': 'x2d::gemm_halo_kernel<64, EpDgrad, 1>',
   'conv3x3.wgrad.x2p.w32': 'x2w::wgrad_kernel<32>',
   'conv3x3.wgrad.x2p.w16': 'x2w::wgrad_kernel<16>',
   'conv3x3.wgrad.x2p.w8': 'x2w::wgrad_kernel<8>',

@@ -1447,6 +1447,16 @@ int stk_conv2d_wgrad_pl_f32(const void* xpl, const float* xrec, const void* dypl
   return STK_OK;
 }
 
+/* map width of the halo-tile GEMM (x2d::gemm_halo_kernel<W, ..>) the plane-operand forward / data-gradient call of this
+ * shape runs on, 0 = x2d::gemm_kernel (diagnostic: one profiler label per kernel symbol) */
+int stk_conv2d_pl_halo(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW) {
+  const int ks = stk_conv2d_pl_ksplit(dir, C1, C2, N, H, W, Cout, KH, KW);
+  if (ks <= 0 || pl::kernel_choice() != 4) return 0;
+  ConvP p = {};
+  if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, 1, KH / 2)) return 0;
+  return x2d::halo_ok(p, p.taps, ks) ? W : 0;
+}
+
 /* which kernel family a call with full scratch takes: 0/1 = f32-input MFMA with 64/128 tiles, 2 = bf16 three-way
  * split, 3 = f32-input all-taps weight gradient, 4 = thin-side streaming kernels, 5 = fp16 two-way split.  dir: 0 fwd, 1 dgrad, 2 wgrad. */
 int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, int OH, int OW, int KH, int KW,

@@ -861,6 +861,163 @@ __global__ __launch_bounds__(1024) void gn_fwd_pl_kernel(GnArgs a, float* __rest
   }
 }
 
+// ---- forward writing planes, two kernels (round 3) -----------------------------------------------------------------
+// The one-pass kernel above holds a (sample, 32-channel block) in registers between the statistics and the
+// normalisation: on the large maps that is one or two big workgroups per CU whose load, reduce and store phases do not
+// overlap (32x32: 2.7-3.3 TB/s against 6.9 for a copy).  Here the statistics are their own streaming kernel (x read once,
+// nothing written but mean / rstd), and the normalisation + SiLU + dropout + split is a second one with the tiling of
+// pl::split_planes_kernel -- a workgroup per (sample, 32-channel block, 128-pixel tile), all element-wise work done on
+// the float4 (four consecutive pixels of one channel = one dropout RNG quad) before the tile goes through LDS for the
+// transposition to [pixel][32 channels].  x is read twice, the second time out of the Infinity Cache.
+__global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                       float eps, float sqrt_lm1, float* __restrict__ rec) {
+  __shared__ float red[16];
+  const int ng = blockIdx.x;
+  const int n = ng / a.G, g = ng - n * a.G;
+  Seg seg[2];
+  group_segments(a, n, g, seg);                          // whole groups per source (C1 % cpg == 0): one segment is empty
+  const float* p = seg[0].len ? seg[0].p : seg[1].p;
+  const int L = a.cpg * a.HW, L4 = L >> 2;
+  const float shift = p[0];
+  const float4* p4 = reinterpret_cast<const float4*>(p);
+  float s[2] = {0.f, 0.f};
+  for (int i = threadIdx.x; i < L4; i += 256) {
+    const float4 v = p4[i];
+    const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+    s[0] += (d0 + d1) + (d2 + d3);
+    s[1] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  block_sum<2>(s, red);
+  const float inv_l = 1.f / (float)L;
+  const float md = s[0] * inv_l;
+  const float var = fmaxf(s[1] * inv_l - md * md, 0.f);
+  if (threadIdx.x == 0) {
+    mean_out[ng] = shift + md;
+    rstd_out[ng] = 1.f / sqrtf(var + eps);
+  }
+  if (rec && ng == 0) {                                  // the planes' scale record: a-priori bound of |y| (gn_bound_kernel)
+    const int C = a.C1 + a.C2;
+    float gm = 0.f, bm = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) { gm = fmaxf(gm, fabsf(a.gamma[c])); bm = fmaxf(bm, fabsf(a.beta[c])); }
+    gm = wave_max(gm); bm = wave_max(bm);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = gm; red[4 + (threadIdx.x >> 6)] = bm; }
+    __syncthreads();
+    gm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    bm = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    rec[threadIdx.x] = threadIdx.x == 0 ? __fmaf_rn(gm, sqrt_lm1, bm) * a.keep_scale : 0.f;
+  }
+}
+
+// mean / rstd of large groups from the per-chunk partials of gn_split_stats_kernel (fixed order), + the scale record
+__global__ __launch_bounds__(256) void gn_fold_stats_kernel(GnArgs a, const float* __restrict__ part, int Sc,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            float eps) {
+  __shared__ float red[16];
+  const int ng = blockIdx.x;
+  const int n = ng / a.G, g = ng - n * a.G;
+  const int C = a.C1 + a.C2;
+  const float shift = gn_chan(a, n, g * a.cpg)[0];
+  float s[2] = {0.f, 0.f};
+  const long pbase = ((long)n * C + g * a.cpg) * Sc;
+  for (int i = threadIdx.x; i < a.cpg * Sc; i += 256) { s[0] += part[(pbase + i) * 2]; s[1] += part[(pbase + i) * 2 + 1]; }
+  block_sum<2>(s, red);
+  const float inv_l = 1.f / ((float)a.cpg * (float)a.HW);
+  const float md = s[0] * inv_l;
+  const float var = fmaxf(s[1] * inv_l - md * md, 0.f);
+  if (threadIdx.x == 0) { mean_out[ng] = shift + md; rstd_out[ng] = 1.f / sqrtf(var + eps); }
+}
+
+constexpr int AP_PIX = 128;
+__global__ __launch_bounds__(256) void gn_apply_pl_kernel(GnArgs a, const float* __restrict__ mean_in,
+                                                          const float* __restrict__ rstd_in, const float* __restrict__ rec,
+                                                          float* __restrict__ y, unsigned char* __restrict__ planes,
+                                                          long plane_stride, float* __restrict__ xmax1,
+                                                          float* __restrict__ xmax2) {
+  __shared__ float t[32 * 129];
+  __shared__ float xm[4];
+  const int tid = threadIdx.x;
+  const int C = a.C1 + a.C2, Cb = C >> 5;
+  const int tiles = a.HW / AP_PIX;
+  const int tile = blockIdx.x % tiles, rest = blockIdx.x / tiles;
+  const int cb = rest % Cb, n = rest / Cb;
+  const int c0 = cb * 32, p0 = tile * AP_PIX;
+  const float* src = c0 < a.C1 ? a.x1 + ((long)n * a.C1 + c0) * a.HW : a.x2 + ((long)n * a.C2 + (c0 - a.C1)) * a.HW;
+  // the power of two that puts the bound in [2^13, 2^14) (x2::pow2_scale_of in conv_x2.h)
+  float sc = 1.f;
+  {
+    const int be = (int)((__float_as_uint(rec[0]) >> 23) & 0xffu);
+    if (be != 0) sc = __uint_as_float((unsigned)min(max(127 + 13 - (be - 127), 1), 254) << 23);
+  }
+  unsigned long long seed = a.seed;
+  if (a.drop_p > 0.f && a.seed_dev) seed += *a.seed_dev;
+  float amax_l = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = tid + 256 * k;
+    const int c = i >> 5, q4 = i & 31;
+    const int ch = c0 + c, px = p0 + 4 * q4;
+    const float4 v = *reinterpret_cast<const float4*>(src + (long)c * a.HW + px);
+    const int g = ch / a.cpg;
+    const float mean = mean_in[n * a.G + g], rstd = rstd_in[n * a.G + g];
+    const float ga = a.gamma[ch], be = a.beta[ch];
+    float r[4] = {v.x, v.y, v.z, v.w};
+    if (xmax1) amax_l = fmaxf(amax_l, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
+    const unsigned long long flat = ((unsigned long long)n * C + ch) * a.HW + px;
+    unsigned long long z = 0;
+    if (a.drop_p > 0.f) z = stk_mix64(seed, flat >> 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float u = ga * ((r[j] - mean) * rstd) + be;
+      float o = a.act ? silu_f(u) : u;
+      if (a.drop_p > 0.f) o = stk_drop_field(z, j) >= a.drop_thr ? o * a.keep_scale : 0.f;
+      r[j] = o;
+    }
+    if (y) *reinterpret_cast<float4*>(y + ((long)n * C + ch) * a.HW + px) = make_float4(r[0], r[1], r[2], r[3]);
+    float* d = t + c * 129 + 4 * q4;
+    d[0] = sc * r[0]; d[1] = sc * r[1]; d[2] = sc * r[2]; d[3] = sc * r[3];
+  }
+  if (xmax1) {
+    const float m = wave_max(amax_l);
+    if ((tid & 63) == 0) xm[tid >> 6] = m;
+  }
+  __syncthreads();
+  if (xmax1 && tid == 0) {
+    float* dst = c0 < a.C1 ? xmax1 : xmax2;
+    if (dst) atomicMax(reinterpret_cast<unsigned*>(dst) + (blockIdx.x & 255),
+                       __float_as_uint(fmaxf(fmaxf(xm[0], xm[1]), fmaxf(xm[2], xm[3]))));
+  }
+#pragma unroll
+  for (int r2 = 0; r2 < 2; ++r2) {
+    const int id = tid + 256 * r2;
+    const int px = id >> 2, q = id & 3;
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v0 = t[(8 * q + 2 * j) * 129 + px], v1 = t[(8 * q + 2 * j + 1) * 129 + px];
+      const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+      const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      hi[j] = __builtin_bit_cast(unsigned, h2{h0, h1});
+      lo[j] = __builtin_bit_cast(unsigned, h2{l0, l1});
+    }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    unsigned char* o = planes + (((long)n * Cb + cb) * a.HW + p0 + px) * 64 + q * 16;
+    *reinterpret_cast<u4*>(o) = u4{hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<u4*>(o + plane_stride) = u4{lo[0], lo[1], lo[2], lo[3]};
+  }
+}
+
+// shapes of the two-kernel route: maps of whole 128-pixel tiles, whole groups per 32-channel block and per source
+static inline bool gn_pl_2k_ok(int C1, int C2, int HW, int G) {
+  static const bool on = [] { const char* e = getenv("STK_GN_PL_2K"); return !e || atoi(e) != 0; }();
+  const int C = C1 + C2;
+  if (!on || C % 32 || C1 % 32 || C % G || HW % AP_PIX) return false;
+  const int cpg = C / G;
+  if (cpg > 32 || 32 % cpg) return false;
+  const long L = (long)cpg * HW;
+  return L <= 16384 || gn_split_ok(HW, cpg);
+}
+
 // shapes the fused kernel takes: whole groups per 32-channel block, both sources in whole blocks, the block in registers
 static inline bool gn_pl_fused_ok(int C1, int C2, int HW, int G) {
   const int C = C1 + C2;
@@ -943,7 +1100,7 @@ int stk_gn_fwd_pl_max_f32(const float* x1, int C1, const float* x2, int C2, cons
                           void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
                           float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws,
                           float* xmax1, float* xmax2, void* stream) {
-  if (!xmax1 || (C2 > 0 && !xmax2) || !gn_pl_fused_ok(C1, C2, HW, G)) return STK_EINVAL;
+  if (!xmax1 || (C2 > 0 && !xmax2) || !(gn_pl_fused_ok(C1, C2, HW, G) || gn_pl_2k_ok(C1, C2, HW, G))) return STK_EINVAL;
   return gn_fwd_pl_impl(x1, C1, x2, C2, gamma, beta, y, planes, rec, mean, rstd, N, HW, G, eps, act, drop_p, seed, seed_dev, ws,
                         stream, xmax1, xmax2);
 }
@@ -958,6 +1115,28 @@ static int gn_fwd_pl_impl(const float* x1, int C1, const float* x2, int C2, cons
     return STK_EINVAL;
   const long plane_stride = (long)N * ((C + 31) / 32) * HW * 64;
   if (2 * plane_stride >= 0x7fffffffL) return STK_EUNSUPPORTED;
+  if (gn_pl_2k_ok(C1, C2, HW, G) && stk_aligned16(x1) && (!x2 || stk_aligned16(x2)) && (!y || stk_aligned16(y))) {
+    GnArgs a;
+    a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
+    a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p); a.drop_thr = stk_drop_threshold(drop_p);
+    a.seed = seed; a.seed_dev = seed_dev;
+    const float sq = sqrtf((float)((long)a.cpg * HW) - 1.f);
+    hipStream_t s = (hipStream_t)stream;
+    if ((long)a.cpg * HW <= 16384) {
+      hipLaunchKernelGGL(gn_stats_kernel, dim3(N * G), dim3(256), 0, s, a, mean, rstd, eps, sq, rec);
+    } else {
+      if (!ws) return STK_EINVAL;
+      const int Sc = HW / GN_CHUNK;
+      hipLaunchKernelGGL(gn_split_stats_kernel, dim3((unsigned)((long)N * C * Sc)), dim3(256), 0, s, a, ws, Sc);
+      hipLaunchKernelGGL(gn_fold_stats_kernel, dim3(N * G), dim3(256), 0, s, a, ws, Sc, mean, rstd, eps);
+      hipLaunchKernelGGL(gn_bound_kernel, dim3(1), dim3(256), 0, s, gamma, beta, C, sq, a.keep_scale, rec);
+    }
+    STK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_pl_kernel, dim3((unsigned)((long)N * (C / 32) * (HW / AP_PIX))), dim3(256), 0, s, a, mean, rstd, rec, y,
+                       static_cast<unsigned char*>(planes), plane_stride, xmax1, xmax2);
+    STK_CHECK_LAUNCH();
+    return STK_OK;
+  }
   if (gn_pl_fused_ok(C1, C2, HW, G)) {
     GnArgs a;
     a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
@@ -988,7 +1167,7 @@ static int gn_fwd_pl_impl(const float* x1, int C1, const float* x2, int C2, cons
 }
 
 /* 1 if stk_gn_fwd_pl_f32 takes this shape in one pass (and therefore accepts y = NULL) */
-int stk_gn_fwd_pl_fused(int C1, int C2, int HW, int G) { return gn_pl_fused_ok(C1, C2, HW, G) ? 1 : 0; }
+int stk_gn_fwd_pl_fused(int C1, int C2, int HW, int G) { return gn_pl_fused_ok(C1, C2, HW, G) || gn_pl_2k_ok(C1, C2, HW, G) ? 1 : 0; }
 
 /* shapes whose backward runs on the register-resident kernel and can therefore leave the by-products behind */
 static inline bool gn_bwd_flat_shape(int C, int HW, int G) {

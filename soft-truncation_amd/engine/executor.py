@@ -464,7 +464,8 @@ class Executor:
       seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     c.uses += 1
     done = False
-    if self._graphs_on() and c.uses > 1:          # first use of a context runs eagerly (warm-up)
+    eager_fwd = with_backward and self.use_side and os.environ.get('STK_FWD_SIDE', '0') == '1'
+    if self._graphs_on() and c.uses > 1 and not eager_fwd:          # first use of a context runs eagerly (warm-up)
       if c.seed_t is None:
         c.seed_t = torch.zeros(1, dtype=torch.int64, device=flat.device)
       if c.gact is None and torch.is_grad_enabled():
@@ -476,7 +477,9 @@ class Executor:
     if not done:
       rt = self._runtime(c, training, seed, None, with_backward)
       for op in g.ops:
+        rt.guard_fwd(op)
         op.forward(rt)
+      rt.join_side()
       c.rt = rt
     o = g.output
     out = c.act[o.off:o.off + o.numel].view(o.shape).clone()

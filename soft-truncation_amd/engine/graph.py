@@ -24,6 +24,7 @@ SQRT2 = float(np.float32(np.sqrt(2.)))
 # A/B switches of the side stream (engine/executor.SideStream): shortcut convolutions' backward / fp32-operand weight gradients
 _SIDE_SHORTCUT = os.environ.get('STK_SIDE_SHORTCUT', '1') != '0'
 _SIDE_WGRAD1 = os.environ.get('STK_SIDE_WGRAD1', '1') != '0'
+_SIDE_FWD = os.environ.get('STK_FWD_SIDE', '0') == '1'     # shortcut convolutions of an (eagerly launched) forward on the side stream
 _SIDE_W1_FILTER = None      # debugging: predicate on the Conv op
 _SIDE_DELAY = int(os.environ.get('STK_SIDE_DELAY', '0'))
 _SIDE_DELAY_FILTER = None
@@ -134,6 +135,31 @@ class Runtime:
     for t in writes:
       if t is not None:
         self.pending[id(t)] = ev
+
+  def run_on_side_fwd(self, outputs, fn):
+    """Forward counterpart of run_on_side: `outputs` = the activation tensors whose VALUES fn writes."""
+    side = self.side
+    s = side.begin()
+    saved = (self.stream, self.ws)
+    self.stream, self.ws, self.side = s, self.ws2, None
+    try:
+      fn()
+    finally:
+      self.stream, self.ws = saved
+      self.side = side
+    ev = side.end()
+    for t in outputs:
+      self.pending[('v', id(t))] = ev
+
+  def guard_fwd(self, op):
+    """Before op.forward on the main stream: wait for side-stream work that wrote a tensor this op reads."""
+    if not self.pending:
+      return
+    for v in vars(op).values():
+      if isinstance(v, Tensor):
+        ev = self.pending.pop(('v', id(v)), None)
+        if ev is not None:
+          self.side.main_waits(ev)
 
   def guard(self, op):
     """Called before op.backward on the main stream: wait for side-stream work that wrote a gradient this op reads or
@@ -380,7 +406,7 @@ class Conv(Op):
   def _label_pl(self, lib, direction):
     """Profiler label of a plane-operand launch: one label per kernel SYMBOL (bench.py's roofline is per kernel):
     fwd / dgrad: '...x2p' = x2d::gemm_kernel<.., EpFwd / EpDgrad>, '...x2p.k' = its K-split form (EpSlab + slab sum, small
-    maps); wgrad: '...x2p.w32' / '.w16' / '.w8' / '.w4' = x2w::wgrad_kernel<min(W, 32)>."""
+    maps), '...x2p.h16 / .h32 / .h64' = x2d::gemm_halo_kernel<W, ..> (the halo-tile GEMM of the 16 / 32 / 64-wide maps); wgrad: '...x2p.w32' / '.w16' / '.w8' / '.w4' = x2w::wgrad_kernel<min(W, 32)>."""
     key = '_label_' + direction
     k = getattr(self, key, None)
     if k is None:
@@ -392,6 +418,10 @@ class Conv(Op):
         c2 = 0 if d == 0 else self.C2
         if int(lib.conv2d_pl_ksplit(d, self.C1, c2, self.N, self.H, self.W, self.Cout, self.KH, self.KW)) > 1:
           k += '.k'
+        elif hasattr(lib, 'conv2d_pl_halo'):
+          hw = int(lib.conv2d_pl_halo(d, self.C1, c2, self.N, self.H, self.W, self.Cout, self.KH, self.KW))
+          if hw:
+            k += f'.h{hw}'
       setattr(self, key, k)
     return k
 
@@ -484,6 +514,12 @@ class Conv(Op):
       Op.plan_backward(self)
 
   def forward(self, rt):
+    if self.dy_from is not None and rt.side is not None and rt.prof is None and _SIDE_FWD:
+      # the block's 1x1 shortcut (HBM-bound) beside its first 3x3 convolution (matrix-pipe-bound); Conv_1 waits for it
+      return rt.run_on_side_fwd((self.y,), lambda: self._forward(rt))
+    return self._forward(rt)
+
+  def _forward(self, rt):
     temb = rt.v(self.temb) + 4 * self.temb_col if self.temb is not None else None
     if self.pl_fwd:
       t = self.x1

@@ -43,7 +43,7 @@ print('roofline:', json.dumps(bench.get('roofline')))
 stats = first('stats/*kernel_stats.csv')
 rows = list(csv.DictReader(open(stats))) if stats else []
 steps = 13.0   # 10 timed + 3 warm-up steps in the profiled command (+ eager profiling steps, see the bench line)
-print('\nper-kernel time, rocprofv3 --kernel-trace --stats of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline`')
+print('\nper-kernel time, rocprofv3 --kernel-trace --stats of `STK_WGRAD_STREAM=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --sampler-steps 0` (one stream, training only)')
 print(f'{"kernel":92s} {"calls":>8s} {"avg_us":>9s} {"total_ms":>10s} {"%":>6s}')
 for r in rows[:45]:
   print(f'{short(r["Name"]):92s} {int(r["Calls"]):8d} {float(r["AverageNs"]) / 1e3:9.1f} {float(r["TotalDurationNs"]) / 1e6:10.2f} {float(r["Percentage"]):6.2f}')
@@ -55,7 +55,7 @@ print('\nper-launch HBM traffic (KB counters -> bytes; FETCH x2 per the gfx950 n
 print(f'{"kernel":92s} {"launches":>8s} {"fetch_MB":>9s} {"write_MB":>9s} {"mfma_busy/cu_busy(of 4)":>24s}')
 keys = sorted(fetch, key=lambda k: -fetch[k].get('FETCH_SIZE', 0))
 out = {}
-for k in keys[:30]:
+for k in keys[:40]:
   n = fc[(k, 'FETCH_SIZE')]
   f_mb = fetch[k]['FETCH_SIZE'] * 1024 * 2 / max(n, 1) / 1e6
   w_mb = write[k].get('WRITE_SIZE', 0.0) * 1024 / max(wc[(k, 'WRITE_SIZE')], 1) / 1e6
