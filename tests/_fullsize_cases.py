@@ -418,8 +418,12 @@ def benched_batch_vs_chunks(st, lib, cfg_name, B=128, chunk=8, tol=2e-5):
   labels, ksplit, slabs = plan_labels(model, B)
   out['labels'], out['ksplit'], out['wgrad_slabs'] = labels, ksplit, slabs
   if not SHRINK and lib.is_device and all(os.environ.get(k, '1') != '0' for k in ('STK_PLANES', 'STK_PLANES_WGRAD')):
-    for need in ('conv3x3.fwd.x2p', 'conv3x3.dgrad.x2p', 'conv3x3.fwd.x2p.k', 'conv3x3.dgrad.x2p.k',
-                 'conv3x3.wgrad.x2p.w32', 'conv3x3.wgrad.x2p.w16', 'conv3x3.wgrad.x2p.w8', 'conv3x3.wgrad.x2p.w4'):
+    # the large maps: the halo-tile GEMM per map width (round 3; STK_X2D_HALO=0: x2d::gemm_kernel for all of them)
+    halo = os.environ.get('STK_X2D_HALO', '1') != '0'
+    big = ('conv3x3.fwd.x2p.h32', 'conv3x3.dgrad.x2p.h32', 'conv3x3.fwd.x2p.h16', 'conv3x3.dgrad.x2p.h16') if halo \
+        else ('conv3x3.fwd.x2p', 'conv3x3.dgrad.x2p')
+    for need in big + ('conv3x3.fwd.x2p.k', 'conv3x3.dgrad.x2p.k',
+                       'conv3x3.wgrad.x2p.w32', 'conv3x3.wgrad.x2p.w16', 'conv3x3.wgrad.x2p.w8', 'conv3x3.wgrad.x2p.w4'):
       assert labels.get(need, 0) > 0, f'the batch-{B} plan never selected {need}: {labels}'
     assert ksplit > 1 and slabs > 1, (ksplit, slabs)
   return out
