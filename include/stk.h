@@ -58,6 +58,22 @@ int stk_upfirdn2d_acc_f32(const float* input, const float* kernel, float* out, f
                           int up_x, int up_y, int down_x, int down_y,
                           int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
+/* The other floating types the reference's pybind functions dispatch on (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * op/upfirdn2d_kernel.cu:311, op/fused_bias_act_kernel.cu:77): same arguments; `_f16` takes IEEE half tensors (fp32
+ * accumulation, one rounding), `_f64` double.  The taps / bias / ref have the tensor's type, as in the reference. */
+int stk_upfirdn2d_f16(const void* input, const void* kernel, void* out, int major, int in_h, int in_w, int minor,
+                      int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+int stk_upfirdn2d_f64(const double* input, const double* kernel, double* out, int major, int in_h, int in_w, int minor,
+                      int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+int stk_fused_bias_act_f16(const void* x, const void* b, const void* ref, void* out,
+                           long size_x, int step_b, int size_b, int act, int grad,
+                           float alpha, float scale, void* stream);
+int stk_fused_bias_act_f64(const double* x, const double* b, const double* ref, double* out,
+                           long size_x, int step_b, int size_b, int act, int grad,
+                           float alpha, float scale, void* stream);
+
 /* out[i] = act(x[i] + b[(i/step_b) % size_b]) * scale;  act*10+grad: 10/11 linear, 12 zero,
  * 30 lrelu, 31 lrelu-grad through `ref`, 32 zero (fused_bias_act_kernel.cu:36-47).
  * b == NULL: no bias; ref == NULL: reference value 0. */

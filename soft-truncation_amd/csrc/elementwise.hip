@@ -288,6 +288,38 @@ __global__ __launch_bounds__(256) void sm_loss_fwd_kernel(const float* __restric
 
 #define S(stream) ((hipStream_t)(stream))
 
+// other floating types of the native op (AT_DISPATCH_FLOATING_TYPES_AND_HALF, op/fused_bias_act_kernel.cu:77): grid-stride,
+// half computes in fp32 and rounds once
+template <class T, class ACC>
+__global__ __launch_bounds__(256) void bias_act_t_kernel(const T* __restrict__ x, const T* __restrict__ b, const T* __restrict__ ref,
+                                                         T* __restrict__ out, long n, int step_b, int size_b, int code, ACC alpha,
+                                                         ACC scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    ACC t = (ACC)x[i];
+    if (b) t += (ACC)b[(i / step_b) % size_b];
+    const ACC rr = ref ? (ACC)ref[i] : (ACC)0;
+    ACC y;
+    switch (code) {
+      default: case 10: case 11: y = t; break;
+      case 12: case 32: y = 0; break;
+      case 30: y = (t > 0) ? t : t * alpha; break;
+      case 31: y = (rr > 0) ? t : t * alpha; break;
+    }
+    out[i] = (T)(y * scale);
+  }
+}
+template <class T, class ACC>
+static int bias_act_t(const void* x, const void* b, const void* ref, void* out, long size_x, int step_b, int size_b, int act,
+                      int grad, float alpha, float scale, void* stream) {
+  if (!x || !out || size_x < 0 || (b && (step_b <= 0 || size_b <= 0))) return STK_EINVAL;
+  if (size_x == 0) return STK_OK;
+  hipLaunchKernelGGL((bias_act_t_kernel<T, ACC>), dim3((unsigned)stk_ew_grid(size_x)), dim3(256), 0, S(stream),
+                     static_cast<const T*>(x), static_cast<const T*>(b), static_cast<const T*>(ref), static_cast<T*>(out), size_x,
+                     b ? step_b : 1, b ? size_b : 1, act * 10 + grad, (ACC)alpha, (ACC)scale);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+
 extern "C" {
 
 int stk_silu_fwd_f32(const float* x, float* y, long n, void* stream) {
@@ -339,6 +371,15 @@ int stk_fused_bias_act_f32(const float* x, const float* b, const float* ref, flo
   const bool v = stk_aligned16(x) && stk_aligned16(out) && (!ref || stk_aligned16(ref));
   return launch_ew(size_x, v, BiasAct{x, b, ref, out, b ? step_b : 1, b ? size_b : 1, act * 10 + grad, alpha, scale},
                    S(stream));
+}
+
+int stk_fused_bias_act_f16(const void* x, const void* b, const void* ref, void* out, long size_x, int step_b, int size_b,
+                           int act, int grad, float alpha, float scale, void* stream) {
+  return bias_act_t<_Float16, float>(x, b, ref, out, size_x, step_b, size_b, act, grad, alpha, scale, stream);
+}
+int stk_fused_bias_act_f64(const double* x, const double* b, const double* ref, double* out, long size_x, int step_b, int size_b,
+                           int act, int grad, float alpha, float scale, void* stream) {
+  return bias_act_t<double, double>(x, b, ref, out, size_x, step_b, size_b, act, grad, alpha, scale, stream);
 }
 
 int stk_rowscale_f32(const float* x, const float* s, float* out, int N, long inner, int mode, void* stream) {

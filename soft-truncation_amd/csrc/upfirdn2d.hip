@@ -333,9 +333,74 @@ int launch(const float* input, const float* kernel, float* out, float beta, int 
   return STK_OK;
 }
 
+// ---- other floating types (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF, op/upfirdn2d_kernel.cu:311):
+// one thread per output element, any parameters; half accumulates in fp32 and rounds once, double in double.  Nothing
+// on the hot path feeds these -- they complete the drop-in surface of the native op.
+template <class T, class ACC>
+__global__ __launch_bounds__(256) void upfirdn2d_direct_t(const T* __restrict__ in, const T* __restrict__ k, T* __restrict__ out,
+                                                          UfdParams p) {
+  const long total = (long)p.major * p.out_h * p.out_w * p.minor;
+  const long stride = (long)gridDim.x * 256;
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+    long r = o;
+    const int mi = (int)(r % p.minor); r /= p.minor;
+    const int ox = (int)(r % p.out_w); r /= p.out_w;
+    const int oy = (int)(r % p.out_h);
+    const int mj = (int)(r / p.out_h);
+    ACC acc = 0;
+    for (int ky = 0; ky < p.kh; ++ky) {
+      const int uy = oy * p.down_y + ky - p.pad_y0;
+      if (uy < 0 || uy % p.up_y) continue;
+      const int iy = uy / p.up_y;
+      if (iy >= p.in_h) continue;
+      for (int kx = 0; kx < p.kw; ++kx) {
+        const int ux = ox * p.down_x + kx - p.pad_x0;
+        if (ux < 0 || ux % p.up_x) continue;
+        const int ix = ux / p.up_x;
+        if (ix >= p.in_w) continue;
+        acc += (ACC)in[((long)(mj * p.in_h + iy) * p.in_w + ix) * p.minor + mi] * (ACC)k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+      }
+    }
+    out[o] = (T)acc;
+  }
+}
+
+template <class T, class ACC>
+int launch_t(const void* input, const void* kernel, void* out, int major, int in_h, int in_w, int minor, int kh, int kw,
+             int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, hipStream_t stream) {
+  if (!input || !kernel || !out || major <= 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0 ||
+      up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
+    return STK_EINVAL;
+  UfdParams p = {};
+  p.major = major; p.in_h = in_h; p.in_w = in_w; p.minor = minor; p.kh = kh; p.kw = kw;
+  p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.pad_x0 = pad_x0; p.pad_y0 = pad_y0;
+  p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
+  p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+  if (p.out_h <= 0 || p.out_w <= 0) return STK_EINVAL;
+  const long total = (long)major * p.out_h * p.out_w * minor;
+  hipLaunchKernelGGL((upfirdn2d_direct_t<T, ACC>), dim3(stk_ew_grid(total)), dim3(256), 0, stream, static_cast<const T*>(input),
+                     static_cast<const T*>(kernel), static_cast<T*>(out), p);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int stk_upfirdn2d_f16(const void* input, const void* kernel, void* out, int major, int in_h, int in_w, int minor, int kh,
+                      int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                      void* stream) {
+  return launch_t<_Float16, float>(input, kernel, out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+                                   pad_y0, pad_y1, (hipStream_t)stream);
+}
+
+int stk_upfirdn2d_f64(const double* input, const double* kernel, double* out, int major, int in_h, int in_w, int minor, int kh,
+                      int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                      void* stream) {
+  return launch_t<double, double>(input, kernel, out, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+                                  pad_y0, pad_y1, (hipStream_t)stream);
+}
 
 int stk_upfirdn2d_f32(const float* input, const float* kernel, float* out, int major, int in_h, int in_w, int minor,
                       int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,

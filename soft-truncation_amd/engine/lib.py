@@ -29,6 +29,10 @@ SIGNATURES = {
   'stk_upfirdn2d_f32': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, S],
   'stk_upfirdn2d_acc_f32': [P, P, P, F, I, I, I, I, I, I, I, I, I, I, I, I, I, I, S],
   'stk_fused_bias_act_f32': [P, P, P, P, L, I, I, I, I, F, F, S],
+  'stk_fused_bias_act_f16': [P, P, P, P, L, I, I, I, I, F, F, S],
+  'stk_fused_bias_act_f64': [P, P, P, P, L, I, I, I, I, F, F, S],
+  'stk_upfirdn2d_f16': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, S],
+  'stk_upfirdn2d_f64': [P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, S],
   'stk_gn_fwd_f32': [P, I, P, I, P, P, P, P, P, I, I, I, F, I, F, U64, P, P, S],
   'stk_gn_ws_bytes': [I, I, I, I],
   'stk_gn_bwd_f32': [P, P, I, P, I, P, P, P, P, P, F, P, F, P, P, P, I, I, I, I, F, U64, P, S],

@@ -21,20 +21,24 @@ from ..engine import lib as stk_lib
 from . import _backend
 
 _LRELU = 3     # `act` code of the kernel (fused_bias_act_kernel.cu:36-47)
+# the reference's pybind function dispatches on every floating type and half (op/fused_bias_act_kernel.cu:77)
+_ENTRY = {torch.float32: 'fused_bias_act_f32', torch.float16: 'fused_bias_act_f16', torch.float64: 'fused_bias_act_f64'}
 
 
 def _launch(x, bias, y_ref, through_ref, slope, scale):
   lib = _backend.get()
   _backend.check(x, lib)
+  if x.dtype not in _ENTRY:
+    raise TypeError(f'fused_leaky_relu: {x.dtype} tensors are not supported (float32, float16, float64 are)')
   x = x.contiguous()
   out = torch.empty_like(x)
   inner = 1
   for d in x.shape[2:]:
     inner *= d
-  b = bias.contiguous() if bias is not None else None
-  r = y_ref.contiguous() if y_ref is not None else None
+  b = bias.to(x.dtype).contiguous() if bias is not None else None
+  r = y_ref.to(x.dtype).contiguous() if y_ref is not None else None
   with stk_lib.device_guard(x.device):
-    lib.fused_bias_act_f32(x.data_ptr(), b.data_ptr() if b is not None else None,
+    getattr(lib, _ENTRY[x.dtype])(x.data_ptr(), b.data_ptr() if b is not None else None,
                            r.data_ptr() if r is not None else None, out.data_ptr(), x.numel(), inner,
                            b.numel() if b is not None else 1, _LRELU, 1 if through_ref else 0,
                            float(slope), float(scale), stk_lib.stream_ptr(x.device))

@@ -8,8 +8,8 @@ transpose; one autograd function applies a `FirMap`, and its backward applies th
 same function.  Differentiating any number of times therefore needs no further code (the reference spells out a second
 Function for the double backward, :62-85; here `transpose(transpose(m))` is `m` again, up to padding no output reads).
 
-The work is done by ``stk_upfirdn2d_f32`` (hand-written HIP for gfx950, csrc/upfirdn2d.hip) on torch's current HIP
-stream.  The reference JIT-builds a CUDA extension at import and silently runs a PyTorch implementation for CPU
+The work is done by ``stk_upfirdn2d_f32`` (hand-written HIP for gfx950, csrc/upfirdn2d.hip; ``_f16`` / ``_f64`` for half
+and double tensors, the other types the reference's extension dispatches on) on torch's current HIP stream.  The reference JIT-builds a CUDA extension at import and silently runs a PyTorch implementation for CPU
 tensors (:145-156); here a tensor that does not live on the GPU is an error, never a fallback.
 """
 import collections
@@ -41,13 +41,19 @@ class FirMap(collections.namedtuple('FirMap', 'up down pad in_hw out_hw')):
     return FirMap(self.down, self.up, pad_t, self.out_hw, self.in_hw)
 
 
+# the reference's pybind function dispatches on every floating type and half (op/upfirdn2d_kernel.cu:311)
+_ENTRY = {torch.float32: 'upfirdn2d_f32', torch.float16: 'upfirdn2d_f16', torch.float64: 'upfirdn2d_f64'}
+
+
 def _run(planes, taps, m):
-  """planes [P, h, w] contiguous float32 on the device -> [P, oh, ow]."""
+  """planes [P, h, w] contiguous (float32 / float16 / float64) on the device -> [P, oh, ow]; taps of the same type."""
   lib = _backend.get()
   _backend.check(planes, lib)
+  if planes.dtype not in _ENTRY:
+    raise TypeError(f'upfirdn2d: {planes.dtype} tensors are not supported (float32, float16, float64 are)')
   out = torch.empty((planes.shape[0],) + m.out_hw, dtype=planes.dtype, device=planes.device)
   with stk_lib.device_guard(planes.device):
-    lib.upfirdn2d_f32(planes.data_ptr(), taps.data_ptr(), out.data_ptr(), planes.shape[0], m.in_hw[0], m.in_hw[1], 1,
+    getattr(lib, _ENTRY[planes.dtype])(planes.data_ptr(), taps.data_ptr(), out.data_ptr(), planes.shape[0], m.in_hw[0], m.in_hw[1], 1,
                       taps.shape[0], taps.shape[1], m.up[0], m.up[1], m.down[0], m.down[1],
                       m.pad[0], m.pad[1], m.pad[2], m.pad[3], stk_lib.stream_ptr(planes.device))
   return out
@@ -75,6 +81,6 @@ class _ApplyFir(torch.autograd.Function):
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
   """[B, C, H, W] -> [B, C, H', W']: zero-insert by `up`, pad by `pad = (before, after)` on both axes (negative =
   crop), correlate with the flipped `kernel`, keep every `down`-th sample (reference op/upfirdn2d.py:159-200)."""
-  taps = kernel.detach().to(device=input.device, dtype=torch.float32).contiguous()
+  taps = kernel.detach().to(device=input.device, dtype=input.dtype).contiguous()
   m = FirMap.of(tuple(input.shape[-2:]), tuple(taps.shape), (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
   return _ApplyFir.apply(input, taps, m)

@@ -132,3 +132,38 @@ def fused_leaky_relu_autograd(st, dev):
   out.sum().backward()
   mask = (_flr_ref(xs, m.bias.detach().cpu(), 0.2, 1.0) > 0).float()
   _close(m.bias.grad, ((mask + (1 - mask) * 0.2) * 2 ** 0.5).sum((0, 2, 3)))
+
+
+def other_dtypes(st, dev):
+  """The half and double entry points of the two native ops (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+  op/upfirdn2d_kernel.cu:311, op/fused_bias_act_kernel.cu:77): forward and input gradient against the reference's own
+  outputs (tests/golden/ops.npz, fp32) and the oracle restatement in double."""
+  g = np.load(GOLDEN)
+  x = torch.from_numpy(g['x'])
+  for dtype, tol in ((torch.float64, 1e-6), (torch.float16, 4e-3)):
+    for name in ('down', 'up', 'pre', 'crop', 'odd'):
+      up, down, p0, p1 = (int(v) for v in g[f'{name}.args'])
+      xd = x.clone().to(dev, dtype).requires_grad_(True)
+      y = st.op.upfirdn2d(xd, torch.from_numpy(g[f'{name}.k']).to(dev), up=up, down=down, pad=(p0, p1))
+      assert y.dtype == dtype
+      _close(y, torch.from_numpy(g[f'{name}.y']), tol)
+      y.backward(torch.from_numpy(g[f'{name}.go']).to(dev, dtype))
+      assert xd.grad.dtype == dtype
+      _close(xd.grad, torch.from_numpy(g[f'{name}.gx']), tol)
+    b = torch.from_numpy(g['flr.bias'])
+    xd = x.clone().to(dev, dtype).requires_grad_(True)
+    bd = b.clone().to(dev, dtype).requires_grad_(True)
+    y = st.op.fused_leaky_relu(xd, bd, 0.2, 2 ** 0.5)
+    assert y.dtype == dtype
+    _close(y, torch.from_numpy(g['flr.y']), tol)
+    xr, br = x.clone().double().requires_grad_(True), b.clone().double().requires_grad_(True)
+    go = torch.randn(x.shape, generator=torch.Generator().manual_seed(2))
+    y.backward(go.to(dev, dtype))
+    _flr_ref(xr, br, 0.2, 2 ** 0.5).backward(go.double())
+    _close(xd.grad, xr.grad, tol)
+    _close(bd.grad, br.grad, 4 * tol)
+  # double precision really is double: a value fp32 cannot hold survives the pass-through FIR
+  one = torch.tensor([[1.0]], dtype=torch.float64)
+  v = torch.full((1, 1, 4, 4), 1.0 + 2.0 ** -40, dtype=torch.float64)
+  out = st.op.upfirdn2d(v.to(dev), one.to(dev))
+  assert torch.equal(out.cpu(), v)

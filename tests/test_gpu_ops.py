@@ -34,3 +34,7 @@ def test_resampling_wrappers(st, dev):
 
 def test_fused_leaky_relu_grad_and_gradgrad(st, dev):
   cases.fused_leaky_relu_autograd(st, dev)
+
+
+def test_half_and_double_entry_points(st, dev):
+  cases.other_dtypes(st, dev)
