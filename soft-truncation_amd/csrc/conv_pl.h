@@ -41,14 +41,6 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   __shared__ float t[32 * 129];
   __shared__ float red[4];
   const int tid = threadIdx.x;
-  // scale from the amax record (every workgroup reduces it itself: no finishing launch)
-  float m = 0.f;
-  for (int i = tid; i < namax; i += 256) m = fmaxf(m, amax[i]);
-  m = wave_max(m);
-  if ((tid & 63) == 0) red[tid >> 6] = m;
-  __syncthreads();
-  const float s = x2::pow2_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-
   const int tiles = (HW + SP_PIX - 1) / SP_PIX;
   const int Cb = (C + 31) >> 5;
   const int tile = blockIdx.x % tiles, rest = blockIdx.x / tiles;
@@ -74,7 +66,14 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     float* d = t + c * 129 + 4 * q4;
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
+  // scale from the amax record (every workgroup reduces it itself: no finishing launch); taken AFTER the tile loads were
+  // issued so that the record's latency hides under them
+  float m = 0.f;
+  for (int i = tid; i < namax; i += 256) m = fmaxf(m, amax[i]);
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
   __syncthreads();
+  const float s = x2::pow2_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int id = tid + 256 * r;
