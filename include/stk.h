@@ -421,6 +421,10 @@ int stk_sumsq_f32(const float* x, long n, float* out, float* ws, void* stream);
 int stk_adam_f32(float* p, float* g, float* m, float* v, long n,
                  float lr, float b1, float b2, float eps, float weight_decay, int adamw,
                  float bc1, float bc2, const float* sumsq, float max_norm, void* stream);
+/* stk_adam_f32 with AMSGrad (torch.optim.Adam(amsgrad=True), losses.py:33): vmax = max(vmax, v), the denominator uses vmax */
+int stk_adam_amsgrad_f32(float* p, float* g, float* m, float* v, float* vmax, long n,
+                         float lr, float b1, float b2, float eps, float weight_decay, int adamw,
+                         float bc1, float bc2, const float* sumsq, float max_norm, void* stream);
 int stk_ema_f32(float* shadow, const float* p, long n, float one_minus_decay, void* stream);
 
 /* Sample post-processing, replaces `np.clip(samples.permute(0,2,3,1).cpu().numpy() * 255., 0, 255).astype(np.uint8)`

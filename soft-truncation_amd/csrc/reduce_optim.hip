@@ -284,6 +284,29 @@ __global__ __launch_bounds__(256) void adam_kernel_scalar(float* __restrict__ p,
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], a, coef);
 }
 
+// AMSGrad (optim.amsgrad, losses.py:33: torch.optim.Adam(amsgrad=True)): the denominator uses the running maximum of v
+__global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, float* __restrict__ vmax, long n, AdamArgs a,
+                                                           const float* __restrict__ sumsq) {
+  float coef = 1.f;
+  if (sumsq && a.max_norm >= 0.f) coef = fminf(a.max_norm / (sqrtf(sumsq[0]) + 1e-6f), 1.f);
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float gi = g[i] * coef;
+    g[i] = gi;
+    float pi = p[i];
+    if (a.wd != 0.f) {
+      if (a.adamw) pi = pi * (1.f - a.lr * a.wd);
+      else gi = gi + a.wd * pi;
+    }
+    const float mi = m[i] + (gi - m[i]) * (1.f - a.b1);
+    const float vi = v[i] * a.b2 + (1.f - a.b2) * gi * gi;
+    const float vm = fmaxf(vmax[i], vi);
+    p[i] = pi - a.step_size * (mi / (sqrtf(vm) / a.bc2_sqrt + a.eps));
+    m[i] = mi; v[i] = vi; vmax[i] = vm;
+  }
+}
+
 // ---- EMA (models/ema.py:50-51) -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ s, const float* __restrict__ p, long n, float omd,
                                                   int vec) {
@@ -422,6 +445,21 @@ int stk_adam_f32(float* p, float* g, float* m, float* v, long n, float lr, float
                        sumsq);
   else
     hipLaunchKernelGGL(adam_kernel_scalar, dim3(stk_ew_grid(n)), dim3(256), 0, S(stream), p, g, m, v, n, a, sumsq);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+
+int stk_adam_amsgrad_f32(float* p, float* g, float* m, float* v, float* vmax, long n, float lr, float b1, float b2, float eps,
+                         float weight_decay, int adamw, float bc1, float bc2, const float* sumsq, float max_norm,
+                         void* stream) {
+  if (!p || !g || !m || !v || !vmax || n < 0 || bc1 == 0.f || bc2 <= 0.f) return STK_EINVAL;
+  if (n == 0) return STK_OK;
+  AdamArgs a;
+  a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = weight_decay; a.adamw = adamw;
+  a.step_size = lr / bc1;
+  a.bc2_sqrt = sqrtf(bc2);
+  a.max_norm = max_norm;
+  hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(stk_ew_grid(n)), dim3(256), 0, S(stream), p, g, m, v, vmax, n, a, sumsq);
   STK_CHECK_LAUNCH();
   return STK_OK;
 }

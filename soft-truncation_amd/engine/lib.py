@@ -95,6 +95,7 @@ SIGNATURES = {
   'stk_sm_loss_bwd_f32': [P, P, P, P, P, P, I, L, I, I, I, S],
   'stk_sumsq_f32': [P, L, P, P, S],
   'stk_adam_f32': [P, P, P, P, L, F, F, F, F, F, I, F, F, P, F, S],
+  'stk_adam_amsgrad_f32': [P, P, P, P, P, L, F, F, F, F, F, I, F, F, P, F, S],
   'stk_ema_f32': [P, P, L, F, S],
   'stk_dropout_mask_f32': [P, L, F, U64, S],
   'stk_samples_to_uint8': [P, P, I, I, L, S],

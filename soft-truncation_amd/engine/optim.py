@@ -20,8 +20,6 @@ from .flat import flat_of
 class FusedAdam(torch.optim.Optimizer):
   def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0., amsgrad=False,
                adamw=False, backend=None):
-    if amsgrad:
-      raise NotImplementedError('amsgrad is False in every shipped config (optim.amsgrad)')
     defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
     super().__init__(params, defaults)
     if len(self.param_groups) != 1:
@@ -29,7 +27,7 @@ class FusedAdam(torch.optim.Optimizer):
     self.adamw = bool(adamw)
     self._backend = backend
     self._flat = None
-    self._m = self._v = None
+    self._m = self._v = self._vmax = None
     self._step = 0
     self._sumsq = None
     self._ws = None
@@ -57,6 +55,11 @@ class FusedAdam(torch.optim.Optimizer):
         m.copy_(self._m)
         v.copy_(self._v)
       self._m, self._v = m, v
+      if self.param_groups[0]['amsgrad']:
+        vmax = torch.zeros(flat.n_train, dtype=torch.float32, device=dev)
+        if old is not None and self._vmax is not None and old.n_train == flat.n_train:
+          vmax.copy_(self._vmax)
+        self._vmax = vmax
       self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
       self._ws = torch.zeros(2048, dtype=torch.float32, device=dev)
       self._publish_state()
@@ -67,8 +70,11 @@ class FusedAdam(torch.optim.Optimizer):
     flat = self._flat
     mv = flat.trainable_views(self._m)
     vv = flat.trainable_views(self._v)
-    for p, m, v in zip(flat.trainable_params(), mv, vv):
+    mx = flat.trainable_views(self._vmax) if self._vmax is not None else [None] * len(mv)
+    for p, m, v, x in zip(flat.trainable_params(), mv, vv, mx):
       self.state[p] = {'step': torch.tensor(float(self._step)), 'exp_avg': m, 'exp_avg_sq': v}
+      if x is not None:
+        self.state[p]['max_exp_avg_sq'] = x              # torch.optim.Adam's key for amsgrad
 
   # -- the torch.optim API --------------------------------------------------------------------
   def zero_grad(self, set_to_none=False):
@@ -107,12 +113,15 @@ class FusedAdam(torch.optim.Optimizer):
     bc2 = 1.0 - b2 ** self._step
     clip = self._pending_clip
     self._pending_clip = None
+    tail = (flat.n_train, float(group['lr']), b1, b2, group['eps'], group['weight_decay'], int(self.adamw), bc1, bc2,
+            self._sumsq.data_ptr() if clip is not None else None, clip if clip is not None else -1.0,
+            stk_lib.stream_ptr(flat.device))
     with stk_lib.device_guard(flat.device):
-      self._lib().adam_f32(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
-                           flat.n_train, float(group['lr']), b1, b2, group['eps'], group['weight_decay'],
-                           int(self.adamw), bc1, bc2,
-                           self._sumsq.data_ptr() if clip is not None else None,
-                           clip if clip is not None else -1.0, stk_lib.stream_ptr(flat.device))
+      if self._vmax is not None:
+        self._lib().adam_amsgrad_f32(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
+                                     self._vmax.data_ptr(), *tail)
+      else:
+        self._lib().adam_f32(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), *tail)
 
   def state_dict(self):
     if self._flat is not None:
@@ -134,6 +143,11 @@ class FusedAdam(torch.optim.Optimizer):
           m.copy_(st['exp_avg'])
           v.copy_(st['exp_avg_sq'])
           step = max(step, int(float(st['step'])))
+      if self._vmax is not None:
+        for p, x in zip(flat.trainable_params(), flat.trainable_views(self._vmax)):
+          st = loaded.get(p)
+          if st and 'max_exp_avg_sq' in st:
+            x.copy_(st['max_exp_avg_sq'])
     self._step = step
     self.state.clear()
     self._publish_state()

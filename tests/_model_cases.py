@@ -59,8 +59,9 @@ def score_fn_parity(st, lib, family):
   assert rel_err(s, sr) <= TOL
 
 
-def train_steps(st, lib, family, steps=3, num_micro_batch=1, mixed=False, B=4):
+def train_steps(st, lib, family, steps=3, num_micro_batch=1, mixed=False, B=4, amsgrad=False):
   base = tiny_config(st, family)
+  base.optim.amsgrad = bool(amsgrad)          # torch.optim.Adam(amsgrad=True) on the oracle side, stk_adam_amsgrad_f32 here
   base.optim.num_micro_batch = num_micro_batch
   base.optim.warmup = 2
   base.training.mixed = mixed

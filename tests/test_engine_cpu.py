@@ -352,3 +352,20 @@ def test_fused_loss_path_on_the_checker(st, ref_lib):
   import _model_cases as cases
   for family in ('vp', 've'):
     cases.fused_loss_matches_torch(st, ref_lib, family)
+
+
+def test_train_steps_amsgrad_on_the_checker(st, ref_lib):
+  """optim.amsgrad=True (losses.py:33): FusedAdam keeps the running maximum of the second moment like torch's Adam, and
+  publishes it under torch's state key."""
+  import _model_cases as cases
+  cases.train_steps(st, ref_lib, 'vp', steps=4, amsgrad=True)
+  from _model_util import build_pair, make_state, tiny_config
+  cfg = tiny_config(st, 'vp')
+  cfg.optim.amsgrad = True
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, cfg, ref_lib)
+  opt = st.losses.get_optimizer(cfg, model.parameters())
+  opt._backend = ref_lib
+  opt.zero_grad()
+  opt.step()
+  sd = opt.state_dict()
+  assert all('max_exp_avg_sq' in v for v in sd['state'].values())

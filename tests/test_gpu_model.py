@@ -26,6 +26,10 @@ def test_train_steps(st, hip_lib, family):
   cases.train_steps(st, hip_lib, family)
 
 
+def test_train_steps_amsgrad(st, hip_lib):
+  cases.train_steps(st, hip_lib, 'vp', steps=4, amsgrad=True)
+
+
 def test_train_steps_micro_batches(st, hip_lib):
   cases.train_steps(st, hip_lib, 'vp', steps=2, num_micro_batch=2)
 
