@@ -418,11 +418,38 @@ def golden_sampler_registry_product(st, lib):
   return golden_sampler_registry(st, make, TOL)
 
 
-def two_streams_deterministic(st, lib, B=96, delays=(150000, 600000, 2000000)):
+class _MfmaNeighbour:
+  """A kernel of ANOTHER stream that issues MFMAs into accumulation registers beside whatever runs meanwhile: the library's
+  own fp32-operand weight gradient of a 192 -> 192 3x3 layer at 8x8 (x2::wgrad3_kernel), launched `calls` times on a
+  stream of its own.  This is the neighbour that made a packed-fp32 instruction of the GroupNorm backward return a wrong
+  16-lane slice in round 3 (DESIGN.md "The hazard"; tools/_probe/cores.hip reproduces it with exactly this call)."""
+
+  def __init__(self, lib, dev, N=96, C=192, H=8):
+    g = torch.Generator().manual_seed(11)
+    self.lib, self.N, self.C, self.H = lib, N, C, H
+    self.x = torch.randn(N, C, H, H, generator=g).to(dev)
+    self.dy = (0.01 * torch.randn(N, C, H, H, generator=g)).to(dev)
+    self.dw = torch.zeros(C, C, 3, 3, device=dev)
+    self.ws_bytes = int(lib.conv2d_wgrad_ws_bytes(C, 0, N, C, H, H, 3, 3))
+    self.ws = torch.empty(self.ws_bytes // 4 + 64, device=dev)
+    self.stream = torch.cuda.Stream(dev)
+
+  def launch(self, calls=40):
+    s = self.stream
+    for _ in range(calls):
+      self.lib.conv2d_wgrad_f32(self.x.data_ptr(), self.C, None, 0, self.dy.data_ptr(), self.dw.data_ptr(), 0, 1.0,
+                                self.ws.data_ptr(), self.ws_bytes, self.N, self.H, self.H, self.C, self.H, self.H, 3, 3, 1, 1,
+                                s.cuda_stream)
+
+
+def two_streams_deterministic(st, lib, B=96, delays=(150000, 600000, 2000000), neighbour_runs=300):
   """The backward with its weight gradients / shortcut convolutions on the side stream (engine/executor.SideStream) must
-  give the gradients of the one-stream backward BIT FOR BIT, whatever the relative timing of the two streams: every side
-  launch site in turn is held back by a spin kernel (torch.cuda._sleep) of three lengths.  This is the watch on the
-  packed-fp32 hazard of csrc/Makefile (profiles/r03_side_stream_race.txt: 3-97 of 112 such runs diverged before)."""
+  give the gradients of a quiet one-stream backward BIT FOR BIT, whatever else is resident on the chip:
+    * every side launch site in turn held back by a spin kernel (torch.cuda._sleep) of three lengths, with and without
+    * a neighbour stream that issues MFMAs into accumulation registers throughout the backward (_MfmaNeighbour), which
+      also runs beside the plain two-stream and the ONE-stream backward `neighbour_runs` times each.
+  Watch on the packed-fp32 hazard (csrc/Makefile HAZARD_FLAGS, profiles/r04_pk_hazard.txt): a build with the SLP vectoriser
+  on fails every one of these runs (tools/_probe/side_race2.py: 168 of 168)."""
   from importlib import import_module
   G = import_module('soft-truncation_amd.engine.graph')
   cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, 'wide'), lib)
@@ -433,31 +460,47 @@ def two_streams_deterministic(st, lib, B=96, delays=(150000, 600000, 2000000)):
   x, t, cond = _inputs(cfg, sde, B)
   go = torch.randn(B, *x.shape[1:], generator=torch.Generator().manual_seed(5)).to(dev)
   model.eval()
+  nb = _MfmaNeighbour(lib, dev)
 
-  def run(side):
+  def run(side, neighbour=False):
     ex.use_side = side
     model.zero_grad()
     xg = x.clone().to(dev).requires_grad_(True)
-    (model(xg, cond.to(dev)) * go).sum().backward()
+    y = model(xg, cond.to(dev))
+    if neighbour:
+      nb.launch()
+    (y * go).sum().backward()
+    busy = neighbour and not nb.stream.query()          # still running when the backward had been queued
     torch.cuda.synchronize()
-    return [p.grad.detach().clone() for p in model.parameters()] + [xg.grad.clone()]
+    return [p.grad.detach().clone() for p in model.parameters()] + [xg.grad.clone()], busy
 
   saved = (G._SIDE_DELAY, G._SIDE_DELAY_FILTER)
   try:
-    base = run(False)
+    base, _ = run(False)
     sites = []
     G._SIDE_DELAY, G._SIDE_DELAY_FILTER = 1, (lambda n: (sites.append(n), False)[1])
     run(True)
     sites = list(dict.fromkeys(sites))
     assert len(sites) >= 10, sites
-    runs = bad = 0
-    for delay in delays:
-      for site in sites:
-        G._SIDE_DELAY, G._SIDE_DELAY_FILTER = delay, (lambda n, site=site: n == site)
-        got = run(True)
-        runs += 1
-        bad += any(not torch.equal(a, b) for a, b in zip(got, base))
-    assert bad == 0, f'{bad} of {runs} two-stream backward passes differ from the one-stream result'
+    runs = bad = beside = 0
+
+    def check(got):
+      nonlocal runs, bad, beside
+      runs += 1
+      beside += bool(got[1])
+      bad += any(not torch.equal(a, b) for a, b in zip(got[0], base))
+
+    for neighbour in (False, True):
+      for delay in delays:
+        for site in sites:
+          G._SIDE_DELAY, G._SIDE_DELAY_FILTER = delay, (lambda n, site=site: n == site)
+          check(run(True, neighbour))
+    G._SIDE_DELAY, G._SIDE_DELAY_FILTER = 0, None
+    for side in (True, False):
+      for _ in range(neighbour_runs):
+        check(run(side, True))
+    assert bad == 0, f'{bad} of {runs} backward passes differ from the quiet one-stream result'
+    assert beside >= neighbour_runs, f'the neighbour kernels ended too early to be resident beside the backward ({beside} of {runs})'
   finally:
     G._SIDE_DELAY, G._SIDE_DELAY_FILTER = saved
     ex.use_side = True

@@ -37,7 +37,10 @@ def hip_lib(st):
   """The product library.  On a GPU box a missing library is a failure, never a skip."""
   import torch
   if os.environ.get('STK_SELFCHECK'):
-    # harness self-check on a CPU-only machine: compare the checker with itself to debug the TEST code
+    # harness self-check on a CPU-only machine: compare the checker with itself to debug the TEST code.  On a GPU box it
+    # would turn every parity test into the oracle against itself, so there it is an error.
+    if torch.cuda.is_available():
+      raise RuntimeError('STK_SELFCHECK is a CPU-only harness check: unset it on a machine with a GPU')
     return st.engine.lib.load_path(os.path.join(ROOT, 'oracle', 'libstk_ref.so'))
   if not torch.cuda.is_available():
     pytest.skip('no GPU in this container')
