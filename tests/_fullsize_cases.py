@@ -269,6 +269,12 @@ def full_forward_backward(st, lib, cfg_name, B, param_grads=True, shrink_kw=None
 # ---------------------------------------------------------------------------------------------------------------------
 # round 3: the BENCHED program (per-GPU batch 128) against sixteen batch-8 runs + the oracle on chunk 0
 # ---------------------------------------------------------------------------------------------------------------------
+def _per_image(a, b):
+  """Worst image: max |a - b| over the image relative to that image's max |b|."""
+  a, b = a.detach().cpu().double().flatten(1), b.detach().cpu().double().flatten(1)
+  return ((a - b).abs().max(1).values / b.abs().max(1).values.clamp_min(1e-300)).max().item()
+
+
 class _SlicedDraws:
   """torch.rand / torch.randn_like served from ONE pre-drawn full-batch noise set, a window of rows at a time: the
   batch-128 run and its sixteen batch-8 chunks (and the oracle on chunk 0) then see identical t and z per sample."""
@@ -321,6 +327,18 @@ def plan_labels(model, B):
         per_slab = 4 * op.KH * op.KW * op.Cout * op.C1
         slabs = max(slabs, int(lib.conv2d_wgrad_pl_ws_bytes(op.N, op.H, op.W, op.C1, op.Cout)) // per_slab)
   return labels, ksplit, slabs
+
+
+# what the benched plan of each BASELINE config must contain (bench.py's kernel labels): halo-tile widths, and the rest
+_SMALL = ('conv3x3.fwd.x2p.k', 'conv3x3.dgrad.x2p.k')
+BENCHED_PLAN = {
+  'cifar10_ddpmpp_nll_st': dict(halo=(32, 16), other=_SMALL + tuple(f'conv3x3.wgrad.x2p.w{w}' for w in (32, 16, 8, 4))),
+  'imagenet32_ddpmpp_st': dict(halo=(32, 16), other=_SMALL + tuple(f'conv3x3.wgrad.x2p.w{w}' for w in (32, 16, 8, 4))),
+  # configs[2]: 64 / 32 / 16 / 8-wide maps at batch 128
+  'celeba_uncsnpp_st': dict(halo=(64, 32, 16), other=_SMALL + tuple(f'conv3x3.wgrad.x2p.w{w}' for w in (32, 16, 8))),
+  # configs[4]: 256 ... 4-wide maps at batch 4: the 128 / 256-wide layers stay on x2d::gemm_kernel (no halo tile that wide)
+  'celebahq_uncsnpp_st': dict(halo=(64, 32), other=_SMALL + ('conv3x3.fwd.x2p', 'conv3x3.dgrad.x2p', 'conv3x3.wgrad.x2p.w32')),
+}
 
 
 def benched_batch_vs_chunks(st, lib, cfg_name, B=128, chunk=8, tol=2e-5):
@@ -378,6 +396,7 @@ def benched_batch_vs_chunks(st, lib, cfg_name, B=128, chunk=8, tol=2e-5):
   gl_sum = torch.zeros_like(GL)
   gs_sum = torch.zeros_like(GS)
   worst = dict(loss=0.0, score=0.0, input_grad=0.0)
+  per_image = dict(score=0.0, input_grad=0.0)      # each image against ITS OWN maximum (the per-sample loss weights spread them)
   for lo in range(0, B, chunk):
     l, s, gx, gl, gs = run(lo, lo + chunk)
     gl_sum += gl
@@ -385,9 +404,14 @@ def benched_batch_vs_chunks(st, lib, cfg_name, B=128, chunk=8, tol=2e-5):
     worst['loss'] = max(worst['loss'], ((L[lo:lo + chunk] - l).abs() / l.abs().clamp_min(1e-6)).max().item())
     worst['score'] = max(worst['score'], rel_err(S[lo:lo + chunk], s))
     worst['input_grad'] = max(worst['input_grad'], rel_err(GX[lo:lo + chunk], gx))
+    per_image['score'] = max(per_image['score'], _per_image(S[lo:lo + chunk], s))
+    per_image['input_grad'] = max(per_image['input_grad'], _per_image(GX[lo:lo + chunk], gx))
     if lo == 0:
       chunk0 = (l, s, gx)
   out.update({'b128_vs_chunks_' + k: v for k, v in worst.items()})
+  out.update({'b128_vs_chunks_per_image_' + k: v for k, v in per_image.items()})
+  for k, v in per_image.items():
+    assert v <= 10 * tol, f'{cfg_name}: batch-{B} {k}: worst single image differs from its batch-{chunk} run by {v:.3e} of its own maximum'
   for k, v in worst.items():
     assert v <= tol, f'{cfg_name}: batch-{B} {k} differs from the batch-{chunk} runs by {v:.3e}'
   # parameter gradients: relative to the largest entry of each parameter's gradient (floored at 1e-3 of the model's)
@@ -412,6 +436,9 @@ def benched_batch_vs_chunks(st, lib, cfg_name, B=128, chunk=8, tol=2e-5):
   out['chunk0_score'] = rel_err(chunk0[1], sr)
   out['chunk0_input_grad'] = rel_err(chunk0[2], xr.grad)
   out['b128_chunk0_loss'] = rel_err(L[:chunk], rl)
+  out['b128_chunk0_score_per_image'] = _per_image(S[:chunk], sr.detach())
+  out['b128_chunk0_input_grad_per_image'] = _per_image(GX[:chunk], xr.grad)
+  assert out['b128_chunk0_score_per_image'] <= TOL and out['b128_chunk0_input_grad_per_image'] <= TOL, out
   out['b128_chunk0_score'] = rel_err(S[:chunk], sr)
   for k in ('chunk0_loss', 'chunk0_score', 'chunk0_input_grad', 'b128_chunk0_loss', 'b128_chunk0_score'):
     assert out[k] <= TOL, f'{cfg_name}: {k} {out[k]:.3e} against the oracle'
@@ -420,10 +447,9 @@ def benched_batch_vs_chunks(st, lib, cfg_name, B=128, chunk=8, tol=2e-5):
   if not SHRINK and lib.is_device and all(os.environ.get(k, '1') != '0' for k in ('STK_PLANES', 'STK_PLANES_WGRAD')):
     # the large maps: the halo-tile GEMM per map width (round 3; STK_X2D_HALO=0: x2d::gemm_kernel for all of them)
     halo = os.environ.get('STK_X2D_HALO', '1') != '0'
-    big = ('conv3x3.fwd.x2p.h32', 'conv3x3.dgrad.x2p.h32', 'conv3x3.fwd.x2p.h16', 'conv3x3.dgrad.x2p.h16') if halo \
-        else ('conv3x3.fwd.x2p', 'conv3x3.dgrad.x2p')
-    for need in big + ('conv3x3.fwd.x2p.k', 'conv3x3.dgrad.x2p.k',
-                       'conv3x3.wgrad.x2p.w32', 'conv3x3.wgrad.x2p.w16', 'conv3x3.wgrad.x2p.w8', 'conv3x3.wgrad.x2p.w4'):
+    widths = BENCHED_PLAN[cfg_name]['halo']
+    big = tuple(f'conv3x3.{d}.x2p.h{w}' for w in widths for d in ('fwd', 'dgrad')) if halo else ('conv3x3.fwd.x2p', 'conv3x3.dgrad.x2p')
+    for need in big + BENCHED_PLAN[cfg_name]['other']:
       assert labels.get(need, 0) > 0, f'the batch-{B} plan never selected {need}: {labels}'
     assert ksplit > 1 and slabs > 1, (ksplit, slabs)
   return out

@@ -23,6 +23,12 @@ def test_train_steps(st, ref_lib, family):
   cases.train_steps(st, ref_lib, family)
 
 
+def test_loss_curve_on_the_checker(st, ref_lib):
+  """The 100-step trajectory test of the GPU suite (tests/test_gpu_model.py::test_loss_curve_100_steps), 40 steps on the checker."""
+  out = cases.loss_curve(st, ref_lib, 'vp', steps=40)
+  print(out)
+
+
 def test_train_steps_micro_batches(st, ref_lib):
   cases.train_steps(st, ref_lib, 'vp', steps=2, num_micro_batch=2)
 

@@ -43,6 +43,16 @@ def test_benched_batch_128_equals_sixteen_batch_8_runs(st, hip_lib, cfg_name):
   print(cfg_name, 'batch-128 parity:', {k: (f'{v:.2e}' if isinstance(v, float) else v) for k, v in out.items()})
 
 
+@pytest.mark.timeout(3000)
+@pytest.mark.parametrize('cfg_name,B,chunk', [('celeba_uncsnpp_st', 128, 8), ('celebahq_uncsnpp_st', 4, 1)])
+def test_benched_batch_of_the_other_baseline_nets(st, hip_lib, cfg_name, B, chunk):
+  """BASELINE configs[2] (UNCSN++ 64x64, per-GPU batch 128) and configs[4] (NCSN++ 256x256, per-GPU batch 4) at the batch
+  bench.py / the scaling run use: tiles, K splits, halo widths and slab counts depend on the batch, so the benched plan is
+  compared sample for sample with chunked runs (chunk 0 against the oracle), as for the 32x32 nets above."""
+  out = full.benched_batch_vs_chunks(st, hip_lib, cfg_name, B=B, chunk=chunk)
+  print(cfg_name, f'batch-{B} parity:', {k: (f'{v:.2e}' if isinstance(v, float) else v) for k, v in out.items()})
+
+
 def test_full_uncsnpp_celeba64_train_step(st, hip_lib):
   """BASELINE configs[2] net: two full `step_fn` calls at batch 2 (RVE loss, sum reduction, FIR resampling, Adam, EMA)."""
   out = full.full_train_step(st, hip_lib, 'celeba_uncsnpp_st', B=2)

@@ -38,6 +38,12 @@ def test_train_steps_mixed(st, hip_lib):
   cases.train_steps(st, hip_lib, 'vp', steps=2, mixed=True)
 
 
+@pytest.mark.parametrize('family', ['vp', 've'])
+def test_loss_curve_100_steps(st, hip_lib, family):
+  """A 100-step training trajectory against RefNet + torch Adam: per-sample losses within 1e-3 at every step."""
+  print('loss curve:', cases.loss_curve(st, hip_lib, family))
+
+
 def test_dropout_consistency(st, hip_lib):
   cases.dropout_consistency(st, hip_lib)
 
