@@ -134,12 +134,17 @@ def parse():
   ap.add_argument('--sampler-steps', type=int, default=6, help='PC-sampler iterations timed after the training steps (0 = skip)')
   ap.add_argument('--no-exchange-proxy', action='store_true',
                   help='N = 1 only: skip the second timed run with the gradient exchange forced on in a one-rank RCCL group')
+  ap.add_argument('--no-extra-workloads', action='store_true',
+                  help='N = 1, default workload only: skip the `workloads` object (BASELINE configs[2] / configs[4] nets, each with its '
+                       'own step time, roofline, bounded CPU baseline, and the configs[4] PC sampler at N = 1000 / 2000)')
+  ap.add_argument('--extra-steps', type=int, default=12, help='timed steps of each extra workload')
+  ap.add_argument('--cpu-big-batch', type=int, default=128, help='batch of the single like-for-like CPU step (0 = skip)')
   ap.add_argument('--force-exchange', action='store_true',
                   help='N = 1: run the WHOLE benchmark (the reported value too) with the exchange forced on')
   return ap.parse_args()
 
 
-def cpu_baseline(st, cfg_name, batch, steps, fir=False):
+def cpu_baseline(st, cfg_name, batch, steps, fir=False, big_batch=0, pc=True):
   """The oracle restatement (PyTorch CPU, oneDNN) of the same training step on the host cores."""
   import ref_torch
   cfg = st.configs.get_config(cfg_name)
@@ -171,6 +176,8 @@ def cpu_baseline(st, cfg_name, batch, steps, fir=False):
   # BASELINE.json configs[0] also names "1 PC sample step": one corrector + predictor iteration of the config's sampler
   # registry (euler_maruyama + none, the CPU-runnable pair), batch `batch`, median of `steps`
   try:
+    if not pc:
+      raise StopIteration
     ref.eval()
     xs = torch.randn(batch, cfg.data.num_channels, cfg.data.image_size, cfg.data.image_size)
     vec_t = torch.ones(batch) * 0.5
@@ -183,20 +190,22 @@ def cpu_baseline(st, cfg_name, batch, steps, fir=False):
         pc.append(time.perf_counter() - t0)
     out['pc_iteration'] = {'sec': float(np.median(pc[1:])), 'batch': batch, 'image_evals_per_s': batch / float(np.median(pc[1:])),
                            'sample': 'euler_maruyama predictor + none corrector, one iteration'}
+  except StopIteration:
+    pass
   except Exception as e:
     out['pc_iteration'] = {'error': repr(e)[:200]}
-  # a larger batch for a like-for-like images/s (BASELINE.md section 4 (ii) asks for 128: 128 images at ~1.5 images/s
-  # would be ~90 s per step, beyond the bounded sample; batch 32, one step after the warm state above)
-  try:
-    ref.train()
-    big = 32
-    xb = st.datasets.synthetic_batch(cfg, big, generator=torch.Generator().manual_seed(1))
-    t0 = time.perf_counter()
-    step_fn(state, xb)
-    dt = time.perf_counter() - t0
-    out['batch32'] = {'value': big / dt, 'unit': 'images/s', 'sec_per_step': dt, 'steps': 1}
-  except Exception as e:
-    out['batch32'] = {'error': repr(e)[:200]}
+  # a like-for-like batch (SURVEY.md 8(d) / BASELINE.md section 4 (ii): the benched per-GPU batch, 128): ONE step on the
+  # warm state above -- about a minute of CPU work, the bounded sample of this leg
+  if big_batch:
+    try:
+      ref.train()
+      xb = st.datasets.synthetic_batch(cfg, big_batch, generator=torch.Generator().manual_seed(1))
+      t0 = time.perf_counter()
+      step_fn(state, xb)
+      dt = time.perf_counter() - t0
+      out[f'batch{big_batch}'] = {'value': big_batch / dt, 'unit': 'images/s', 'sec_per_step': dt, 'steps': 1}
+    except Exception as e:
+      out[f'batch{big_batch}'] = {'error': repr(e)[:200]}
   return out
 
 
@@ -263,6 +272,132 @@ def sampler_rate(st, cfg, sde, score_model, batch, steps, device):
   return {'score_evals_per_s': evals / dt, 'image_evals_per_s': evals * batch / dt, 'batch': batch, 'iterations': steps,
           'network_evals': evals, 'method': cfg.sampling.method, 'predictor': cfg.sampling.predictor,
           'corrector': cfg.sampling.corrector, 'ms_per_eval': 1e3 * dt / evals}
+
+
+def roofline_of(summ, prof_steps, ms_per_step):
+  """The `roofline` / `kernels` objects from a KernelTimer summary (dominant contraction kernel by total time)."""
+  dom = max(summ, key=lambda k: summ[k]['total_ms'])
+  a = summ[dom]
+  traffic, traffic_src = traffic_of(dom)
+  roof = {'bound': 'mfma', 'achieved': a['tflops'], 'peak': kernel_peak(dom), 'unit': 'TFLOP/s',
+          'frac': a['tflops'] / kernel_peak(dom), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
+          'traffic_source': traffic_src, 'kernel': dom, 'symbol': KERNEL_SYMBOL.get(dom),
+          'peak_note': ('bf16 MFMA dense peak / 6 products per fp32 product' if dom.endswith('.x3')
+                        else 'fp16 MFMA dense peak / 3 products per fp32 product' if kernel_peak(dom) == PEAK_X2_TFLOPS
+                        else 'f32-input MFMA peak'),
+          'avg_us': a['avg_us'], 'launches': a['count'], 'flops_per_launch': a['flops_per_launch'],
+          'share_of_step': (a['total_ms'] / max(prof_steps, 1)) / ms_per_step,
+          'measured': f'{prof_steps} eager steps right after the timed (hipGraph) steps'}
+  kernels = {k: {'tflops': round(v['tflops'], 2), 'frac_of_peak': round(v['tflops'] / kernel_peak(k), 3),
+                 'avg_us': round(v['avg_us'], 1), 'launches': v['count'],
+                 'total_ms_per_step': round(v['total_ms'] / max(prof_steps, 1), 3)} for k, v in summ.items()}
+  return roof, kernels
+
+
+def extra_workload(st, name, device, args):
+  """One more BASELINE workload inside the same run (N = 1): the same measurement as the headline -- K timed step_fn calls
+  between device syncs after priming + warm-up, the dominant kernel's roofline from event-bracketed eager steps, the step
+  against the matrix-pipe and HBM ceilings, a bounded CPU baseline of the same net -- as a sub-object of the JSON line.
+  celebahq256 adds the config's PC sampler (reverse_diffusion + langevin) at N = 1000 and N = 2000 (the
+  reference runs 2000, BASELINE.json says "1000-step"): the time grid has N points, a bounded number of iterations is timed."""
+  import copy
+  from importlib import import_module
+  cfg_name, per_gpu_batch, desc = WORKLOADS[name]
+  cfg = st.configs.get_config(cfg_name)
+  cfg.device = device
+  sde = st.sde_lib.get_sde(cfg, None)
+  torch.manual_seed(0)
+  score_model = st.models.utils.create_model(cfg, sde)
+  eng = score_model.module.engine()
+  eng.ensure_flat()
+  optimizer = st.losses.get_optimizer(cfg, score_model.parameters())
+  ema = st.models.ema.ExponentialMovingAverage(score_model.parameters(), decay=cfg.model.ema_rate)
+  state = dict(optimizer=optimizer, model=score_model, ema=ema, step=0)
+  step_fn = st.losses.get_step_fn(cfg, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg))
+  batch = st.datasets.synthetic_batch(cfg, per_gpu_batch, device=device, generator=torch.Generator().manual_seed(4321))
+  steps = args.extra_steps
+  for _ in range(2 + 4):
+    step_fn(state, batch)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    losses_ = step_fn(state, batch)
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  ms = 1e3 * elapsed / steps
+  ips = per_gpu_batch * steps / elapsed
+  out = {'metric': f'training images/sec ({name})', 'value': ips, 'unit': 'images/s', 'ms_per_step': ms, 'steps': steps, 'warmup': 4,
+         'dtype': 'f32', 'data': 'synthetic',
+         'config': {'workload': desc, 'per_gpu_batch': per_gpu_batch, 'loss_mean': float(losses_.mean())}}
+  tf = TRAIN_FLOPS_PER_IMG[cfg_name] * ips / 1e12
+  gbs = (TRAIN_HBM_BYTES_PER_IMG[cfg_name] * per_gpu_batch + 16.0 * 4 * eng.flat.data.numel()) * (steps / elapsed) / 1e9
+  out['step_roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_X2_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_X2_TFLOPS,
+                          'frac_of_f32_input_mfma_peak': tf / PEAK_F32_MFMA_TFLOPS, 'hbm_algorithmic_GBps': gbs, 'frac_hbm': gbs / 8000.0}
+  if not args.no_kernel_timer:
+    timer = import_module('soft-truncation_amd.engine.profile').KernelTimer()
+    eng.profiler = timer
+    for _ in range(args.prof_steps):
+      step_fn(state, batch)
+    torch.cuda.synchronize()
+    eng.profiler = None
+    summ = timer.summary()
+    if summ:
+      out['roofline'], out['kernels'] = roofline_of(summ, args.prof_steps, ms)
+  if name == 'celebahq256':
+    out['sampler'] = {}
+    for n_grid in (1000, 2000):
+      try:
+        sde_n = copy.copy(sde)
+        sde_n.N = n_grid
+        sb = cfg.sampling.batch_size if hasattr(cfg.sampling, 'batch_size') else 16
+        out['sampler'][f'N{n_grid}'] = pc_rate(st, cfg, sde_n, score_model, sb, 12, device)
+      except Exception as e:
+        out['sampler'][f'N{n_grid}'] = {'error': repr(e)[:200]}
+  del state, optimizer, ema, score_model, eng, step_fn
+  torch.cuda.empty_cache()
+  if not args.no_cpu_baseline:
+    try:
+      out['cpu_baseline'] = cpu_baseline(st, cfg_name, {'celeba64': 4, 'celebahq256': 1}.get(name, 2), 1, pc=False)
+    except Exception as e:
+      out['cpu_baseline'] = {'error': repr(e)[:200]}
+  return out
+
+
+def pc_rate(st, cfg, sde, score_model, batch, iterations, device):
+  """Score evaluations per second of the PC sampler on the FULL-length time grid (sde.N points, timesteps = linspace(T, eps, N),
+  sampling.py:404): `iterations` consecutive corrector + predictor iterations from the start of the grid, timed between
+  syncs after two untimed ones (each iteration = 2 network evaluations for reverse_diffusion + langevin with n_steps = 1);
+  the full run is N of these plus the denoising evaluation."""
+  shape = (batch, cfg.data.num_channels, cfg.data.image_size, cfg.data.image_size)
+  eps = 1e-3 if cfg.training.sde == 'vpsde' else 1e-5
+  predictor = st.sampling.get_predictor(cfg.sampling.predictor.lower())
+  corrector = st.sampling.get_corrector(cfg.sampling.corrector.lower())
+  snr, n_steps = cfg.sampling.snr, cfg.sampling.n_steps_each
+  score_model.eval()
+  with torch.no_grad():
+    x = sde.prior_sampling(shape).to(device)
+    timesteps = torch.linspace(sde.T, eps, sde.N, device=device)
+
+    def iterate(i):
+      nonlocal x
+      vec_t = torch.ones(shape[0], device=device) * timesteps[i]
+      x, _ = st.sampling.shared_corrector_update_fn(x, vec_t, sde, score_model, corrector, cfg.training.continuous, snr, n_steps, cfg)
+      x, _ = st.sampling.shared_predictor_update_fn(x, vec_t, sde, score_model, predictor, cfg.sampling.probability_flow,
+                                                    cfg.training.continuous, cfg)
+    for i in range(2):
+      iterate(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(2, 2 + iterations):
+      iterate(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+  evals = iterations * (n_steps + 1)
+  full = sde.N * (n_steps + 1) + 1
+  return {'score_evals_per_s': evals / dt, 'image_evals_per_s': evals * batch / dt, 'ms_per_eval': 1e3 * dt / evals, 'batch': batch,
+          'grid_points': sde.N, 'iterations_timed': iterations, 'network_evals_timed': evals, 'network_evals_full_run': full,
+          'full_run_s_extrapolated': full * dt / evals, 'images_per_s_full_run': batch / (full * dt / evals),
+          'predictor': cfg.sampling.predictor, 'corrector': cfg.sampling.corrector, 'finite': bool(torch.isfinite(x).all())}
 
 
 def arithmetic_check(device):
@@ -522,21 +657,7 @@ def main():
     if timer is not None:
       summ = timer.summary()
       if summ:
-        dom = max(summ, key=lambda k: summ[k]['total_ms'])
-        a = summ[dom]
-        traffic, traffic_src = traffic_of(dom)
-        out['roofline'] = {'bound': 'mfma', 'achieved': a['tflops'], 'peak': kernel_peak(dom), 'unit': 'TFLOP/s',
-                           'frac': a['tflops'] / kernel_peak(dom), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
-                           'traffic_source': traffic_src, 'kernel': dom, 'symbol': KERNEL_SYMBOL.get(dom),
-                           'peak_note': ('bf16 MFMA dense peak / 6 products per fp32 product' if dom.endswith('.x3')
-                                         else 'fp16 MFMA dense peak / 3 products per fp32 product' if kernel_peak(dom) == PEAK_X2_TFLOPS
-                                         else 'f32-input MFMA peak'),
-                           'avg_us': a['avg_us'], 'launches': a['count'], 'flops_per_launch': a['flops_per_launch'],
-                           'share_of_step': (a['total_ms'] / max(args.prof_steps, 1)) / (1e3 * elapsed / args.steps),
-                           'measured': f'{args.prof_steps} eager steps right after the timed (hipGraph) steps'}
-        out['kernels'] = {k: {'tflops': round(v['tflops'], 2), 'frac_of_peak': round(v['tflops'] / kernel_peak(k), 3),
-                              'avg_us': round(v['avg_us'], 1), 'launches': v['count'],
-                              'total_ms_per_step': round(v['total_ms'] / max(args.prof_steps, 1), 3)} for k, v in summ.items()}
+        out['roofline'], out['kernels'] = roofline_of(summ, args.prof_steps, 1e3 * elapsed / args.steps)
     hbm_bytes = TRAIN_HBM_BYTES_PER_IMG.get(cfg_name)
     if hbm_bytes is not None:
       gbs = (hbm_bytes * per_gpu_batch + 16.0 * 4 * score_model.module.engine().flat.data.numel()) * (args.steps / elapsed) / 1e9
@@ -562,7 +683,7 @@ def main():
       except Exception as e:                         # the reference's RVE sampling raises: report, do not fail
         out['sampler'] = {'error': repr(e)[:200]}
     if world == 1 and not args.no_cpu_baseline:
-      out['cpu_baseline'] = cpu_baseline(st, cfg_name, args.cpu_batch, args.cpu_steps, args.fir)
+      out['cpu_baseline'] = cpu_baseline(st, cfg_name, args.cpu_batch, args.cpu_steps, args.fir, big_batch=args.cpu_big_batch)
     if world == 1 and not args.no_parity_probe:
       try:
         del state, optimizer, ema, score_model       # free the benched replica's arenas before building the probe's
@@ -570,6 +691,19 @@ def main():
         out['parity_probe'] = parity_probe(st, cfg_name, device)
       except Exception as e:
         out['parity_probe'] = {'error': repr(e)[:300]}
+    if world == 1 and args.workload == 'cifar10' and not args.no_extra_workloads and not args.fir and not args.batch:
+      # north_star: "throughput on 32x32 AND 256x256 batches": BASELINE configs[2] / configs[4] nets in the same driver-timed run
+      try:
+        del state, optimizer, ema, score_model           # (already gone when the parity probe ran)
+      except NameError:
+        pass
+      torch.cuda.empty_cache()
+      out['workloads'] = {}
+      for name in ('celeba64', 'celebahq256'):
+        try:
+          out['workloads'][name] = extra_workload(st, name, device, args)
+        except Exception as e:
+          out['workloads'][name] = {'error': repr(e)[:300]}
     real_stdout.write(json.dumps(out) + '\n')
     real_stdout.flush()
   if world > 1 or (args.force_exchange and dist.is_initialized()):
