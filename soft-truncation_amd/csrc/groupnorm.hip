@@ -339,193 +339,137 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnArgs a, const float* __re
 // (algorithmic traffic: read x, read dy, write dx).  Per-channel sums come from a segmented wave reduction (a wave
 // covers one channel or 64/(HW/4) whole channels) written to fixed LDS slots and folded in slot order -- no
 // atomics, so results are reproducible.  blockDim = 64/128/256 so small groups do not idle lanes.
-//
-// Round 4: PERSISTENT and software-pipelined.  With one workgroup per (sample, group) all resident workgroups of a round
-// walked through load burst -> arithmetic -> store burst in lockstep and the memory pipe idled in between (C128 @ 32x32,
-// batch 128: 189 MB in 44.8 us = 4.2 TB/s).  Now a workgroup owns the groups blockIdx.x, blockIdx.x + gridDim.x, ... and
-// issues the x / dy loads of its NEXT group as soon as the current group's (du, xhat) are in registers -- behind the loads
-// of the values phase 2 accumulates into (dx, the identity-skip addend), so the in-order vmcnt wait of phase 2 does not
-// cover them: they stream in under the reductions, the dx arithmetic and the stores.  Same arithmetic per group, in the
-// same order: results are bit-identical to the one-group-per-workgroup form.
-// TMAX = 256: workgroups of <= 256 threads, three per SIMD-wave slot set (<= 168 VGPRs: du, xhat, the accumulated values and
-// the next group's x / dy are all live at once); TMAX = 1024 (groups of > 4096 elements): 128 VGPRs, no prefetch.
-template <int IPT, bool WANT, int TMAX>
-__global__ __launch_bounds__(TMAX, TMAX <= 256 ? 3 : 1) void gn_bwd_flat_kernel(GnArgs a, const float* __restrict__ dy,
+template <int IPT, bool WANT>
+__global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float* __restrict__ dy,
                                                           const float* __restrict__ mean_in,
                                                           const float* __restrict__ rstd_in, float* __restrict__ dx1,
                                                           float beta1, float* __restrict__ dx2, float beta2,
-                                                          float* __restrict__ ws, int hw_log2, GnBwdOut out, int ngroups) {
+                                                          float* __restrict__ ws, int hw_log2, GnBwdOut out) {
   __shared__ float s_part[2048], s_ch[1024], s_mx[16];
   const int T = blockDim.x;
+  const int ng = blockIdx.x;
+  const int n = ng / a.G, g = ng - n * a.G;
   const int C = a.C1 + a.C2;
+  const float mean = mean_in[ng], rstd = rstd_in[ng];
   unsigned long long seed = a.seed;
   if (a.drop_p > 0.f && a.seed_dev) seed += *a.seed_dev;
+  const int c0 = g * a.cpg;
   const int L4 = (a.cpg << hw_log2) >> 2;
   const int seglog = min(6, hw_log2 - 2);          // lanes of a wave that share a channel = 2^seglog
   const int lane = threadIdx.x & 63;
-  const int spc = (a.HW >> 2) >> seglog;            // slots per channel
-  const float inv_l = 1.f / ((float)a.cpg * (float)a.HW);
-  constexpr bool want = WANT;            // compile-time: the plain instances carry none of the by-product code
-  float wg_max = 0.f;                    // thread 0: max |dx1| over this workgroup's groups (one atomic at the end)
 
-  // element (group ng, item k) of this thread: channel, offset in the channel, source pointer
-  auto locate = [&](int ng, int k, int& c, int& off, bool& valid) {
-    const int g = ng % a.G;
+  float du[IPT][4], xh[IPT][4], gam[IPT];
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
     const int i = threadIdx.x + T * k;
-    valid = i < L4;
+    const bool valid = i < L4;
     const int e = valid ? 4 * i : 0;
-    c = g * a.cpg + (e >> hw_log2);
-    off = e & (a.HW - 1);
-  };
-  float4 xv[IPT], dv[IPT];
-  // (`live` = there is such a group: xv / dv are (re)defined on every path, so they are dead between phase 1 and here and
-  // cost no registers there; without it the last iteration's untaken branch keeps 8 float4 alive through the whole body)
-  auto fetch = [&](int ng, bool live) {
-    const int n = ng / a.G;
+    const int c = c0 + (e >> hw_log2), off = e & (a.HW - 1);
+    const float* xp = c < a.C1 ? a.x1 + (((long)n * a.C1 + c) << hw_log2) + off
+                               : a.x2 + (((long)n * a.C2 + (c - a.C1)) << hw_log2) + off;
+    const unsigned long long flat = ((((unsigned long long)n * C + c)) << hw_log2) + off;
+    const float4 xv = *reinterpret_cast<const float4*>(xp);
+    const float4 dv = *reinterpret_cast<const float4*>(dy + flat);
+    const float ga = a.gamma[c], be = a.beta[c];
+    gam[k] = ga;
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+    float cs0 = 0.f, cs1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-      int c, off; bool valid;
-      locate(ng, k, c, off, valid);
-      const float* xp = c < a.C1 ? a.x1 + (((long)n * a.C1 + c) << hw_log2) + off
-                                 : a.x2 + (((long)n * a.C2 + (c - a.C1)) << hw_log2) + off;
-      xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      dv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live) {
-        xv[k] = *reinterpret_cast<const float4*>(xp);
-        dv[k] = *reinterpret_cast<const float4*>(dy + ((((long)n * C + c)) << hw_log2) + off);
-      }
+    for (int j = 0; j < 4; ++j) {
+      const float d = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, (flat & ~3ULL) + j, xh[k][j]);
+      du[k][j] = valid ? d : 0.f;
+      cs0 += du[k][j];
+      cs1 += du[k][j] * xh[k][j];
     }
-  };
+    for (int o = 0; o < seglog; ++o) {
+      cs0 += __shfl_xor(cs0, 1 << o);
+      cs1 += __shfl_xor(cs1, 1 << o);
+    }
+    if (valid && (lane & ((1 << seglog) - 1)) == 0) {
+      s_part[2 * (i >> seglog)] = cs0;
+      s_part[2 * (i >> seglog) + 1] = cs1;
+    }
+  }
+  __syncthreads();
+  const int spc = (a.HW >> 2) >> seglog;            // slots per channel
+  for (int cl = threadIdx.x; cl < a.cpg; cl += T) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int q = 0; q < spc; ++q) {
+      t0 += s_part[2 * (cl * spc + q)];
+      t1 += s_part[2 * (cl * spc + q) + 1];
+    }
+    s_ch[2 * cl] = t0;
+    s_ch[2 * cl + 1] = t1;
+    ws[((long)n * C + c0 + cl) * 2 + 0] = t0;
+    ws[((long)n * C + c0 + cl) * 2 + 1] = t1;
+  }
+  __syncthreads();
+  float g0 = 0.f, g1 = 0.f;
+  for (int cl = 0; cl < a.cpg; ++cl) {
+    const float ga = a.gamma[c0 + cl];
+    g0 += ga * s_ch[2 * cl];
+    g1 += ga * s_ch[2 * cl + 1];
+  }
+  const float inv_l = 1.f / ((float)a.cpg * (float)a.HW);
+  const float m1 = g0 * inv_l, m2 = g1 * inv_l;
 
-  int ng = blockIdx.x;
-  constexpr bool PIPE = TMAX <= 256;     // 1024-thread workgroups are capped at 128 VGPRs: no room for a group in flight
-  if (PIPE) fetch(min(ng, ngroups - 1), ng < ngroups);
-  // (TMAX = 1024: one group per workgroup, grid = ngroups -- as a loop the same body needs 28 registers more than the 128 it has)
-  for (; ng < ngroups; ng += PIPE ? gridDim.x : ngroups) {
-    if (!PIPE) fetch(ng, true);
-    const int n = ng / a.G, g = ng - n * a.G;
-    const float mean = mean_in[ng], rstd = rstd_in[ng];
-    const int c0 = g * a.cpg;
-
-    float du[IPT][4], xh[IPT][4], gam[IPT];
+  // `out` (stk_gn_bwd_out_f32, single-source layers): what the consumer of dx1 -- the backward of the convolution that
+  // produced x1 -- would otherwise take one more pass over dx1 for: per-(sample, channel) sums of the FINAL dx1 values
+  // (bias / time-embedding gradients) and max |dx1| (scale record of its planes).  Block-uniform branches only.
+  constexpr bool want = WANT;            // compile-time: the plain instances carry none of the by-product code
+  float amax_l = 0.f;
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-      int c, off; bool valid;
-      locate(ng, k, c, off, valid);
-      const int i = threadIdx.x + T * k;
-      const unsigned long long flat = ((((unsigned long long)n * C + c)) << hw_log2) + off;
-      const float ga = a.gamma[c], be = a.beta[c];
-      gam[k] = ga;
-      const float xs[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w}, ds[4] = {dv[k].x, dv[k].y, dv[k].z, dv[k].w};
-      float cs0 = 0.f, cs1 = 0.f;
+  for (int k = 0; k < IPT; ++k) {
+    const int i = threadIdx.x + T * k;
+    const bool valid = i < L4;
+    const int e = valid ? 4 * i : 0;
+    const int c = c0 + (e >> hw_log2), off = e & (a.HW - 1);
+    float* op; float ob;
+    if (c < a.C1) { op = dx1 ? dx1 + (((long)n * a.C1 + c) << hw_log2) + off : nullptr; ob = beta1; }
+    else { op = dx2 ? dx2 + (((long)n * a.C2 + (c - a.C1)) << hw_log2) + off : nullptr; ob = beta2; }
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid && op) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float d = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, (flat & ~3ULL) + j, xh[k][j]);
-        du[k][j] = valid ? d : 0.f;
-        cs0 += du[k][j];
-        cs1 += du[k][j] * xh[k][j];
+      for (int j = 0; j < 4; ++j) r[j] = rstd * (du[k][j] * gam[k] - m1 - xh[k][j] * m2);
+      if (ob != 0.f) {
+        const float4 old = *reinterpret_cast<const float4*>(op);
+        r[0] += ob * old.x; r[1] += ob * old.y; r[2] += ob * old.z; r[3] += ob * old.w;
       }
-      for (int o = 0; o < seglog; ++o) {
-        cs0 += __shfl_xor(cs0, 1 << o);
-        cs1 += __shfl_xor(cs1, 1 << o);
+      if (want && out.add && c < a.C1) {
+        const float4 ad = *reinterpret_cast<const float4*>(out.add + (((long)n * a.C1 + c) << hw_log2) + off);
+        r[0] += out.add_scale * ad.x; r[1] += out.add_scale * ad.y; r[2] += out.add_scale * ad.z; r[3] += out.add_scale * ad.w;
       }
-      if (valid && (lane & ((1 << seglog) - 1)) == 0) {
-        s_part[2 * (i >> seglog)] = cs0;
-        s_part[2 * (i >> seglog) + 1] = cs1;
-      }
+      *reinterpret_cast<float4*>(op) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+    if (want) {
+      const bool mine = c < a.C1;                           // by-products cover dx1 only
+      float rs = mine ? (r[0] + r[1]) + (r[2] + r[3]) : 0.f;
+      if (mine) amax_l = fmaxf(amax_l, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
+      for (int o = 0; o < seglog; ++o) rs += __shfl_xor(rs, 1 << o);
+      if (valid && (lane & ((1 << seglog) - 1)) == 0) s_part[i >> seglog] = rs;     // s_part is free after the barrier above
+    }
+  }
+  if (want) {
+    {
+      const float m = wave_max(amax_l);
+      if (lane == 0) s_mx[threadIdx.x >> 6] = m;          // (not s_ch: another wave may still be reading its group sums)
     }
     __syncthreads();
     for (int cl = threadIdx.x; cl < a.cpg; cl += T) {
-      float t0 = 0.f, t1 = 0.f;
-      for (int q = 0; q < spc; ++q) {
-        t0 += s_part[2 * (cl * spc + q)];
-        t1 += s_part[2 * (cl * spc + q) + 1];
-      }
-      s_ch[2 * cl] = t0;
-      s_ch[2 * cl + 1] = t1;
-      ws[((long)n * C + c0 + cl) * 2 + 0] = t0;
-      ws[((long)n * C + c0 + cl) * 2 + 1] = t1;
+      if (c0 + cl >= a.C1) continue;
+      float t = 0.f;
+      for (int q = 0; q < spc; ++q) t += s_part[cl * spc + q];
+      t *= out.scale;
+      if (out.sum) { out.sum[((long)n * a.C1 + c0 + cl) * 2] = t; out.sum[((long)n * a.C1 + c0 + cl) * 2 + 1] = t; }
+      if (out.temb) out.temb[(long)n * out.temb_stride + c0 + cl] = t;
     }
-    __syncthreads();
-    float g0 = 0.f, g1 = 0.f;
-    for (int cl = 0; cl < a.cpg; ++cl) {
-      const float ga = a.gamma[c0 + cl];
-      g0 += ga * s_ch[2 * cl];
-      g1 += ga * s_ch[2 * cl + 1];
+    if (out.amax && threadIdx.x == 0) {
+      // ONE atomic per workgroup (4096 workgroups on 256 slots: 16 per address; one per wave measured no gain over the
+      // separate pass).  Non-negative floats order like their bit patterns: an integer max is exact and order-independent
+      float m = 0.f;
+      for (int w = 0; w < (T >> 6); ++w) m = fmaxf(m, s_mx[w]);
+      atomicMax(reinterpret_cast<unsigned*>(out.amax) + (blockIdx.x & 255), __float_as_uint(m));
     }
-    const float m1 = g0 * inv_l, m2 = g1 * inv_l;
-
-    // `out` (stk_gn_bwd_out_f32, single-source layers): what the consumer of dx1 -- the backward of the convolution that
-    // produced x1 -- would otherwise take one more pass over dx1 for: per-(sample, channel) sums of the FINAL dx1 values
-    // (bias / time-embedding gradients) and max |dx1| (scale record of its planes).  Block-uniform branches only.
-    float amax_l = 0.f;
-    float4 rr[IPT];
-#pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-      int c, off; bool valid;
-      locate(ng, k, c, off, valid);
-      const int i = threadIdx.x + T * k;
-      float* op; float ob;
-      if (c < a.C1) { op = dx1 ? dx1 + (((long)n * a.C1 + c) << hw_log2) + off : nullptr; ob = beta1; }
-      else { op = dx2 ? dx2 + (((long)n * a.C2 + (c - a.C1)) << hw_log2) + off : nullptr; ob = beta2; }
-      float r[4] = {0.f, 0.f, 0.f, 0.f};
-      if (valid && op) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = rstd * (du[k][j] * gam[k] - m1 - xh[k][j] * m2);
-        if (ob != 0.f) {
-          const float4 old = *reinterpret_cast<const float4*>(op);
-          r[0] += ob * old.x; r[1] += ob * old.y; r[2] += ob * old.z; r[3] += ob * old.w;
-        }
-        if (want && out.add && c < a.C1) {
-          const float4 ad = *reinterpret_cast<const float4*>(out.add + (((long)n * a.C1 + c) << hw_log2) + off);
-          r[0] += out.add_scale * ad.x; r[1] += out.add_scale * ad.y; r[2] += out.add_scale * ad.z; r[3] += out.add_scale * ad.w;
-        }
-      }
-      if (PIPE) rr[k] = make_float4(r[0], r[1], r[2], r[3]);
-      else if (valid && op) *reinterpret_cast<float4*>(op) = make_float4(r[0], r[1], r[2], r[3]);
-      if (want) {
-        const bool mine = c < a.C1;                           // by-products cover dx1 only
-        float rs = mine ? (r[0] + r[1]) + (r[2] + r[3]) : 0.f;
-        if (mine) amax_l = fmaxf(amax_l, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
-        for (int o = 0; o < seglog; ++o) rs += __shfl_xor(rs, 1 << o);
-        if (valid && (lane & ((1 << seglog) - 1)) == 0) s_part[i >> seglog] = rs;     // s_part is free after the barrier above
-      }
-    }
-    // every load of this group has been consumed: the next group's x / dy go out BEFORE the stores, and stay in flight
-    // through the stores, the by-product reductions and the next iteration's preamble
-    if (PIPE) fetch(min(ng + (int)gridDim.x, ngroups - 1), ng + (int)gridDim.x < ngroups);
-#pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-      int c, off; bool valid;
-      locate(ng, k, c, off, valid);
-      float* op;
-      if (c < a.C1) op = dx1 ? dx1 + (((long)n * a.C1 + c) << hw_log2) + off : nullptr;
-      else op = dx2 ? dx2 + (((long)n * a.C2 + (c - a.C1)) << hw_log2) + off : nullptr;
-      if (PIPE && valid && op) *reinterpret_cast<float4*>(op) = rr[k];
-    }
-    if (want) {
-      {
-        const float m = wave_max(amax_l);
-        if (lane == 0) s_mx[threadIdx.x >> 6] = m;          // (not s_ch: another wave may still be reading its group sums)
-      }
-      __syncthreads();
-      for (int cl = threadIdx.x; cl < a.cpg; cl += T) {
-        if (c0 + cl >= a.C1) continue;
-        float t = 0.f;
-        for (int q = 0; q < spc; ++q) t += s_part[cl * spc + q];
-        t *= out.scale;
-        if (out.sum) { out.sum[((long)n * a.C1 + c0 + cl) * 2] = t; out.sum[((long)n * a.C1 + c0 + cl) * 2 + 1] = t; }
-        if (out.temb) out.temb[(long)n * out.temb_stride + c0 + cl] = t;
-      }
-      if (threadIdx.x == 0)
-        for (int w = 0; w < (T >> 6); ++w) wg_max = fmaxf(wg_max, s_mx[w]);
-      __syncthreads();                   // s_part / s_mx are rewritten by the next group's phase 1 / by-products
-    }
-  }
-  if (want && out.amax && threadIdx.x == 0 && blockIdx.x < ngroups) {
-    // ONE atomic per workgroup.  Non-negative floats order like their bit patterns: an integer max is exact and
-    // order-independent
-    atomicMax(reinterpret_cast<unsigned*>(out.amax) + (blockIdx.x & 255), __float_as_uint(wg_max));
   }
 }
 
@@ -1295,35 +1239,20 @@ static int gn_bwd_impl(const float* dy, const float* x1, int C1, const float* x2
     int T = 64;
     while (T < 1024 && T * tgt < L4) T <<= 1;
     const int ipt = stk_cdiv(L4, T);
-    // persistent grid: every workgroup walks the same number of groups (+-1); ~4 workgroups of <= 256 threads per CU
-    // keep the loads of their next group in flight while they store the current one (STK_GN_BWD_WGS: workgroups per CU)
-    static const int per_cu = [] { const char* e = getenv("STK_GN_BWD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-    const int NG = N * G;
-    int wgs = per_cu ? per_cu : (T > 256 ? 1 : T == 256 ? 3 : T == 128 ? 6 : 12);
-    int grid = NG;
-    if ((long)wgs * STK_NUM_CU < NG) grid = stk_cdiv(NG, stk_cdiv(NG, wgs * STK_NUM_CU));
 #define STK_GN_FLAT(IPT)                                                                                          \
   do {                                                                                                            \
     if (out.sum || out.temb || out.amax || out.add)                                                               \
-      STK_GN_FLAT_T(IPT, true);                                                                                   \
+      hipLaunchKernelGGL((gn_bwd_flat_kernel<IPT, true>), dim3(N * G), dim3(T), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, \
+                         dx1_beta, dx2, dx2_beta, ws, hw_log2, out);                                               \
     else                                                                                                          \
-      STK_GN_FLAT_T(IPT, false);                                                                                  \
-  } while (0)
-#define STK_GN_FLAT_T(IPT, W)                                                                                     \
-  do {                                                                                                            \
-    if (T <= 256)                                                                                                 \
-      hipLaunchKernelGGL((gn_bwd_flat_kernel<IPT, W, 256>), dim3(grid), dim3(T), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, \
-                         dx1_beta, dx2, dx2_beta, ws, hw_log2, out, NG);                                           \
-    else                                                                                                          \
-      hipLaunchKernelGGL((gn_bwd_flat_kernel<IPT, W, 1024>), dim3(grid), dim3(T), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, \
-                         dx1_beta, dx2, dx2_beta, ws, hw_log2, out, NG);                                           \
+      hipLaunchKernelGGL((gn_bwd_flat_kernel<IPT, false>), dim3(N * G), dim3(T), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, \
+                         dx1_beta, dx2, dx2_beta, ws, hw_log2, out);                                               \
   } while (0)
     if (ipt <= 1) STK_GN_FLAT(1);
     else if (ipt <= 2) STK_GN_FLAT(2);
     else if (ipt <= 3) STK_GN_FLAT(3);
     else STK_GN_FLAT(4);
 #undef STK_GN_FLAT
-#undef STK_GN_FLAT_T
   } else {
     hipLaunchKernelGGL(gn_bwd_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, a, dy, mean, rstd, dx1, dx1_beta,
                        dx2, dx2_beta, ws);
