@@ -561,33 +561,95 @@ struct EpSlab {
     }
   }
 };
-// sum of the split slabs in a fixed order, then the same epilogue arithmetic as EpFwd / EpDgrad
+// sum of the split slabs in a fixed order, then the same epilogue arithmetic as EpFwd / EpDgrad.
+// VEC = 4 (H W % 4 == 0, 16-byte aligned tensors): four consecutive pixels of one image per thread -- 16-byte loads of the
+// `splits` slabs and of the residual, one 16-byte store (round 4: the scalar form spent 9 us on 33 MB).
+template <int VEC>
 __global__ __launch_bounds__(256) void slab_fwd_kernel(ConvP p, int splits, int M, int Nn) {
-  const long total = (long)M * Nn, gstride = (long)gridDim.x * 256;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+  const long total = (long)M * Nn / VEC, gstride = (long)gridDim.x * 256;
+  for (long iv = (long)blockIdx.x * 256 + threadIdx.x; iv < total; iv += gstride) {
+    const long i = iv * VEC;
     const int m = (int)(i / Nn), n = (int)(i - (long)m * Nn);
-    float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += p.part[(long)z * p.part_stride + i];
+    float v[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) v[u] = 0.f;
+    for (int z = 0; z < splits; ++z) {
+      const float* q = p.part + (long)z * p.part_stride + i;
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(q);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      } else {
+        v[0] += q[0];
+      }
+    }
     const int b = n / p.OHW;
     const long idx = ((long)b * p.Cout + m) * p.OHW + (n - b * p.OHW);
-    if (p.bias) v += p.bias[m];
-    if (p.temb) v += p.temb[(long)b * p.temb_stride + m];
-    if (p.res) v += p.res[idx];
-    if (p.use_div) v *= p.inv_div;
-    p.y[idx] = v;
+    float r[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) r[u] = 0.f;
+    if (p.res) {
+      if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p.res + idx); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+      else r[0] = p.res[idx];
+    }
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      // same order of additions as the scalar epilogue: acc + bias + temb + res, then the division
+      float w = v[u];
+      if (p.bias) w += p.bias[m];
+      if (p.temb) w += p.temb[(long)b * p.temb_stride + m];
+      if (p.res) w += r[u];
+      if (p.use_div) w *= p.inv_div;
+      v[u] = w;
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(p.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    else p.y[idx] = v[0];
   }
 }
+template <int VEC>
 __global__ __launch_bounds__(256) void slab_dgrad_kernel(ConvP p, int splits, int M, int Nn) {
-  const long total = (long)M * Nn, gstride = (long)gridDim.x * 256;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+  const long total = (long)M * Nn / VEC, gstride = (long)gridDim.x * 256;
+  for (long iv = (long)blockIdx.x * 256 + threadIdx.x; iv < total; iv += gstride) {
+    const long i = iv * VEC;
     const int m = (int)(i / Nn), n = (int)(i - (long)m * Nn);
-    float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += p.part[(long)z * p.part_stride + i];
+    float v[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) v[u] = 0.f;
+    for (int z = 0; z < splits; ++z) {
+      const float* q = p.part + (long)z * p.part_stride + i;
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(q);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      } else {
+        v[0] += q[0];
+      }
+    }
     const int b = n / p.HW, hw = n - b * p.HW;
     float* d; float beta;
     if (m < p.C1) { d = p.dx1 ? p.dx1 + ((long)b * p.C1 + m) * p.HW + hw : nullptr; beta = p.beta1; }
     else { d = p.dx2 ? p.dx2 + ((long)b * p.C2 + (m - p.C1)) * p.HW + hw : nullptr; beta = p.beta2; }
-    if (d) *d = (beta != 0.f ? beta * *d : 0.f) + p.alpha * v;
+    if (!d) continue;
+    if (VEC == 4) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (beta != 0.f) { const float4 t = *reinterpret_cast<const float4*>(d); o = make_float4(beta * t.x, beta * t.y, beta * t.z, beta * t.w); }
+      *reinterpret_cast<float4*>(d) = make_float4(o.x + p.alpha * v[0], o.y + p.alpha * v[1], o.z + p.alpha * v[2], o.w + p.alpha * v[3]);
+    } else {
+      *d = (beta != 0.f ? beta * *d : 0.f) + p.alpha * v[0];
+    }
+  }
+}
+// launch of the slab sum: the 16-byte form when four consecutive pixels never leave an image / a tensor row
+inline void launch_slab_sum(const ConvP& p, int splits, int M, long Ng, int dgrad, hipStream_t s) {
+  const bool al = stk_aligned16(p.part) && p.part_stride % 4 == 0 &&
+                  (dgrad ? (p.HW % 4 == 0 && (!p.dx1 || stk_aligned16(p.dx1)) && (!p.dx2 || stk_aligned16(p.dx2)))
+                         : (p.OHW % 4 == 0 && stk_aligned16(p.y) && (!p.res || stk_aligned16(p.res))));
+  if (al && Ng % 4 == 0) {
+    const dim3 rgrid((unsigned)stk_ew_grid((long)M * Ng / 4));
+    if (dgrad) hipLaunchKernelGGL(slab_dgrad_kernel<4>, rgrid, dim3(256), 0, s, p, splits, M, (int)Ng);
+    else hipLaunchKernelGGL(slab_fwd_kernel<4>, rgrid, dim3(256), 0, s, p, splits, M, (int)Ng);
+  } else {
+    const dim3 rgrid((unsigned)stk_ew_grid((long)M * Ng));
+    if (dgrad) hipLaunchKernelGGL(slab_dgrad_kernel<1>, rgrid, dim3(256), 0, s, p, splits, M, (int)Ng);
+    else hipLaunchKernelGGL(slab_fwd_kernel<1>, rgrid, dim3(256), 0, s, p, splits, M, (int)Ng);
   }
 }
 
@@ -888,8 +950,13 @@ inline X3Plan x3_plan(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
   const int nch = p.taps * (Kc / 32);
   r.chunks_per_split = nch;
   if (tiles >= 192) { r.ok = 1; return r; }
-  long splits = 512 / tiles;
-  if (splits > nch / 6) splits = nch / 6;            // >= 6 chunks per workgroup, or the prologue dominates
+  // STK_KSPLIT_WGS / STK_KSPLIT_MINCH: A-B knobs of the split (workgroups to fill, fewest chunks per workgroup)
+  static const long target = [] { const char* e = getenv("STK_KSPLIT_WGS"); return e && atol(e) > 0 ? atol(e) : 512L; }();
+  // (round 4 sweep, profiles/r04_ksplit_sweep.txt: >= 12 chunks per workgroup -- 256 -> 256 at 4x4, batch 128: 12 splits 27.4 us,
+  // 6 splits 23.8; 512 -> 256 at 8x8: 73.9 -> 71.9; the 8x8 256 -> 256 layers keep their 4 splits either way)
+  static const long minch = [] { const char* e = getenv("STK_KSPLIT_MINCH"); return e && atol(e) > 0 ? atol(e) : 12L; }();
+  long splits = target / tiles;
+  if (splits > nch / minch) splits = nch / minch;    // few chunks per workgroup: the prologue and the slab traffic dominate
   // few tiles: the 3x3 layers still pay (4 tiles of a 256-channel 8x8 map at batch 4: 94 us on 16 workgroups of the
   // f32-input kernel); a 1x1 layer has too few chunks to split
   if ((tiles < 16 && p.taps != 9) || splits < 2) return r;
@@ -1036,9 +1103,7 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
     }
     STK_X2_LAUNCH_E(EpSlab)
     STK_CHECK_LAUNCH();
-    const dim3 rgrid((unsigned)stk_ew_grid((long)M * Ng));
-    if (dgrad) hipLaunchKernelGGL(slab_dgrad_kernel, rgrid, dim3(256), 0, s, p, r.splits, M, (int)Ng);
-    else hipLaunchKernelGGL(slab_fwd_kernel, rgrid, dim3(256), 0, s, p, r.splits, M, (int)Ng);
+    launch_slab_sum(p, r.splits, M, Ng, dgrad, s);
 #undef STK_X2_LAUNCH_E
 #undef STK_X2_LAUNCH
 #undef STK_PL_LAUNCH
@@ -1072,9 +1137,7 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
   }
   STK_X3_LAUNCH_E(EpSlab)
   STK_CHECK_LAUNCH();
-  const dim3 rgrid((unsigned)stk_ew_grid((long)M * Ng));
-  if (dgrad) hipLaunchKernelGGL(slab_dgrad_kernel, rgrid, dim3(256), 0, s, p, r.splits, M, (int)Ng);
-  else hipLaunchKernelGGL(slab_fwd_kernel, rgrid, dim3(256), 0, s, p, r.splits, M, (int)Ng);
+  launch_slab_sum(p, r.splits, M, Ng, dgrad, s);
 #undef STK_X3_LAUNCH_E
 #undef STK_X3_LAUNCH
   STK_CHECK_LAUNCH();

@@ -1158,7 +1158,9 @@ static int gn_fwd_pl_impl(const float* x1, int C1, const float* x2, int C2, cons
     STK_CHECK_LAUNCH();
     return STK_OK;
   }
-  if (!y) return STK_EINVAL;          // the unfused route goes through the fp32 copy
+  // the unfused route goes through the fp32 copy and leaves no |x| records: a caller that relied on stk_gn_fwd_pl_fused()
+  // for a shape whose pointers miss the 16-byte alignment of the two-kernel route gets an error, not a fault / stale records
+  if (!y || xmax1 || xmax2) return STK_EINVAL;
   int rc = stk_gn_fwd_f32(x1, C1, x2, C2, gamma, beta, y, mean, rstd, N, HW, G, eps, act, drop_p, seed, seed_dev, ws, stream);
   if (rc) return rc;
   rc = stk_gn_bound_f32(gamma, beta, C, G, HW, drop_p, rec, stream);

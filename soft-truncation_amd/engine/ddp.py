@@ -144,9 +144,21 @@ def arm_overlap(model, bucket_mb=None):
   return x
 
 
-def disarm_overlap(model):
-  """Drop whatever :func:`arm_overlap` left armed for `model` (a step that raised before ``sync_gradients``): the
-  executor's hook is cleared and outstanding handles are waited for, so the next step starts clean."""
+def begin_step(model):
+  """Start of a training step: evaluations of EARLIER steps that never ran a backward (a grad-mode output the caller kept
+  and did not differentiate) no longer count as pending -- otherwise a single forgotten output would silently turn every
+  later step's overlapped exchange into a plain post-backward all-reduce (engine/executor.py `_awaiting`)."""
+  net = getattr(model, 'module', model)
+  engine = getattr(net, 'engine', None)
+  if engine is not None:
+    engine()._awaiting.clear()
+
+
+def disarm_overlap(model, wait=True):
+  """Drop whatever :func:`arm_overlap` left armed for `model`: the executor's hook is cleared and outstanding handles are
+  waited for, so the next step starts clean.  `wait=False` (a step that RAISED on this rank): the handles are dropped
+  without waiting -- the peers may never issue the matching collective, and a wait here would hang the process and hide
+  the exception that is about to surface."""
   net = getattr(model, 'module', model)
   engine = getattr(net, 'engine', None)
   if engine is None:
@@ -155,8 +167,9 @@ def disarm_overlap(model):
   ex.grad_hook = None
   x = _armed.pop(id(ex.flat), None) if ex.flat is not None else None
   if x is not None:
-    for h in x.handles:
-      h.wait()
+    if wait:
+      for h in x.handles:
+        h.wait()
     x.handles, x.covered = [], []
 
 

@@ -144,6 +144,9 @@ class _ScoreMatching(torch.autograd.Function):
     return dnet, None, None, None, None, None, None
 
 
+_fused_bufs = {}
+
+
 def _engine_lib(model, batch):
   """The kernel library of a score network that runs on the engine, when `batch` lives where that library computes."""
   net = getattr(model, 'module', model)
@@ -190,7 +193,11 @@ def get_sde_loss_fn(config, sde, train, variance='scoreflow'):
     from .engine import lib as stk_lib
     B = batch.shape[0]
     z = torch.randn_like(batch)
-    ones = torch.ones((B, 1, 1, 1), dtype=batch.dtype, device=batch.device)
+    key = (B, batch.dtype, batch.device)
+    bufs = _fused_bufs.get(key)
+    if bufs is None:       # per batch size: the [B,1,1,1] ones the coefficients are read off (never written again)
+      bufs = _fused_bufs[key] = torch.ones((B, 1, 1, 1), dtype=batch.dtype, device=batch.device)
+    ones = bufs
     coeff, std = sde.marginal_prob(ones, t)                    # mean = coeff * x: [B,1,1,1] coefficients, [B] std
     std = std.to(torch.float32).contiguous()
     x = batch.contiguous()
@@ -200,7 +207,11 @@ def get_sde_loss_fn(config, sde, train, variance='scoreflow'):
       lib.perturb_f32(x.data_ptr(), z.data_ptr(), a.data_ptr() if a is not None else None, std.data_ptr(), xt.data_ptr(),
                       B, x[0].numel(), stk_lib.stream_ptr(x.device))
     net = raw_fn(xt, t)
-    wgt = (0.5 * Z) * torch.ones(B, dtype=torch.float32, device=x.device)
+    if torch.is_tensor(Z) and Z.device.type != 'cpu':
+      wgt = (0.5 * Z) * torch.ones(B, dtype=torch.float32, device=x.device)
+    else:                  # a host scalar (the normalising constant of the importance-sampled times): a fill, no host-to-device
+      # copy.  (A fresh tensor per evaluation: the autograd node keeps it, and `training.mixed` holds two evaluations at once.)
+      wgt = torch.full((B,), 0.5 * float(Z), dtype=torch.float32, device=x.device)
     return _ScoreMatching.apply(net, z, std, wgt, lib, neg_over_std, bool(tr.reduce_mean))
 
   def loss_fn(model, batch, importance_sampling, t_min=None):
@@ -317,6 +328,7 @@ def get_step_fn(config, sde, train, optimize_fn=None):
     losses_ = torch.zeros(n // 2 if mixed else n)
     t_min = sde.get_t_min(config)
     pinned, copied = None, None
+    ddp.begin_step(model)
     try:
       for k in range(parts):
         losses = micro_losses(model, batch[per * k: per * (k + 1)], t_min)
@@ -342,8 +354,10 @@ def get_step_fn(config, sde, train, optimize_fn=None):
           torch.mean(losses).backward(retain_graph=True)
           losses_[out_per * k: out_per * (k + 1)] = losses.cpu().detach()
       optimize_fn(optimizer, model.parameters(), step=state['step'])
-    finally:
-      ddp.disarm_overlap(model)      # no-op after optimize_fn; a step that raised must not leave its hook armed
+    except BaseException:
+      ddp.disarm_overlap(model, wait=False)      # a step that raised must not leave its hook armed -- nor wait for its peers
+      raise
+    ddp.disarm_overlap(model)        # no-op after optimize_fn
     state['step'] += 1
     state['ema'].update(model.parameters())
     if pinned is not None:

@@ -483,12 +483,32 @@ class _MfmaNeighbour:
                                 s.cuda_stream)
 
 
-def two_streams_deterministic(st, lib, B=96, delays=(150000, 600000, 2000000), neighbour_runs=300):
+class _CopyNeighbour:
+  """What a gradient exchange puts beside the backward on a multi-GPU run, as far as one GPU can show it: a stream of its own
+  that moves 64 MB blocks (the bucket size of engine/ddp.py) through HBM -- reduce-copy kernels of a ring step read two
+  buffers and write one -- while the backward runs."""
+
+  def __init__(self, dev, mb=64):
+    n = mb * 2 ** 20 // 4
+    self.a = torch.randn(n, device=dev)
+    self.b = torch.randn(n, device=dev)
+    self.c = torch.empty(n, device=dev)
+    self.stream = torch.cuda.Stream(dev)
+
+  def launch(self, calls=24):
+    with torch.cuda.stream(self.stream):
+      for _ in range(calls):
+        torch.add(self.a, self.b, out=self.c)
+
+
+def two_streams_deterministic(st, lib, B=96, delays=(150000, 600000, 2000000), neighbour_runs=300, copy_runs=100):
   """The backward with its weight gradients / shortcut convolutions on the side stream (engine/executor.SideStream) must
   give the gradients of a quiet one-stream backward BIT FOR BIT, whatever else is resident on the chip:
     * every side launch site in turn held back by a spin kernel (torch.cuda._sleep) of three lengths, with and without
     * a neighbour stream that issues MFMAs into accumulation registers throughout the backward (_MfmaNeighbour), which
-      also runs beside the plain two-stream and the ONE-stream backward `neighbour_runs` times each.
+      also runs beside the plain two-stream and the ONE-stream backward `neighbour_runs` times each;
+    * a neighbour stream that streams 64 MB blocks through HBM like the reduce-copy kernels of a gradient exchange
+      (_CopyNeighbour), `copy_runs` times beside each of the two backward modes.
   Watch on the packed-fp32 hazard (csrc/Makefile HAZARD_FLAGS, profiles/r04_pk_hazard.txt): a build with the SLP vectoriser
   on fails every one of these runs (tools/_probe/side_race2.py: 168 of 168)."""
   from importlib import import_module
@@ -502,8 +522,19 @@ def two_streams_deterministic(st, lib, B=96, delays=(150000, 600000, 2000000), n
   go = torch.randn(B, *x.shape[1:], generator=torch.Generator().manual_seed(5)).to(dev)
   model.eval()
   nb = _MfmaNeighbour(lib, dev)
+  cp = _CopyNeighbour(dev)
 
   def run(side, neighbour=False):
+    if neighbour == 'copy':
+      ex.use_side = side
+      model.zero_grad()
+      xg = x.clone().to(dev).requires_grad_(True)
+      y = model(xg, cond.to(dev))
+      cp.launch()
+      (y * go).sum().backward()
+      busy = not cp.stream.query()
+      torch.cuda.synchronize()
+      return [p.grad.detach().clone() for p in model.parameters()] + [xg.grad.clone()], busy
     ex.use_side = side
     model.zero_grad()
     xg = x.clone().to(dev).requires_grad_(True)
@@ -540,12 +571,48 @@ def two_streams_deterministic(st, lib, B=96, delays=(150000, 600000, 2000000), n
     for side in (True, False):
       for _ in range(neighbour_runs):
         check(run(side, True))
+      for _ in range(copy_runs):
+        check(run(side, 'copy'))
     assert bad == 0, f'{bad} of {runs} backward passes differ from the quiet one-stream result'
     assert beside >= neighbour_runs, f'the neighbour kernels ended too early to be resident beside the backward ({beside} of {runs})'
   finally:
     G._SIDE_DELAY, G._SIDE_DELAY_FILTER = saved
     ex.use_side = True
   return runs
+
+
+def score_matching_pieces(st, lib):
+  """losses._ScoreMatching on samples larger than its PIECE (3 x 128 x 128 = 49152 elements: cut into pieces that the kernel
+  sees as samples of their own and that are summed afterwards, so the summation order differs from torch.mean / torch.sum):
+  forward and backward against the torch expressions of losses.py:122-132, reduce_mean on and off, VP (score = -net / std)
+  and VE (score = net) forms."""
+  dev = torch.device('cuda:0') if lib.is_device else torch.device('cpu')
+  g = torch.Generator().manual_seed(9)
+  B, shape = 5, (3, 128, 128)
+  inner = 3 * 128 * 128
+  SM = st.losses._ScoreMatching
+  assert SM._pieces(B, inner) > 1, 'the case must exercise the piece-split branch'
+  out = {}
+  for vp in (True, False):
+    for reduce_mean in (True, False):
+      net = torch.randn(B, *shape, generator=g).to(dev).requires_grad_(True)
+      z = torch.randn(B, *shape, generator=g).to(dev)
+      std = (torch.rand(B, generator=g) * 3 + 0.05).to(dev)
+      wgt = (torch.rand(B, generator=g) + 0.5).to(dev)
+      go = torch.randn(B, generator=g).to(dev)
+      losses = SM.apply(net, z, std, wgt, lib, vp, reduce_mean)
+      (losses * go).sum().backward()
+      netr = net.detach().clone().requires_grad_(True)
+      s4 = std[:, None, None, None]
+      score = -netr / s4 if vp else netr
+      r2 = torch.square(score * s4 + z).reshape(B, -1)
+      want = wgt * (torch.mean(r2, dim=-1) if reduce_mean else 0.5 * torch.sum(r2, dim=-1))
+      (want * go).sum().backward()
+      e_l = float(((losses.detach() - want.detach()).abs() / want.detach().abs()).max())
+      e_g = float((net.grad - netr.grad).abs().max() / netr.grad.abs().max())
+      out[(vp, reduce_mean)] = (e_l, e_g)
+      assert e_l <= 2e-6 and e_g <= 1e-5, (vp, reduce_mean, e_l, e_g)
+  return out
 
 
 def fused_loss_matches_torch(st, lib, family):

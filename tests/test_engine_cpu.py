@@ -29,6 +29,10 @@ def test_loss_curve_on_the_checker(st, ref_lib):
   print(out)
 
 
+def test_score_matching_loss_on_large_samples(st, ref_lib):
+  cases.score_matching_pieces(st, ref_lib)
+
+
 def test_train_steps_micro_batches(st, ref_lib):
   cases.train_steps(st, ref_lib, 'vp', steps=2, num_micro_batch=2)
 

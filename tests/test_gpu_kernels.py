@@ -567,10 +567,11 @@ def per_image_error(got, ref):
 def test_conv_split_per_image_accuracy(ref_lib, hip_lib):
   """Where the split kernels stop being fp32 PER SAMPLE.  One power-of-two scale per operand TENSOR puts the batch maximum at
   [2^13, 2^14); an image whose magnitude is rho times the maximum keeps its fp16 hi term (11 bits) and a lo term that goes
-  subnormal (absolute precision 2^-24 in scaled units) once rho < ~2^-16: its own relative error is then ~ 2^-38.5 / rho --
-  3e-7 at 1e-5 of the maximum (the 4-5 decades the per-sample loss weights g^2 / sigma spread dy over in the VE configs),
-  3e-6 at 1e-6, 3e-4 at 1e-8, 3e-3 at 1e-9.  Asserted per image for forward and data gradient over NINE decades:
-  error <= max(3e-6, 8 * 2^-38.5 / rho); the images above 1e-6 of the maximum therefore hold fp32-level 3e-6."""
+  subnormal (absolute precision 2^-24 in scaled units) once rho < ~2^-16: its own relative error then grows like 1 / rho.
+  Measured on MI355X (forward; the data gradient is the same): 2e-7 down to 1e-4 of the maximum, 9e-7 at 1e-5 (the 4-5
+  decades the per-sample loss weights g^2 / sigma spread dy over in the VE configs), 8e-6 at 1e-6, 8e-5 at 1e-7, 9e-4 at
+  1e-8, 9e-3 at 1e-9 -- i.e. ~ 2^-36.8 / rho.  Asserted per image for forward and data gradient over NINE decades:
+  error <= max(3e-6, 8 * 2^-38.5 / rho), and fp32-level (1.5e-6) for every image within five decades of the maximum."""
   N, C, H, decades = 28, 128, 16, 9.0
   rho = 10.0 ** (-decades * torch.arange(N).double() / (N - 1))
   ramp = rho.float().view(N, 1, 1, 1)
@@ -596,7 +597,7 @@ def test_conv_split_per_image_accuracy(ref_lib, hip_lib):
     e = per_image_error(got[k], ref[k])
     print(k, 'per-image error by decade:', [f'{rho[i].item():.0e}: {e[i].item():.1e}' for i in range(0, N, 3)])
     assert (e <= bound).all(), f'{k}: per-image errors {e.tolist()} exceed {bound.tolist()}'
-    assert e[rho >= 1e-6].max().item() <= 3e-6
+    assert e[rho >= 0.99e-5].max().item() <= 1.5e-6
 
 
 THIN_FULL = [

@@ -167,6 +167,11 @@ def test_fused_loss_path(st, hip_lib, family):
   print('fused loss path:', cases.fused_loss_matches_torch(st, hip_lib, family))
 
 
+def test_score_matching_loss_on_large_samples(st, hip_lib):
+  """stk_sm_loss forward / backward with samples cut into pieces (inner > PIECE) against the torch expressions."""
+  print('score matching, piece-split samples:', cases.score_matching_pieces(st, hip_lib))
+
+
 def test_two_streams_are_deterministic(st, hip_lib):
   """Weight gradients on the side stream: bit-identical to the quiet one-stream backward under timing perturbations and beside
   a neighbour stream issuing MFMAs (the trigger of the gfx950 packed-fp32 hazard), > 700 backward passes."""
