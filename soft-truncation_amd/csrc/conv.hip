@@ -698,6 +698,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// The same sum for 3x3 layers in the weight's own layout (w_layout 0), with COALESCED read-modify-writes of dw (round 4).
+// The kernel above reads the slabs in 16-byte runs but scatters its dw updates with a stride of nine floats: a wave touches
+// 72 cache lines for 256 values, nine times over per line.  Here a workgroup owns 256 consecutive (co, ci) pairs: thread t sums
+// its pair's nine taps over the splits (4-byte loads, contiguous over the workgroup: 1 KB per tap and slab), the 2304 sums
+// meet in LDS in dw order, and the update of dw is nine fully coalesced 1 KB read-modify-writes.  Same summation order per
+// element (z ascending): bit-identical results.
+__global__ __launch_bounds__(256) void splitk_reduce9_kernel(const float* __restrict__ part, float* __restrict__ dw, long CC,
+                                                             int splits, long stride, float alpha) {
+  __shared__ float s[256 * 9];
+  const long q0 = (long)blockIdx.x * 256;
+  const long q = q0 + threadIdx.x;
+  const bool live = q < CC;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  const float* src = part + (live ? q : 0);
+  int z = 0;
+  for (; z + 4 <= splits; z += 4) {          // 36 independent loads in flight, added in z order
+    float v[4][9];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[u][t] = src[(long)(z + u) * stride + (long)t * CC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] += v[u][t];
+  }
+  for (; z < splits; ++z)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] += src[(long)z * stride + (long)t * CC];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[threadIdx.x * 9 + t] = alpha * acc[t];
+  __syncthreads();
+  const long base = q0 * 9, end = CC * 9;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const long i = base + k * 256 + threadIdx.x;
+    if (i < end) dw[i] += s[k * 256 + threadIdx.x];
+  }
+}
+inline bool reduce9_on() { static const bool v = [] { const char* e = getenv("STK_REDUCE9"); return !e || atoi(e) != 0; }(); return v; }
+
 // ---- 3x3 / stride-1 / pad-1 weight gradient: all nine taps per workgroup ------------------------------------
 // The per-tap GEMM above re-reads dy and x once per tap and per tile and is bound by L2/Infinity-Cache
 // bandwidth (measured ~70 TFLOP/s).  Here one workgroup owns a 128(co) x 32(ci) x 9(taps) block of dw:
@@ -956,7 +999,9 @@ inline X3Plan x3_plan(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
   // 6 splits 23.8; 512 -> 256 at 8x8: 73.9 -> 71.9; the 8x8 256 -> 256 layers keep their 4 splits either way)
   static const long minch = [] { const char* e = getenv("STK_KSPLIT_MINCH"); return e && atol(e) > 0 ? atol(e) : 12L; }();
   long splits = target / tiles;
-  if (splits > nch / minch) splits = nch / minch;    // few chunks per workgroup: the prologue and the slab traffic dominate
+  // few chunks per workgroup: the prologue and the slab traffic dominate (1x1 layers have Kc / 32 chunks in all: they keep 6)
+  const long mc = p.taps == 9 ? minch : (minch < 6 ? minch : 6);
+  if (splits > nch / mc) splits = nch / mc;
   // few tiles: the 3x3 layers still pay (4 tiles of a 256-channel 8x8 map at batch 4: 94 us on 16 workgroups of the
   // f32-input kernel); a 1x1 layer has too few chunks to split
   if ((tiles < 16 && p.taps != 9) || splits < 2) return r;
@@ -1499,13 +1544,24 @@ int stk_conv2d_wgrad_pl_f32(const void* xpl, const float* xrec, const void* dypl
   a.nchunks_total = (int)((long)N * H * W / 32); a.chunks_per_split = q.chunks_per_split;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)(a.tiles_co * a.tiles_ci * q.splits));
-  if (W >= 32) hipLaunchKernelGGL((x2w::wgrad_kernel<32>), grid, dim3(256), 0, s, a);
+  if (q.groups == 2) {
+    if (W >= 32) hipLaunchKernelGGL((x2w::wgrad_kernel<32, 2>), grid, dim3(512), 0, s, a);
+    else if (W == 16) hipLaunchKernelGGL((x2w::wgrad_kernel<16, 2>), grid, dim3(512), 0, s, a);
+    else if (W == 8) hipLaunchKernelGGL((x2w::wgrad_kernel<8, 2>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((x2w::wgrad_kernel<4, 2>), grid, dim3(512), 0, s, a);
+  } else if (W >= 32) hipLaunchKernelGGL((x2w::wgrad_kernel<32>), grid, dim3(256), 0, s, a);
   else if (W == 16) hipLaunchKernelGGL((x2w::wgrad_kernel<16>), grid, dim3(256), 0, s, a);
   else if (W == 8) hipLaunchKernelGGL((x2w::wgrad_kernel<8>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((x2w::wgrad_kernel<4>), grid, dim3(256), 0, s, a);
   STK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((q.slab + 3) / 4)), dim3(256), 0, s, ws, dw, q.slab, q.splits,
-                     q.slab, alpha, 0, Cout, Cin, 9);
+  // measured (tools/bench_x2d.py, kernel + reduce, us, old -> new): 32 slabs 118.5 -> 117.0 / 55.1 -> 51.1, 64: 74.4 -> 72.3, 16: 206.0 ->
+  // 201.8, 8: 44.8 -> 39.7, but 128 slabs 124.1 -> 130.8 (1152 four-byte loads per thread): the coalesced form up to 64 slabs
+  if (reduce9_on() && q.splits <= 64)
+    hipLaunchKernelGGL(splitk_reduce9_kernel, dim3((unsigned)stk_cdiv((long)Cout * Cin, 256L)), dim3(256), 0, s, ws, dw, (long)Cout * Cin,
+                       q.splits, q.slab, alpha);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((q.slab + 3) / 4)), dim3(256), 0, s, ws, dw, q.slab, q.splits,
+                       q.slab, alpha, 0, Cout, Cin, 9);
   STK_CHECK_LAUNCH();
   return STK_OK;
 }

@@ -41,6 +41,16 @@ struct Args {
   int tiles_co, tiles_ci, nchunks_total, chunks_per_split;
 };
 
+// maximum of the x2::NPART (= 256) partial maxima of a scale record, by the 256 threads of one group (`red`: that group's LDS)
+__device__ __forceinline__ float group_amax(const float* __restrict__ part, int tid, float* red) {
+  float m = wave_max(part[tid]);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return m;
+}
+
 __device__ __forceinline__ halfx8 cat(s4 lo, s4 hi) {
   typedef short s8 __attribute__((__vector_size__(16)));
   const s8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -49,16 +59,26 @@ __device__ __forceinline__ halfx8 cat(s4 lo, s4 hi) {
 
 // COLS = min(W, 32): pixels of a chunk per map row (a chunk is 32 consecutive pixels = 32 / COLS whole rows, or a
 // 32-pixel piece of one row when W > 32)
-template <int COLS>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(Args a) {
+// GROUPS = 2 (round 4): a workgroup of EIGHT waves, two groups of four that own the SAME 128 x 32 x 9 block and take the
+// split's chunks alternately, each with its own pair of LDS buffers; after the last chunk group 1 hands its 144 accumulators
+// per thread to group 0 through the (now free) LDS in three rounds of three taps, and group 0 writes the slab.  One such
+// workgroup per CU holds the same eight waves as two four-wave ones did, but the K split -- and with it the slab traffic
+// (every split writes, and the reduce reads, 9 Cout Cin floats: 75 MB per launch on the 128 -> 128 layers at batch 128 for
+// a 0.6 MB result) -- is half as deep.  The sum of the two groups is taken in a fixed order (group 0 + group 1).
+template <int COLS, int GROUPS = 1>
+__global__ __launch_bounds__(256 * GROUPS, 2) void wgrad_kernel(Args a) {
   // COLS = 4 (4 x 4 maps): a chunk is TWO whole images, each with its own 6 x 6 halo tile (slot = 36 img + 6 ty + tx)
   constexpr bool TWO = COLS == 4;
   constexpr int ROWS = 32 / COLS, TP = COLS + 2, TR = TWO ? 12 : ROWS + 2;
   static_assert(TR * TP <= B_INSTR * 16, "halo tile exceeds the staged slots");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS];
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float sa = x2::pow2_scale_of(x2::block_amax(a.dyrec, x2::NPART, reinterpret_cast<float*>(lds)));
-  const float sb = x2::pow2_scale_of(x2::block_amax(a.xrec, x2::NPART, reinterpret_cast<float*>(lds)));
+  __shared__ __attribute__((aligned(1024))) unsigned char lds_all[LDS * GROUPS];
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int grp = GROUPS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* const lds = lds_all + grp * LDS;               // this group's two buffers
+  // (every group reduces the 256 partial maxima for itself, in its own LDS: the barriers inside are workgroup-wide)
+  const float sa = x2::pow2_scale_of(group_amax(a.dyrec, tid, reinterpret_cast<float*>(lds)));
+  const float sb = x2::pow2_scale_of(group_amax(a.xrec, tid, reinterpret_cast<float*>(lds)));
   const float unscale = 1.f / (sa * sb);
   const int ntiles = a.tiles_co * a.tiles_ci;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -165,14 +185,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(Args a) {
     }
   };
 
-  stage(c_begin, lds);
+  // group g takes chunks c_begin + g, c_begin + g + GROUPS, ...; both groups run the same number of barrier rounds
+  const int rounds = (c_last - c_begin + GROUPS) / GROUPS;
+  if (c_begin + grp <= c_last) stage(c_begin + grp, lds);
   int cur = 0;
-  for (int c = c_begin; c <= c_last; ++c) {
+  for (int it = 0; it < rounds; ++it) {
+    const int c = c_begin + it * GROUPS + grp;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of chunk c has landed ...
     __syncthreads();                                   // ... everybody's has, and nobody reads the other buffer any more
-    if (c < c_last) stage(c + 1, lds + (cur ^ 1) * BUF);
-    compute(lds + cur * BUF);
+    if (c + GROUPS <= c_last) stage(c + GROUPS, lds + (cur ^ 1) * BUF);
+    if (c <= c_last) compute(lds + cur * BUF);
     cur ^= 1;
+  }
+  if (GROUPS == 2) {
+    // group 1 -> group 0, three taps (48 floats per thread, 48 KB) per round through group 0's buffers; element (t, e) of
+    // thread tid at float (16 t + e) 256 + tid: conflict-free for writer and reader
+    float* const xch = reinterpret_cast<float*>(lds_all);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      __syncthreads();                                 // the tiles (r = 0) / the previous round's values have been consumed
+      if (grp == 1) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) xch[(16 * t + e) * 256 + tid] = acc[3 * r + t][e];
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[3 * r + t][e] += xch[(16 * t + e) * 256 + tid];
+      }
+    }
+    if (grp == 1) return;
   }
 
   // partial slab of split zs as [tap][Cout][Cin] (lanes = ci, contiguous); splitk_reduce_kernel re-lays it out
@@ -192,9 +238,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(Args a) {
 
 // H = W a power of two >= 8 (a chunk of 32 pixels is whole rows or a piece of one row, never across images) or H = W = 4
 // (a chunk is two whole images), channel counts in whole 32-blocks (planes), enough work to fill the chip
-struct Plan { int ok; int splits; int chunks_per_split; long slab; };
+struct Plan { int ok; int splits; int chunks_per_split; long slab; int groups; };
+inline int groups_mode() { static const int v = [] { const char* e = getenv("STK_X2W_GROUPS"); return e ? atoi(e) : 2; }(); return v; }
 inline Plan plan(int N, int H, int W, int Cin, int Cout) {
-  Plan r = {0, 1, 0, 0};
+  Plan r = {0, 1, 0, 0, 1};
   if (H != W || W < 4 || (W & (W - 1)) || Cin % 32 || Cout % 32 || Cin < 32 || Cout < 32) return r;
   const long px = (long)N * H * W;
   if (px % 32 || px / 32 > 0x7fffffffL / 64) return r;
@@ -210,6 +257,13 @@ inline Plan plan(int N, int H, int W, int Cin, int Cout) {
   const long cap = (cap_mb << 20) / (9L * Cout * Cin * 4);
   if (splits > cap) splits = cap;
   if (splits < 1) splits = 1;
+  // two groups of four waves per workgroup (wgrad_kernel<COLS, 2>): half the splits, the same eight waves per CU, when every
+  // group still gets >= 8 chunks (STK_X2W_GROUPS=1: off, 3: every map width).  Measured, kernel + reduce, batch 128, us, one
+  // group -> two (profiles/r04_x2w_groups.txt): 16 x 16: 115.9 -> 113.1, 203.8 -> 199.3, 73.7 -> 68.0; 8 x 8: 52.1 -> 47.8, 71.7 ->
+  // 68.6; but 32 x 32: 122.8 -> 126.4, 317.9 -> 339.0 (eight waves in barrier lockstep) and 4 x 4: 32.8 -> 35.5: the 8- and
+  // 16-wide maps only.
+  const bool gw = groups_mode() == 3 || (groups_mode() == 2 && (W == 8 || W == 16));
+  if (gw && splits >= 2 && splits % 2 == 0 && nch / splits >= 8) { r.groups = 2; splits /= 2; }
   r.chunks_per_split = stk_cdiv(nch, splits);
   r.splits = stk_cdiv(nch, r.chunks_per_split);
   r.slab = 9L * Cout * Cin;

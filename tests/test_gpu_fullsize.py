@@ -9,6 +9,19 @@ import _fullsize_cases as full
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _release_device_memory():
+  """Every case here builds a full-size engine (tens of GB of arenas at batch 128): drop it before the next one starts --
+  without this the 64x64 batch-128 case and the 256x256 case only fit together when the garbage collector happened to run."""
+  yield
+  import gc
+  import torch
+  gc.collect()
+  if torch.cuda.is_available():
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
 def test_baseline_config0_ddpmpp_cifar10(st, hip_lib):
   out = full.baseline_config0(st, hip_lib)
   print('configs[0] parity:', {k: (f'{v:.2e}' if isinstance(v, float) else v) for k, v in out.items()})
