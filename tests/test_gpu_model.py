@@ -38,10 +38,11 @@ def test_train_steps_mixed(st, hip_lib):
   cases.train_steps(st, hip_lib, 'vp', steps=2, mixed=True)
 
 
-@pytest.mark.parametrize('family', ['vp', 've'])
-def test_loss_curve_100_steps(st, hip_lib, family):
-  """A 100-step training trajectory against RefNet + torch Adam: per-sample losses within 1e-3 at every step."""
-  print('loss curve:', cases.loss_curve(st, hip_lib, family))
+@pytest.mark.parametrize('family,steps', [('vp', 100), ('ve', 50)])
+def test_loss_curve_100_steps(st, hip_lib, family, steps):
+  """A 100-step (VP; VE: 50 -- its fixture net is the slow one on the host side) training trajectory against RefNet + torch
+  Adam: per-sample losses within 1e-3 at every step."""
+  print('loss curve:', cases.loss_curve(st, hip_lib, family, steps=steps))
 
 
 def test_dropout_consistency(st, hip_lib):
