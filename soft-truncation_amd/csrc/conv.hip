@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void slab_fwd_kernel(ConvP p, int splits, int 
     for (int u = 0; u < VEC; ++u) v[u] = 0.f;
     for (int z = 0; z < splits; ++z) {
       const float* q = p.part + (long)z * p.part_stride + i;
-      if (VEC == 4) {
+      if constexpr (VEC == 4) {
         const float4 t = *reinterpret_cast<const float4*>(q);
         v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
       } else {
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void slab_fwd_kernel(ConvP p, int splits, int 
 #pragma unroll
     for (int u = 0; u < VEC; ++u) r[u] = 0.f;
     if (p.res) {
-      if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p.res + idx); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
+      if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p.res + idx); r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w; }
       else r[0] = p.res[idx];
     }
 #pragma unroll
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void slab_fwd_kernel(ConvP p, int splits, int 
       if (p.use_div) w *= p.inv_div;
       v[u] = w;
     }
-    if (VEC == 4) *reinterpret_cast<float4*>(p.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(p.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
     else p.y[idx] = v[0];
   }
 }
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void slab_dgrad_kernel(ConvP p, int splits, in
     for (int u = 0; u < VEC; ++u) v[u] = 0.f;
     for (int z = 0; z < splits; ++z) {
       const float* q = p.part + (long)z * p.part_stride + i;
-      if (VEC == 4) {
+      if constexpr (VEC == 4) {
         const float4 t = *reinterpret_cast<const float4*>(q);
         v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
       } else {
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) void slab_dgrad_kernel(ConvP p, int splits, in
     if (m < p.C1) { d = p.dx1 ? p.dx1 + ((long)b * p.C1 + m) * p.HW + hw : nullptr; beta = p.beta1; }
     else { d = p.dx2 ? p.dx2 + ((long)b * p.C2 + (m - p.C1)) * p.HW + hw : nullptr; beta = p.beta2; }
     if (!d) continue;
-    if (VEC == 4) {
+    if constexpr (VEC == 4) {
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (beta != 0.f) { const float4 t = *reinterpret_cast<const float4*>(d); o = make_float4(beta * t.x, beta * t.y, beta * t.z, beta * t.w); }
       *reinterpret_cast<float4*>(d) = make_float4(o.x + p.alpha * v[0], o.y + p.alpha * v[1], o.z + p.alpha * v[2], o.w + p.alpha * v[3]);

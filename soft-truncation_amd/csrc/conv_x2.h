@@ -218,6 +218,10 @@ struct ActLoader {
   __device__ __forceinline__ void st(int g, unsigned char* t) { sp.st(g, r, scale, t, nl, kg * 16); }
 };
 
+// (Round 4, measured and dropped: a loader for the 1x1 layers that fetches 4 pixels x 4 channels per thread with 16-byte loads
+// instead of 16 four-byte ones -- what had made the per-tap weight gradient 30 % faster -- changes nothing here: 384 -> 128 at
+// 32 x 32 53.2 vs 52.3 us, 256 -> 256 data gradient 42.6 vs 41.3.  These kernels are not address-bound: a workgroup has 8-16
+// chunks in all, and the chunk time is the staging round trip of the fp32-operand pipeline, profiles/r04_experiments.txt.)
 // ---- the kernel: out tile 128 x 128, 4 waves of 64 x 64, chunks of 32 k; 12 MFMAs per 16-k step and wave -------------
 // Grid (XCD-remapped): one flat dimension of tiles x K-splits.  xpart: `nxpart` (256 / 512) partial |x| maxima.
 template <class BL, class EP, int WPS = 2>       // WPS: waves per SIMD the register allocation must admit
