@@ -368,12 +368,28 @@ int stk_attention_bwd_f32(const float* q, const float* k, const float* v, long q
 /* y = x*sigmoid(x);  dx = beta*dx + dy * sig(x)*(1 + x*(1-sig(x))) */
 int stk_silu_fwd_f32(const float* x, float* y, long n, void* stream);
 int stk_silu_bwd_f32(const float* x, const float* dy, float* dx, float beta, long n, void* stream);
+/* The activations of layers.get_act (models/layers.py:29-41), by the `act` code every GroupNorm entry of this header takes too:
+ *   STK_ACT_NONE 0 | STK_ACT_SILU 1 ('swish', nn.SiLU) | STK_ACT_RELU 2 (nn.ReLU) | STK_ACT_LRELU 3 (nn.LeakyReLU(0.2)) |
+ *   STK_ACT_ELU 4 (nn.ELU(), alpha 1).   y = act(x);  dx = beta*dx + dy * act'(x)  (ReLU / LeakyReLU: act'(0) = 0 / 0.2 as torch). */
+#define STK_ACT_NONE 0
+#define STK_ACT_SILU 1
+#define STK_ACT_RELU 2
+#define STK_ACT_LRELU 3
+#define STK_ACT_ELU 4
+int stk_act_fwd_f32(const float* x, float* y, long n, int act, void* stream);
+int stk_act_bwd_f32(const float* x, const float* dy, float* dx, float beta, long n, int act, void* stream);
 /* out = alpha*a + beta*b   (b may be NULL -> treated as 0; out may alias a or b).
  * Every `beta` of this header follows the same rule: beta == 0 means the accumulated operand is NOT READ (it may be
  * uninitialised memory), never multiplied by zero. */
 int stk_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out, long n, void* stream);
 /* out = (a + b) * (1.f/div)  -- the skip_rescale combine (x + h)/sqrt(2), models/layerspp.py:104,287 */
 int stk_add_div_f32(const float* a, const float* b, float div, float* out, long n, void* stream);
+/* FixedFouriereProjection (models/layerspp.py:31-43; config.model.fourier_feature):
+ *   y[n] = cat(x[n], sin(128 pi x[n]), cos(128 pi x[n]), sin(256 pi x[n]), cos(256 pi x[n])) along the channels: x [N, C, HW] ->
+ *   y [N, 5 C, HW]; the arguments are formed as torch forms them (fl(fl(128 x) * fl(pi))).
+ *   bwd: dx = beta*dx + dy0 + 128 pi (cos1 dy1 - sin1 dy2) + 256 pi (cos2 dy3 - sin2 dy4). */
+int stk_fixed_fourier_fwd_f32(const float* x, float* y, int N, int C, int HW, void* stream);
+int stk_fixed_fourier_bwd_f32(const float* x, const float* dy, float* dx, float beta, int N, int C, int HW, void* stream);
 /* out = a*x + b */
 int stk_affine_f32(const float* x, float a, float b, float* out, long n, void* stream);
 /* out[0..n) = v */

@@ -51,6 +51,46 @@ int launch_ew(long n, bool vec_ok, F f, hipStream_t s) {
 }
 
 // ---- functors -------------------------------------------------------------------------------
+// layers.get_act by code (include/stk.h STK_ACT_*); the code is uniform over a launch
+__device__ __forceinline__ float act_value(int act, float u) {
+  switch (act) {
+    case STK_ACT_SILU: return u / (1.f + expf(-u));
+    case STK_ACT_RELU: return u > 0.f ? u : 0.f;
+    case STK_ACT_LRELU: return u > 0.f ? u : 0.2f * u;
+    case STK_ACT_ELU: return u > 0.f ? u : expm1f(u);
+    default: return u;
+  }
+}
+__device__ __forceinline__ float act_slope(int act, float u) {
+  switch (act) {
+    case STK_ACT_SILU: { const float sg = 1.f / (1.f + expf(-u)); return sg * (1.f + u * (1.f - sg)); }
+    case STK_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case STK_ACT_LRELU: return u > 0.f ? 1.f : 0.2f;
+    case STK_ACT_ELU: return u > 0.f ? 1.f : expf(u);
+    default: return 1.f;
+  }
+}
+struct ActFwd {
+  const float* x; float* y; int act;
+  template <int V> __device__ void run(long i) const {
+    auto a = Vec<V>::load(x, i);
+#pragma unroll
+    for (int j = 0; j < V; ++j) a.v[j] = act_value(act, a.v[j]);
+    a.store(y, i);
+  }
+};
+struct ActBwd {
+  const float* x; const float* dy; float* dx; float beta; int act;
+  template <int V> __device__ void run(long i) const {
+    auto a = Vec<V>::load(x, i);
+    auto d = Vec<V>::load(dy, i);
+    Vec<V> o;
+    if (beta != 0.f) o = Vec<V>::load(dx, i);
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.v[j] = (beta != 0.f ? beta * o.v[j] : 0.f) + d.v[j] * act_slope(act, a.v[j]);
+    o.store(dx, i);
+  }
+};
 struct SiluFwd {
   const float* x; float* y;
   template <int V> __device__ void run(long i) const {
@@ -332,6 +372,18 @@ int stk_silu_bwd_f32(const float* x, const float* dy, float* dx, float beta, lon
   return launch_ew(n, stk_aligned16(x) && stk_aligned16(dy) && stk_aligned16(dx), SiluBwd{x, dy, dx, beta}, S(stream));
 }
 
+int stk_act_fwd_f32(const float* x, float* y, long n, int act, void* stream) {
+  if (!x || !y || n < 0 || act < 0 || act > STK_ACT_ELU) return STK_EINVAL;
+  if (act == STK_ACT_SILU) return stk_silu_fwd_f32(x, y, n, stream);
+  return launch_ew(n, stk_aligned16(x) && stk_aligned16(y), ActFwd{x, y, act}, S(stream));
+}
+
+int stk_act_bwd_f32(const float* x, const float* dy, float* dx, float beta, long n, int act, void* stream) {
+  if (!x || !dy || !dx || n < 0 || act < 0 || act > STK_ACT_ELU) return STK_EINVAL;
+  if (act == STK_ACT_SILU) return stk_silu_bwd_f32(x, dy, dx, beta, n, stream);
+  return launch_ew(n, stk_aligned16(x) && stk_aligned16(dy) && stk_aligned16(dx), ActBwd{x, dy, dx, beta, act}, S(stream));
+}
+
 int stk_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out, long n, void* stream) {
   if (!a || !out || n < 0) return STK_EINVAL;
   return launch_ew(n, stk_aligned16(a) && stk_aligned16(out) && (!b || stk_aligned16(b)),
@@ -342,6 +394,42 @@ int stk_add_div_f32(const float* a, const float* b, float div, float* out, long 
   if (!a || !b || !out || n < 0 || div == 0.f) return STK_EINVAL;
   return launch_ew(n, stk_aligned16(a) && stk_aligned16(b) && stk_aligned16(out),
                    AddDiv{a, b, 1.f / div, div != 1.f, out}, S(stream));
+}
+
+// FixedFouriereProjection (models/layerspp.py:31-43): one thread per input element, five outputs CHW apart
+__global__ __launch_bounds__(256) void fixed_fourier_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long total, long CHW) {
+  const float PI = 3.14159274101257324f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / CHW, r = i - n * CHW;
+    const float v = x[i], a1 = (v * 128.f) * PI, a2 = (v * 256.f) * PI;
+    float* o = y + n * 5 * CHW + r;
+    o[0] = v; o[CHW] = sinf(a1); o[2 * CHW] = cosf(a1); o[3 * CHW] = sinf(a2); o[4 * CHW] = cosf(a2);
+  }
+}
+__global__ __launch_bounds__(256) void fixed_fourier_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                                float beta, long total, long CHW) {
+  const float PI = 3.14159274101257324f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / CHW, r = i - n * CHW;
+    const float v = x[i], a1 = (v * 128.f) * PI, a2 = (v * 256.f) * PI;
+    const float* d = dy + n * 5 * CHW + r;
+    const float g = d[0] + (128.f * PI) * (cosf(a1) * d[CHW] - sinf(a1) * d[2 * CHW]) + (256.f * PI) * (cosf(a2) * d[3 * CHW] - sinf(a2) * d[4 * CHW]);
+    dx[i] = (beta != 0.f ? beta * dx[i] : 0.f) + g;
+  }
+}
+int stk_fixed_fourier_fwd_f32(const float* x, float* y, int N, int C, int HW, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return STK_EINVAL;
+  const long total = (long)N * C * HW;
+  hipLaunchKernelGGL(fixed_fourier_fwd_kernel, dim3((unsigned)stk_ew_grid(total)), dim3(256), 0, S(stream), x, y, total, (long)C * HW);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+int stk_fixed_fourier_bwd_f32(const float* x, const float* dy, float* dx, float beta, int N, int C, int HW, void* stream) {
+  if (!x || !dy || !dx || N <= 0 || C <= 0 || HW <= 0) return STK_EINVAL;
+  const long total = (long)N * C * HW;
+  hipLaunchKernelGGL(fixed_fourier_bwd_kernel, dim3((unsigned)stk_ew_grid(total)), dim3(256), 0, S(stream), x, dy, dx, beta, total, (long)C * HW);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
 }
 
 int stk_affine_f32(const float* x, float a, float b, float* out, long n, void* stream) {

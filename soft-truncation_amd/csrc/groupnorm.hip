@@ -109,6 +109,24 @@ __device__ __forceinline__ float sigmoid_f(float u) {
 #endif
 }
 
+// The activation behind the normalisation, by the `act` code of include/stk.h (layers.get_act, models/layers.py:29-41).  SiLU -- the
+// only one the shipped configs use -- keeps its hand-tuned form and its place first in the (launch-uniform) branch.
+__device__ __forceinline__ float act_f(int act, float u) {
+  if (act == STK_ACT_SILU) return silu_f(u);
+  if (act == STK_ACT_RELU) return u > 0.f ? u : 0.f;
+  if (act == STK_ACT_LRELU) return u > 0.f ? u : 0.2f * u;
+  if (act == STK_ACT_ELU) return u > 0.f ? u : expm1f(u);
+  return u;
+}
+// d act(u) / du
+__device__ __forceinline__ float act_slope_f(int act, float u) {
+  if (act == STK_ACT_SILU) { const float sg = sigmoid_f(u); return sg * (1.f + u * (1.f - sg)); }
+  if (act == STK_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+  if (act == STK_ACT_LRELU) return u > 0.f ? 1.f : 0.2f;
+  if (act == STK_ACT_ELU) return u > 0.f ? 1.f : expf(u);
+  return 1.f;
+}
+
 // ---- forward ------------------------------------------------------------------------------------
 // Register-resident forward for groups of up to 16384 elements (every group of the 32x32 / 64x64 networks): a thread
 // keeps its <= 4 float4 of the group, so the group is read ONCE (the looping kernel below reads it for the statistics
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(1024) void gn_fwd_flat_kernel(GnArgs a, float* __re
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float u = ga * ((r[j] - mean) * rstd) + be;
-      float t = a.act ? silu_f(u) : u;
+      float t = a.act ? act_f(a.act, u) : u;
       if (a.drop_p > 0.f) t = stk_drop_field(stk_mix64(seed, (flat0 + (unsigned long long)(i * 4)) >> 2), j) >= a.drop_thr ? t * a.keep_scale : 0.f;
       r[j] = t;
     }
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs a, float* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float u = ga * ((r[j] - mean) * rstd) + be;
-          float t = a.act ? silu_f(u) : u;
+          float t = a.act ? act_f(a.act, u) : u;
           if (a.drop_p > 0.f) t = stk_drop_field(stk_mix64(seed, (flat0 + (unsigned long long)(i * 4)) >> 2), j) >= a.drop_thr ? t * a.keep_scale : 0.f;
           r[j] = t;
         }
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs a, float* __restrict
       for (int i = threadIdx.x; i < len; i += 256) {
         const int c = seg[q].c_first + i / a.HW;
         float u = a.gamma[c] * ((p[i] - mean) * rstd) + a.beta[c];
-        float t = a.act ? silu_f(u) : u;
+        float t = a.act ? act_f(a.act, u) : u;
         if (a.drop_p > 0.f) t = stk_keep(seed, flat0 + (unsigned long long)i, a.drop_thr) ? t * a.keep_scale : 0.f;
         o[i] = t;
       }
@@ -264,8 +282,7 @@ __device__ __forceinline__ float gn_du(const GnArgs& a, float xv, float dyv, flo
   if (a.drop_p > 0.f) go = stk_keep(seed, flat, a.drop_thr) ? go * a.keep_scale : 0.f;
   if (a.act) {
     const float u = ga * xhat + be;
-    const float sg = sigmoid_f(u);
-    go = go * (sg * (1.f + u * (1.f - sg)));
+    go = go * act_slope_f(a.act, u);
   }
   return go;
 }
@@ -535,7 +552,7 @@ __global__ __launch_bounds__(256) void gn_split_fwd_kernel(GnArgs a, const float
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float u = ga * ((r[j] - mean) * rstd) + be;
-      float t = a.act ? silu_f(u) : u;
+      float t = a.act ? act_f(a.act, u) : u;
       if (a.drop_p > 0.f) t = stk_drop_field(stk_mix64(seed, (flat0 + (unsigned long long)(e * 4)) >> 2), j) >= a.drop_thr ? t * a.keep_scale : 0.f;
       r[j] = t;
     }
@@ -840,7 +857,7 @@ __global__ __launch_bounds__(1024) void gn_fwd_pl_kernel(GnArgs a, float* __rest
     for (int j = 0; j < 8; ++j) {
       const float mean = j < 4 ? m_lo : m_hi, rstd = j < 4 ? r_lo : r_hi;
       const float u = ga[j] * ((v[k][j] - mean) * rstd) + be8[j];
-      float r = a.act ? silu_f(u) : u;
+      float r = a.act ? act_f(a.act, u) : u;
       if (a.drop_p > 0.f) r = ((keep >> j) & 1u) ? r * a.keep_scale : 0.f;
       t[j] = r;
       if (yo) yo[(long)(8 * q + j) * a.HW + px] = r;
@@ -968,7 +985,7 @@ __global__ __launch_bounds__(256) void gn_apply_pl_kernel(GnArgs a, const float*
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float u = ga * ((r[j] - mean) * rstd) + be;
-      float o = a.act ? silu_f(u) : u;
+      float o = a.act ? act_f(a.act, u) : u;
       if (a.drop_p > 0.f) o = stk_drop_field(z, j) >= a.drop_thr ? o * a.keep_scale : 0.f;
       r[j] = o;
     }
@@ -1043,7 +1060,7 @@ int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float
                    unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream) {
   const int C = C1 + C2;
   if (!x1 || !gamma || !beta || !y || !mean || !rstd || N <= 0 || HW <= 0 || G <= 0 || C1 <= 0 || C2 < 0 || C % G ||
-      (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f)
+      (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f || act < 0 || act > STK_ACT_ELU)
     return STK_EINVAL;
   GnArgs a;
   a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
@@ -1111,7 +1128,7 @@ static int gn_fwd_pl_impl(const float* x1, int C1, const float* x2, int C2, cons
                           float* xmax1, float* xmax2) {
   const int C = C1 + C2;
   if (!x1 || !gamma || !beta || !planes || !rec || !mean || !rstd || N <= 0 || HW <= 0 || G <= 0 || C1 <= 0 || C2 < 0 ||
-      C % G || (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f)
+      C % G || (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f || act < 0 || act > STK_ACT_ELU)
     return STK_EINVAL;
   const long plane_stride = (long)N * ((C + 31) / 32) * HW * 64;
   if (2 * plane_stride >= 0x7fffffffL) return STK_EUNSUPPORTED;
@@ -1213,7 +1230,7 @@ static int gn_bwd_impl(const float* dy, const float* x1, int C1, const float* x2
                        unsigned long long seed, const unsigned long long* seed_dev, void* stream, GnBwdOut out) {
   const int C = C1 + C2;
   if (!dy || !x1 || !gamma || !beta || !mean || !rstd || !ws || N <= 0 || HW <= 0 || G <= 0 || C1 <= 0 || C2 < 0 ||
-      C % G || (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f)
+      C % G || (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f || act < 0 || act > STK_ACT_ELU)
     return STK_EINVAL;
   GnArgs a;
   a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;

@@ -707,18 +707,29 @@ class Linear(Op):
 
 
 class SiLU(Op):
-  def __init__(self, g, x, name='silu'):
+  """The model's activation (layers.get_act, models/layers.py:29-41) on a plain tensor; `code` = STK_ACT_* of include/stk.h
+  (1 = swish / nn.SiLU, what every shipped config uses; 2 ReLU, 3 LeakyReLU(0.2), 4 ELU)."""
+
+  def __init__(self, g, x, name='silu', code=1):
     self.x = x
+    self.code = int(code)
     self.y = g.new(x.shape, name=name)
     self.inputs = (x,)
 
   def forward(self, rt):
-    rt.lib.silu_fwd_f32(rt.v(self.x), rt.v(self.y), self.x.numel, rt.stream)
+    if self.code == 1:
+      rt.lib.silu_fwd_f32(rt.v(self.x), rt.v(self.y), self.x.numel, rt.stream)
+    else:
+      rt.lib.act_fwd_f32(rt.v(self.x), rt.v(self.y), self.x.numel, self.code, rt.stream)
 
   def backward(self, rt):
     gx = rt.g(self.x)
-    if gx is not None:
+    if gx is None:
+      return
+    if self.code == 1:
       rt.lib.silu_bwd_f32(rt.v(self.x), rt.g(self.y), gx, self.b(self.x), self.x.numel, rt.stream)
+    else:
+      rt.lib.act_bwd_f32(rt.v(self.x), rt.g(self.y), gx, self.b(self.x), self.x.numel, self.code, rt.stream)
 
 
 class TimestepEmbedding(Op):
@@ -776,6 +787,25 @@ class Affine(Op):
     gx = rt.g(self.x)
     if gx is not None:
       rt.lib.axpby_f32(rt.g(self.y), self.a, gx, self.b(self.x), gx, self.x.numel, rt.stream)
+
+
+class FixedFourier(Op):
+  """layerspp.FixedFouriereProjection (models/layerspp.py:31-43): y = cat(x, sin / cos of 128 pi x and 256 pi x) -> 5 C channels."""
+
+  def __init__(self, g, x, name='fixed_fourier'):
+    self.x = x
+    N, C, H, W = x.shape
+    self.N, self.C, self.HW = N, C, H * W
+    self.y = g.new((N, 5 * C, H, W), needs_grad=x.needs_grad, name=name)
+    self.inputs = (x,)
+
+  def forward(self, rt):
+    rt.lib.fixed_fourier_fwd_f32(rt.v(self.x), rt.v(self.y), self.N, self.C, self.HW, rt.stream)
+
+  def backward(self, rt):
+    gx = rt.g(self.x)
+    if gx is not None:
+      rt.lib.fixed_fourier_bwd_f32(rt.v(self.x), rt.g(self.y), gx, self.b(self.x), self.N, self.C, self.HW, rt.stream)
 
 
 class ResampleNaive(Op):
@@ -1093,9 +1123,12 @@ class Graph:
     return op.y
 
   # -- convenience emitters -------------------------------------------------------------------
+  # STK_ACT_* code of the model's nonlinearity (set by the model before it emits; 1 = swish)
+  act_code = 1
+
   def gn_act(self, x1, x2, gn, act=True, drop_p=0.0, name='gn'):
     op = GroupNormAct(self, x1, x2, self.param(gn.weight), self.param(gn.bias), gn.num_groups, gn.eps,
-                      act, drop_p, name)
+                      self.act_code if act else 0, drop_p, name)
     return self.add(op)
 
   def conv(self, x1, x2, weight, bias, w_layout=0, stride=1, pad=None, out_hw=None,
@@ -1129,7 +1162,7 @@ class Graph:
     return self.add(Linear(self, x, w_tensor, b_tensor, name))
 
   def silu(self, x, name='silu'):
-    return self.add(SiLU(self, x, name))
+    return self.add(SiLU(self, x, name, self.act_code))
 
   # -- planning -----------------------------------------------------------------------------------
   def finalize(self, output, lib):

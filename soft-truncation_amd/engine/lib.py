@@ -81,8 +81,12 @@ SIGNATURES = {
   'stk_attention_bwd_f32': [P, P, P, L, P, P, P, P, P, F, P, F, P, F, L, I, I, I, F, S],
   'stk_silu_fwd_f32': [P, P, L, S],
   'stk_silu_bwd_f32': [P, P, P, F, L, S],
+  'stk_act_fwd_f32': [P, P, L, I, S],
+  'stk_act_bwd_f32': [P, P, P, F, L, I, S],
   'stk_axpby_f32': [P, F, P, F, P, L, S],
   'stk_add_div_f32': [P, P, F, P, L, S],
+  'stk_fixed_fourier_fwd_f32': [P, P, I, I, I, S],
+  'stk_fixed_fourier_bwd_f32': [P, P, P, F, I, I, I, S],
   'stk_affine_f32': [P, F, F, P, L, S],
   'stk_fill_f32': [P, F, L, S],
   'stk_fill_strided_f32': [P, F, L, L, L, S],

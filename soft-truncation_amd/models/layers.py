@@ -17,8 +17,8 @@ import torch.nn as nn
 
 
 def get_act(config):
-  """Activation named by ``config.model.nonlinearity``.  The engine implements 'swish' (SiLU),
-  the only value used by the NCSN++ configs; the others are returned for API parity."""
+  """Activation named by ``config.model.nonlinearity`` (models/layers.py:29-41).  The engine runs all four through the
+  `act` code of include/stk.h (``act_code``): 'swish' is what every shipped config uses."""
   name = config.model.nonlinearity.lower()
   if name == 'elu':
     return nn.ELU()
@@ -29,6 +29,16 @@ def get_act(config):
   if name == 'swish':
     return nn.SiLU()
   raise NotImplementedError('activation function does not exist!')
+
+
+ACT_CODES = {'swish': 1, 'relu': 2, 'lrelu': 3, 'elu': 4}     # STK_ACT_* of include/stk.h
+
+
+def act_code(config):
+  name = config.model.nonlinearity.lower()
+  if name not in ACT_CODES:
+    raise NotImplementedError('activation function does not exist!')
+  return ACT_CODES[name]
 
 
 # fan used as the denominator of the variance, per `mode` (models/layers.py:68-76)

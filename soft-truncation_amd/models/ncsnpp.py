@@ -40,9 +40,7 @@ class NCSNpp(nn.Module):
     self.sde = sde
     self.config = config
     self.act = act = get_act(config)
-    if config.model.nonlinearity.lower() != 'swish':
-      raise NotImplementedError('the HIP GroupNorm/activation kernels implement swish (SiLU), the only '
-                                'nonlinearity used by the NCSN++ configs')
+    self.act_code = layers.act_code(config)       # the kernels' code for it (include/stk.h STK_ACT_*)
     self.register_buffer('sigmas', torch.tensor(utils.get_sigmas(config)))
 
     m = config.model
@@ -73,9 +71,6 @@ class NCSNpp(nn.Module):
     assert embedding_type in ['fourier', 'positional']
     combine_method = m.progressive_combine.lower()
     combiner = functools.partial(Combine, method=combine_method)
-    if fourier_feature:
-      raise NotImplementedError('model.fourier_feature=True is not used by any shipped config')
-
     modules = []
     if embedding_type == 'fourier':
       assert config.training.continuous, "Fourier features are only used for continuous training."
@@ -93,6 +88,9 @@ class NCSNpp(nn.Module):
         lin.weight.data = default_initializer()(lin.weight.shape)
         nn.init.zeros_(lin.bias)
         modules.append(lin)
+
+    if fourier_feature:          # (models/ncsnpp.py:104-105: a parameter-free module, but it takes a slot of all_modules)
+      modules.append(layerspp.FixedFouriereProjection())
 
     AttnBlock = functools.partial(layerspp.AttnBlockpp, init_scale=init_scale, skip_rescale=skip_rescale)
     Upsample = functools.partial(layerspp.Upsample, with_conv=resamp_with_conv, fir=fir, fir_kernel=fir_kernel)
@@ -119,7 +117,7 @@ class NCSNpp(nn.Module):
     channels = config.data.num_channels
     if progressive_input != 'none':
       input_pyramid_ch = channels
-    modules.append(conv3x3(channels, nf))
+    modules.append(conv3x3(channels + 12 if fourier_feature else channels, nf))      # (models/ncsnpp.py:156-159: 12 = 4 x 3 channels)
     hs_c = [nf]
     in_ch = nf
     for i_level in range(num_resolutions):
@@ -259,6 +257,7 @@ class NCSNpp(nn.Module):
     cfg = self.config
     C = cfg.data.num_channels
     m_idx = 0
+    g.act_code = self.act_code          # every gn_act(act=True) / silu() below applies the configured nonlinearity
     x = g.input('x', (B, C, H, W), needs_grad=need_xgrad)
     emb_in = g.input('emb', (B,))
     sigma = g.input('sigma', (B,)) if cfg.model.scale_by_sigma else None
@@ -301,7 +300,11 @@ class NCSNpp(nn.Module):
     input_pyramid = x if self.progressive_input != 'none' else None
     div = SQRT2 if self.skip_rescale else 1.0
 
-    hs = [layers.conv_emit(g, modules[m_idx], x, name='stem')]
+    if self.fourier_feature:     # models/ncsnpp.py:305-308
+      m_idx += 1
+      hs = [layers.conv_emit(g, modules[m_idx], g.add(G.FixedFourier(g, x)), name='stem')]
+    else:
+      hs = [layers.conv_emit(g, modules[m_idx], x, name='stem')]
     m_idx += 1
     for i_level in range(self.num_resolutions):
       for i_block in range(self.num_res_blocks):

@@ -21,6 +21,12 @@ def tiny_config(st, family, dropout=0.0, device='cpu'):
     # few-tile variants and the prepared-weight path; the other families stay on the f32-input kernels
     cfg = st.configs.tiny(st.configs.cifar10_ddpmpp_nll_st(), nf=96, ch_mult=(1, 2), num_res_blocks=1, image_size=16,
                           attn_resolutions=(8,), dropout=dropout)
+  elif family in ('vp_elu', 'vp_relu', 'vp_lrelu'):   # the other activations of layers.get_act (models/layers.py:29-41)
+    cfg = st.configs.tiny(st.configs.cifar10_ddpmpp_nll_st(), dropout=dropout)
+    cfg.model.nonlinearity = family[3:]
+  elif family == 'vp_ff':   # model.fourier_feature: FixedFouriereProjection in front of the stem (models/ncsnpp.py:104,156,305)
+    cfg = st.configs.tiny(st.configs.cifar10_ddpmpp_nll_st(), dropout=dropout)
+    cfg.model.fourier_feature = True
   else:
     raise ValueError(family)
   cfg.device = torch.device(device)

@@ -29,6 +29,13 @@ def test_loss_curve_on_the_checker(st, ref_lib):
   print(out)
 
 
+@pytest.mark.parametrize('family', ['vp_elu', 'vp_relu', 'vp_lrelu', 'vp_ff'])
+def test_other_activations(st, ref_lib, family):
+  """config.model.nonlinearity = elu / relu / lrelu on the checker: engine graph vs RefNet."""
+  cases.forward_backward(st, ref_lib, family)
+  cases.train_steps(st, ref_lib, family, steps=2)
+
+
 def test_score_matching_loss_on_large_samples(st, ref_lib):
   cases.score_matching_pieces(st, ref_lib)
 

@@ -111,6 +111,30 @@ def test_upfirdn2d_adjoint_full_size(hip_lib):
 # ---------------------------------------------------------------------------------------------------
 # element-wise family
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [(2, 3, 16), (3, 3, 1024), (1, 5, 77)])
+def test_fixed_fourier(ref_lib, hip_lib, shape):
+  """layerspp.FixedFouriereProjection (models/layerspp.py:31-43) forward / backward; arguments reach 256 pi = 804 rad."""
+  N, C, HW = shape
+  x = torch.rand(N, C, HW, generator=torch.Generator().manual_seed(1)) * 2 - 1
+  dy = rnd(N, 5 * C, HW, seed=2)
+  old = rnd(N, C, HW, seed=3)
+
+  def fn(lib, to):
+    y = to(torch.full((N, 5 * C, HW), float('nan')))
+    call(lib, 'fixed_fourier_fwd_f32', to(x), y, N, C, HW)
+    dx = to(old.clone())
+    call(lib, 'fixed_fourier_bwd_f32', to(x), to(dy), dx, 0.5, N, C, HW)
+    dx0 = to(torch.full((N, C, HW), float('nan')))
+    call(lib, 'fixed_fourier_bwd_f32', to(x), to(dy), dx0, 0.0, N, C, HW)
+    return {'y': y, 'dx': dx, 'dx0': dx0}
+
+  outs = both(ref_lib, hip_lib, fn)
+  compare(outs, 1e-5, 'fixed fourier')
+  want = torch.cat((x, torch.sin(x * 128 * np.pi), torch.cos(x * 128 * np.pi), torch.sin(x * 256 * np.pi), torch.cos(x * 256 * np.pi)), dim=1)
+  assert (outs[0]['y'].cpu() - want).abs().max().item() <= 2e-6      # the checker against the torch expression itself
+
+
+
 @pytest.mark.parametrize('n', [1, 7, 1024, 4099, 1 << 20])
 def test_elementwise(ref_lib, hip_lib, n):
   a, b, g = rnd(n, seed=1), rnd(n, seed=2), rnd(n, seed=3)
@@ -120,6 +144,9 @@ def test_elementwise(ref_lib, hip_lib, n):
     y = to(torch.zeros(n)); call(lib, 'silu_fwd_f32', to(a), y, n); o['silu'] = y
     dx = to(b.clone()); call(lib, 'silu_bwd_f32', to(a), to(g), dx, 0.5, n); o['silu_bwd'] = dx
     dx0 = to(torch.full((n,), float('nan'))); call(lib, 'silu_bwd_f32', to(a), to(g), dx0, 0.0, n); o['silu_bwd0'] = dx0
+    for code in (0, 1, 2, 3, 4):       # layers.get_act by code (include/stk.h STK_ACT_*)
+      y = to(torch.zeros(n)); call(lib, 'act_fwd_f32', to(a), y, n, code); o[f'act{code}'] = y
+      dx = to(b.clone()); call(lib, 'act_bwd_f32', to(a), to(g), dx, 0.5, n, code); o[f'act{code}_bwd'] = dx
     z = to(torch.zeros(n)); call(lib, 'axpby_f32', to(a), 1.5, to(b), -0.25, z, n); o['axpby'] = z
     z2 = to(torch.zeros(n)); call(lib, 'axpby_f32', to(a), 0.7, None, 0.0, z2, n); o['ax'] = z2
     z3 = to(b.clone()); call(lib, 'axpby_f32', to(a), 0.7, z3, 1.0, z3, n); o['axpby_alias'] = z3
@@ -221,6 +248,9 @@ GN_CASES = [
   (1, 128, 0, 64, 32, 1, 0.0),
   (2, 64, 0, 128, 32, 1, 0.1),       # 32 K-element groups: split over workgroups (HW = 4 chunks)
   (1, 32, 32, 64, 8, 1, 0.0),        # split path, concat input, 8 channels per group
+  # the other activations of layers.get_act (models/layers.py:29-41): ReLU, LeakyReLU(0.2), ELU -- flat, concat and split paths
+  (3, 128, 0, 8, 32, 2, 0.0), (2, 256, 128, 8, 32, 3, 0.1), (2, 128, 0, 32, 32, 4, 0.0), (2, 64, 0, 128, 32, 4, 0.1),
+  (1, 32, 32, 64, 8, 3, 0.0), (2, 12, 0, 5, 3, 2, 0.0),
 ]
 
 

@@ -16,6 +16,14 @@ def test_forward_backward(st, hip_lib, family):
   cases.forward_backward(st, hip_lib, family)
 
 
+@pytest.mark.parametrize('family', ['vp_elu', 'vp_relu', 'vp_lrelu', 'vp_ff'])
+def test_other_activations(st, hip_lib, family):
+  """config.model.nonlinearity = elu / relu / lrelu (models/layers.py:29-41): forward, input and parameter gradients and
+  two training steps against RefNet."""
+  cases.forward_backward(st, hip_lib, family)
+  cases.train_steps(st, hip_lib, family, steps=2)
+
+
 @pytest.mark.parametrize('family', ['vp', 'rve', 've'])
 def test_score_fn(st, hip_lib, family):
   cases.score_fn_parity(st, hip_lib, family)

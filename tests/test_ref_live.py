@@ -72,3 +72,37 @@ def test_init_statistics_match_reference(st):
   model = st.models.utils.DataParallel(st.models.ncsnpp.NCSNpp(cfg, None))
   for (k, a), (_, b) in zip(rmodel.state_dict().items(), model.state_dict().items()):
     assert torch.equal(a, b), k     # same RNG consumption order and formulas -> identical tensors
+
+
+@pytest.mark.parametrize('name', ['elu', 'relu', 'lrelu', 'swish+fourier_feature'])
+def test_other_activations_match_reference(st, name):
+  """config.model.nonlinearity != 'swish' (models/layers.py:29-41; no shipped config uses it): the LIVE reference NCSNpp on a
+  fixture-size config against the oracle RefNet on the same state_dict -- pins the oracle the product's activation codes are
+  tested against (tests/test_engine_cpu.py::test_other_activations, tests/test_gpu_model.py::test_other_activations)."""
+  import ref_torch
+  ns = refimport.load()
+  rcfg = refimport.get_config('configs.vp.CIFAR10.ddpmpp_nll_st')
+  cfg = st.configs.cifar10_ddpmpp_nll_st()
+  for c in (rcfg, cfg):
+    c.model.nf, c.model.ch_mult, c.model.num_res_blocks, c.model.attn_resolutions = 16, (1, 2), 1, (8,)
+    c.model.dropout, c.data.image_size, c.model.nonlinearity = 0.0, 16, name.split('+')[0]
+    c.model.fourier_feature = name.endswith('fourier_feature')
+    c.device = torch.device('cpu')
+  torch.manual_seed(0)
+  rmodel = ns.mutils.create_model(rcfg, ns.sde_lib.get_sde(rcfg, None))
+  g = torch.Generator().manual_seed(3)
+  with torch.no_grad():
+    for p in rmodel.parameters():
+      if p.requires_grad:
+        p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+  sd = {k: v.detach().clone() for k, v in rmodel.state_dict().items()}
+  ref = ref_torch.RefNet(cfg, sd)
+  x = torch.randn(3, 3, 16, 16, generator=g)
+  t = torch.rand(3, generator=g) * 999
+  rmodel.eval(); ref.eval()
+  with torch.no_grad():
+    want = rmodel(x, t)
+    got = ref(x, t)
+  err = float((got - want).abs().max() / want.abs().max())
+  assert err <= 2e-6, (name, err)
+
