@@ -384,6 +384,10 @@ int stk_act_bwd_f32(const float* x, const float* dy, float* dx, float beta, long
 int stk_axpby_f32(const float* a, float alpha, const float* b, float beta, float* out, long n, void* stream);
 /* out = (a + b) * (1.f/div)  -- the skip_rescale combine (x + h)/sqrt(2), models/layerspp.py:104,287 */
 int stk_add_div_f32(const float* a, const float* b, float div, float* out, long n, void* stream);
+/* torch.cat([a, b], dim=1) materialised (Combine(method='cat'), models/layerspp.py:57-72): out [N, Ca + Cb, HW];
+ * bwd: da = beta_a*da + dout[:, :Ca], db = beta_b*db + dout[:, Ca:]  (either may be NULL). */
+int stk_concat_f32(const float* a, int Ca, const float* b, int Cb, float* out, int N, int HW, void* stream);
+int stk_concat_bwd_f32(const float* dout, float* da, float beta_a, int Ca, float* db, float beta_b, int Cb, int N, int HW, void* stream);
 /* FixedFouriereProjection (models/layerspp.py:31-43; config.model.fourier_feature):
  *   y[n] = cat(x[n], sin(128 pi x[n]), cos(128 pi x[n]), sin(256 pi x[n]), cos(256 pi x[n])) along the channels: x [N, C, HW] ->
  *   y [N, 5 C, HW]; the arguments are formed as torch forms them (fl(fl(128 x) * fl(pi))).

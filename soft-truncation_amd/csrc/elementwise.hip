@@ -396,6 +396,39 @@ int stk_add_div_f32(const float* a, const float* b, float div, float* out, long 
                    AddDiv{a, b, 1.f / div, div != 1.f, out}, S(stream));
 }
 
+// torch.cat along the channels, materialised (Combine('cat')); one thread per output / gradient element
+__global__ __launch_bounds__(256) void concat_kernel(const float* __restrict__ a, long na, const float* __restrict__ b, long nb,
+                                                     float* __restrict__ out, long total) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / (na + nb), r = i - n * (na + nb);
+    out[i] = r < na ? a[n * na + r] : b[n * nb + (r - na)];
+  }
+}
+__global__ __launch_bounds__(256) void concat_bwd_kernel(const float* __restrict__ dout, float* __restrict__ da, float beta_a, long na,
+                                                         float* __restrict__ db, float beta_b, long nb, long total) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / (na + nb), r = i - n * (na + nb);
+    const float g = dout[i];
+    if (r < na) { if (da) { float* q = da + n * na + r; *q = (beta_a != 0.f ? beta_a * *q : 0.f) + g; } }
+    else if (db) { float* q = db + n * nb + (r - na); *q = (beta_b != 0.f ? beta_b * *q : 0.f) + g; }
+  }
+}
+int stk_concat_f32(const float* a, int Ca, const float* b, int Cb, float* out, int N, int HW, void* stream) {
+  if (!a || !b || !out || Ca <= 0 || Cb <= 0 || N <= 0 || HW <= 0) return STK_EINVAL;
+  const long total = (long)N * (Ca + Cb) * HW;
+  hipLaunchKernelGGL(concat_kernel, dim3((unsigned)stk_ew_grid(total)), dim3(256), 0, S(stream), a, (long)Ca * HW, b, (long)Cb * HW, out, total);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+int stk_concat_bwd_f32(const float* dout, float* da, float beta_a, int Ca, float* db, float beta_b, int Cb, int N, int HW, void* stream) {
+  if (!dout || (!da && !db) || Ca <= 0 || Cb <= 0 || N <= 0 || HW <= 0) return STK_EINVAL;
+  const long total = (long)N * (Ca + Cb) * HW;
+  hipLaunchKernelGGL(concat_bwd_kernel, dim3((unsigned)stk_ew_grid(total)), dim3(256), 0, S(stream), dout, da, beta_a, (long)Ca * HW, db, beta_b,
+                     (long)Cb * HW, total);
+  STK_CHECK_LAUNCH();
+  return STK_OK;
+}
+
 // FixedFouriereProjection (models/layerspp.py:31-43): one thread per input element, five outputs CHW apart
 __global__ __launch_bounds__(256) void fixed_fourier_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long total, long CHW) {
   const float PI = 3.14159274101257324f;

@@ -789,6 +789,30 @@ class Affine(Op):
       rt.lib.axpby_f32(rt.g(self.y), self.a, gx, self.b(self.x), gx, self.x.numel, rt.stream)
 
 
+class Concat(Op):
+  """torch.cat([a, b], dim=1) as a tensor of its own (Combine(method='cat'), models/layerspp.py:57-72).  The skip connections of the
+  up path never need this -- GroupNorm and the convolutions take two sources -- but a concatenation that is itself pushed on the
+  skip stack and concatenated again does."""
+
+  def __init__(self, g, a, b, name='cat'):
+    self.a, self.bt = a, b
+    N, Ca, H, W = a.shape
+    Cb = b.shape[1]
+    self.N, self.Ca, self.Cb, self.HW = N, Ca, Cb, H * W
+    self.y = g.new((N, Ca + Cb, H, W), name=name)
+    self.inputs = (a, b)
+
+  def forward(self, rt):
+    rt.lib.concat_f32(rt.v(self.a), self.Ca, rt.v(self.bt), self.Cb, rt.v(self.y), self.N, self.HW, rt.stream)
+
+  def backward(self, rt):
+    ga, gb = rt.g(self.a), rt.g(self.bt)
+    if ga is None and gb is None:
+      return
+    rt.lib.concat_bwd_f32(rt.g(self.y), ga, self.b(self.a) if ga is not None else 0.0, self.Ca,
+                          gb, self.b(self.bt) if gb is not None else 0.0, self.Cb, self.N, self.HW, rt.stream)
+
+
 class FixedFourier(Op):
   """layerspp.FixedFouriereProjection (models/layerspp.py:31-43): y = cat(x, sin / cos of 128 pi x and 256 pi x) -> 5 C channels."""
 

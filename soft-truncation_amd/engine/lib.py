@@ -85,6 +85,8 @@ SIGNATURES = {
   'stk_act_bwd_f32': [P, P, P, F, L, I, S],
   'stk_axpby_f32': [P, F, P, F, P, L, S],
   'stk_add_div_f32': [P, P, F, P, L, S],
+  'stk_concat_f32': [P, I, P, I, P, I, I, S],
+  'stk_concat_bwd_f32': [P, P, F, I, P, F, I, I, I, S],
   'stk_fixed_fourier_fwd_f32': [P, P, I, I, I, S],
   'stk_fixed_fourier_bwd_f32': [P, P, P, F, I, I, I, S],
   'stk_affine_f32': [P, F, F, P, L, S],

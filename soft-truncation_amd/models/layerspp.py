@@ -60,7 +60,8 @@ class Combine(nn.Module):
     if self.method == 'sum':
       return layers.conv_emit(g, self.Conv_0, x, res=y, name=name)
     if self.method == 'cat':
-      raise NotImplementedError("Combine(method='cat') is not used by any shipped config")
+      from ..engine import graph as G
+      return g.add(G.Concat(g, layers.conv_emit(g, self.Conv_0, x, name=name + '.conv'), y, name=name))
     raise ValueError(f'Method {self.method} not recognized.')
 
   def forward(self, x, y):

@@ -24,6 +24,9 @@ def tiny_config(st, family, dropout=0.0, device='cpu'):
   elif family in ('vp_elu', 'vp_relu', 'vp_lrelu'):   # the other activations of layers.get_act (models/layers.py:29-41)
     cfg = st.configs.tiny(st.configs.cifar10_ddpmpp_nll_st(), dropout=dropout)
     cfg.model.nonlinearity = family[3:]
+  elif family == 've_cat':  # NCSN++ pyramids with Combine(method='cat') (models/layerspp.py:57-72, models/ncsnpp.py:183-184)
+    cfg = st.configs.tiny(st.configs.celebahq_uncsnpp_st(), ch_mult=(1, 1, 2), dropout=dropout)
+    cfg.model.progressive_combine = 'cat'
   elif family == 'vp_ff':   # model.fourier_feature: FixedFouriereProjection in front of the stem (models/ncsnpp.py:104,156,305)
     cfg = st.configs.tiny(st.configs.cifar10_ddpmpp_nll_st(), dropout=dropout)
     cfg.model.fourier_feature = True

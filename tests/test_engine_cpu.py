@@ -29,7 +29,7 @@ def test_loss_curve_on_the_checker(st, ref_lib):
   print(out)
 
 
-@pytest.mark.parametrize('family', ['vp_elu', 'vp_relu', 'vp_lrelu', 'vp_ff'])
+@pytest.mark.parametrize('family', ['vp_elu', 'vp_relu', 'vp_lrelu', 'vp_ff', 've_cat'])
 def test_other_activations(st, ref_lib, family):
   """config.model.nonlinearity = elu / relu / lrelu on the checker: engine graph vs RefNet."""
   cases.forward_backward(st, ref_lib, family)

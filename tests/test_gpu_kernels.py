@@ -111,6 +111,26 @@ def test_upfirdn2d_adjoint_full_size(hip_lib):
 # ---------------------------------------------------------------------------------------------------
 # element-wise family
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [(2, 3, 5, 16), (3, 16, 16, 64), (1, 7, 2, 9)])
+def test_concat(ref_lib, hip_lib, shape):
+  """torch.cat along the channels, materialised, and its backward (Combine(method='cat'), models/layerspp.py:57-72)."""
+  N, Ca, Cb, HW = shape
+  a, b = rnd(N, Ca, HW, seed=1), rnd(N, Cb, HW, seed=2)
+  dout = rnd(N, Ca + Cb, HW, seed=3)
+  oa, ob = rnd(N, Ca, HW, seed=4), rnd(N, Cb, HW, seed=5)
+
+  def fn(lib, to):
+    y = to(torch.full((N, Ca + Cb, HW), float('nan')))
+    call(lib, 'concat_f32', to(a), Ca, to(b), Cb, y, N, HW)
+    da, db = to(oa.clone()), to(torch.full((N, Cb, HW), float('nan')))
+    call(lib, 'concat_bwd_f32', to(dout), da, 0.5, Ca, db, 0.0, Cb, N, HW)
+    return {'y': y, 'da': da, 'db': db}
+
+  outs = both(ref_lib, hip_lib, fn)
+  compare(outs, 1e-6, 'concat')
+  assert torch.equal(outs[0]['y'].cpu(), torch.cat([a, b], dim=1)) and torch.equal(outs[0]['db'].cpu(), dout[:, Ca:])
+
+
 @pytest.mark.parametrize('shape', [(2, 3, 16), (3, 3, 1024), (1, 5, 77)])
 def test_fixed_fourier(ref_lib, hip_lib, shape):
   """layerspp.FixedFouriereProjection (models/layerspp.py:31-43) forward / backward; arguments reach 256 pi = 804 rad."""

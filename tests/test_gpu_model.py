@@ -16,7 +16,7 @@ def test_forward_backward(st, hip_lib, family):
   cases.forward_backward(st, hip_lib, family)
 
 
-@pytest.mark.parametrize('family', ['vp_elu', 'vp_relu', 'vp_lrelu', 'vp_ff'])
+@pytest.mark.parametrize('family', ['vp_elu', 'vp_relu', 'vp_lrelu', 'vp_ff', 've_cat'])
 def test_other_activations(st, hip_lib, family):
   """config.model.nonlinearity = elu / relu / lrelu (models/layers.py:29-41): forward, input and parameter gradients and
   two training steps against RefNet."""

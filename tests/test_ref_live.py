@@ -106,3 +106,35 @@ def test_other_activations_match_reference(st, name):
   err = float((got - want).abs().max() / want.abs().max())
   assert err <= 2e-6, (name, err)
 
+
+def test_combine_cat_matches_reference(st):
+  """progressive_combine = 'cat' (Combine, models/layerspp.py:57-72; channel doubling models/ncsnpp.py:183-184) on the NCSN++
+  pyramid config: live reference vs RefNet on the same state_dict, and the product module list has the reference's keys / shapes."""
+  import ref_torch
+  ns = refimport.load()
+  rcfg = refimport.get_config('configs.ve.celebahq.uncsnpp_st')
+  cfg = st.configs.celebahq_uncsnpp_st()
+  for c in (rcfg, cfg):
+    c.model.nf, c.model.ch_mult, c.model.num_res_blocks, c.model.attn_resolutions = 16, (1, 1, 2), 1, (8,)
+    c.model.dropout, c.data.image_size, c.model.progressive_combine = 0.0, 16, 'cat'
+    c.device = torch.device('cpu')
+  torch.manual_seed(0)
+  rmodel = ns.mutils.create_model(rcfg, ns.sde_lib.get_sde(rcfg, None))
+  torch.manual_seed(0)
+  model = st.models.utils.DataParallel(st.models.ncsnpp.NCSNpp(cfg, None))
+  rsd, sd = rmodel.state_dict(), model.state_dict()
+  assert list(rsd) == list(sd) and all(rsd[k].shape == sd[k].shape for k in rsd)
+  g = torch.Generator().manual_seed(3)
+  with torch.no_grad():
+    for p in rmodel.parameters():
+      if p.requires_grad:
+        p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+  ref = ref_torch.RefNet(cfg, {k: v.detach().clone() for k, v in rmodel.state_dict().items()})
+  x = torch.rand(2, 3, 16, 16, generator=g)
+  sig = torch.rand(2, generator=g) * 5 + 0.1
+  rmodel.eval(); ref.eval()
+  with torch.no_grad():
+    want, got = rmodel(x, sig), ref(x, sig)
+  err = float((got - want).abs().max() / want.abs().max())
+  assert err <= 2e-6, err
+
