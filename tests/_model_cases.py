@@ -116,6 +116,8 @@ def loss_curve(st, lib, family='vp', steps=100, B=8, tol=1e-3):
   step_fn = st.losses.get_step_fn(cfg, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg))
   rstep_fn = st.losses.get_step_fn(cfg_cpu, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg_cpu))
   curve, rcurve, worst = [], [], 0.0
+  threads = torch.get_num_threads()
+  torch.set_num_threads(min(threads, 8))      # the fixture-size RefNet on a 128-thread host spends its time in thread hand-offs
   for i in range(steps):
     batch = st.datasets.synthetic_batch(cfg_cpu, B, generator=torch.Generator().manual_seed(1000 + i))
     np.random.seed(70 + i)
@@ -128,6 +130,7 @@ def loss_curve(st, lib, family='vp', steps=100, B=8, tol=1e-3):
     worst = max(worst, e)
     assert e <= tol, f'step {i}: per-sample losses differ by {e:.3e}'
     curve.append(loss.mean().item()); rcurve.append(rloss.mean().item())
+  torch.set_num_threads(threads)
   curve, rcurve = np.array(curve), np.array(rcurve)
   mean_err = np.abs(curve - rcurve).max() / np.abs(rcurve).max()
   assert mean_err <= tol, f'loss curve differs by {mean_err:.3e}'
