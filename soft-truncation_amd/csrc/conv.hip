@@ -1107,7 +1107,9 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
                        r.chunks_per_split, xpart, nx);                                                            \
   } else if (pl::kernel_choice() == 4 && x2d::halo_ok(p, TAPS, r.splits)) {                                       \
     /* one halo tile of the activations per channel group serves the nine taps */                                 \
-    if (p.W == 64)                                                                                                \
+    if (p.W >= 128)                                                                                               \
+      hipLaunchKernelGGL((x2d::gemm_halo_kernel<128, E, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
+    else if (p.W == 64)                                                                                           \
       hipLaunchKernelGGL((x2d::gemm_halo_kernel<64, E, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
     else if (p.W == 32 && x2d::halo_mode() == 2)                                                                  \
       hipLaunchKernelGGL((x2d::gemm_halo_kernel<32, E, 2>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
@@ -1573,7 +1575,7 @@ int stk_conv2d_pl_halo(int dir, int C1, int C2, int N, int H, int W, int Cout, i
   if (ks <= 0 || pl::kernel_choice() != 4) return 0;
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, 1, KH / 2)) return 0;
-  return x2d::halo_ok(p, p.taps, ks) ? W : 0;
+  return x2d::halo_ok(p, p.taps, ks) ? x2d::halo_cols(W) : 0;
 }
 
 /* which kernel family a call with full scratch takes: 0/1 = f32-input MFMA with 64/128 tiles, 2 = bf16 three-way

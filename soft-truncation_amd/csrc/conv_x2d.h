@@ -217,6 +217,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M,
 // 26 instead of 72 B-side DMA instructions per group and workgroup (W = 32), issued one per wave and chunk into the
 // OTHER of two B buffers while the current group computes.  A (weights) is staged per chunk as before.
 // Shapes: W = 16, 32 or (NB = 1) 64, maps of whole tiles (H W % 128 == 0), no K split.
+// Round 4: W = 128 instantiates ROW STRIPS for the wide maps of the 256 x 256 net (map width 128 or 256): a tile is 128
+// consecutive pixels of ONE row starting at column x0 = hw0 % width, its halo tile 3 rows x 130 columns (390 rows of 64 bytes per
+// plane: 50 instead of 144 B-side DMA instructions per channel group and workgroup; 67 KB of LDS, two workgroups per CU).
+// Bit-identical to gemm_kernel, but slower than it (see halo_cols): kept behind STK_X2D_HALO_WIDE=1.
 // NB = 2: two B buffers, the next group's tile streams in one piece per wave and chunk (two workgroups per CU);
 // NB = 1: one B buffer, refilled in a burst behind the last tap's fragment reads (three workgroups per CU cover the wait).
 template <int W, class EP, int NB>
@@ -252,14 +256,14 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(ConvP p, x3::Src q, i
   unsigned b_voff[NK];
   {
     const int Cb = q.Kc >> 5;
-    const int b = n0 / p.HW, hw0 = n0 - b * p.HW, y0 = hw0 / W;
+    const int b = n0 / p.HW, hw0 = n0 - b * p.HW, y0 = hw0 / p.W, x0 = hw0 - y0 * p.W;      // x0 = 0 unless the map is wider than a tile
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
       const int row = 16 * (wid + 4 * k) + (lane >> 2);
       const int ty = row / TP, tx = row - ty * TP;
-      const int y = y0 - 1 + ty, x = tx - 1;
-      const bool ok = row < HR && y >= 0 && y < p.H && x >= 0 && x < W;
-      b_voff[k] = ok ? ((unsigned)(b * Cb) * p.HW + (unsigned)(y * W + x)) * 64u + seg_src : 0x80000000u;
+      const int y = y0 - 1 + ty, x = x0 + tx - 1;
+      const bool ok = row < HR && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      b_voff[k] = ok ? ((unsigned)(b * Cb) * p.HW + (unsigned)(y * p.W + x)) * 64u + seg_src : 0x80000000u;
     }
   }
   auto stage_a = [&](int c) {
@@ -368,9 +372,18 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(ConvP p, x3::Src q, i
 
 // shapes of the halo kernel: 3x3 on 16- or 32-wide maps made of whole 128-pixel tiles, no K split (STK_X2D_HALO=0: off)
 inline int halo_mode() { static const int v = [] { const char* e = getenv("STK_X2D_HALO"); return e ? atoi(e) : 1; }(); return v; }
+// template width of the kernel that takes a map of width W (0 = none): the map width itself up to 64, row strips of 128 beyond
+inline int halo_cols(int W) {
+  // row strips on the 128- / 256-wide maps: measured SLOWER than x2d::gemm_kernel (256 x 256 net, batch 4: forward 187.9 -> 203.1 us,
+  // data gradient 184.0 -> 190.9: 67 KB of LDS leave two workgroups per CU for the refill burst) -- off unless STK_X2D_HALO_WIDE=1
+  static const bool wide = [] { const char* e = getenv("STK_X2D_HALO_WIDE"); return e && atoi(e) != 0; }();
+  if (W == 16 || W == 32) return W;
+  if (W == 64 && halo_mode() == 1) return 64;
+  if ((W == 128 || W == 256) && halo_mode() == 1 && wide) return 128;
+  return 0;
+}
 inline bool halo_ok(const ConvP& p, int taps, int splits) {
-  return halo_mode() != 0 && taps == 9 && splits == 1 && (p.W == 16 || p.W == 32 || (p.W == 64 && halo_mode() == 1)) &&
-         p.HW % 128 == 0 && p.H * p.W == p.HW;
+  return halo_mode() != 0 && taps == 9 && splits == 1 && halo_cols(p.W) != 0 && p.HW % 128 == 0 && p.H * p.W == p.HW;
 }
 
 }  // namespace x2d

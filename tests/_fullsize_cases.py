@@ -336,9 +336,11 @@ BENCHED_PLAN = {
   'imagenet32_ddpmpp_st': dict(halo=(32, 16), other=_SMALL + tuple(f'conv3x3.wgrad.x2p.w{w}' for w in (32, 16, 8, 4))),
   # configs[2]: 64 / 32 / 16 / 8-wide maps at batch 128
   'celeba_uncsnpp_st': dict(halo=(64, 32, 16), other=_SMALL + tuple(f'conv3x3.wgrad.x2p.w{w}' for w in (32, 16, 8))),
-  # configs[4]: 256 ... 4-wide maps at batch 4: the 128 / 256-wide layers stay on x2d::gemm_kernel (no halo tile that wide)
-  # (64-wide: halo tiles; 32-wide and below: too few tiles at batch 4, K-split)
-  'celebahq_uncsnpp_st': dict(halo=(64,), other=_SMALL + ('conv3x3.fwd.x2p', 'conv3x3.dgrad.x2p') + tuple(f'conv3x3.wgrad.x2p.w{w}' for w in (32, 16, 8))),
+  # configs[4]: 256 ... 4-wide maps at batch 4: the 128- / 256-wide layers stay on x2d::gemm_kernel (their row-strip halo form,
+  # STK_X2D_HALO_WIDE=1, measured slower), halo tiles on the 64-wide ones; 32-wide and below: too few tiles at batch 4, K-split
+  'celebahq_uncsnpp_st': dict(halo=(128, 64) if os.environ.get('STK_X2D_HALO_WIDE', '0') != '0' else (64,),
+                              other=_SMALL + tuple(f'conv3x3.wgrad.x2p.w{w}' for w in (32, 16, 8)) +
+                              (() if os.environ.get('STK_X2D_HALO_WIDE', '0') != '0' else ('conv3x3.fwd.x2p', 'conv3x3.dgrad.x2p'))),
 }
 
 
