@@ -252,7 +252,9 @@ inline Plan plan(int N, int H, int W, int Cin, int Cout) {
   static const long cap_mb = [] { const char* e = getenv("STK_WGRAD_SLAB_MB"); return e ? atol(e) : 128L; }();
   // at most 512 workgroups = ONE round of two per CU (rounding the quotient up gave 516 for 12 tiles: a second round of four
   // workgroups, 441 us instead of ~330 on the 384 -> 128 layer at 32 x 32)
-  long splits = tiles >= 512 ? 1 : 512 / tiles;
+  // STK_X2W_WGS (A/B): workgroups to fill (512 = one round of two per CU)
+  static const long target = [] { const char* e = getenv("STK_X2W_WGS"); return e && atol(e) > 0 ? atol(e) : 512L; }();
+  long splits = tiles >= target ? 1 : target / tiles;
   if (splits > nch / 8) splits = nch / 8;
   const long cap = (cap_mb << 20) / (9L * Cout * Cin * 4);
   if (splits > cap) splits = cap;
