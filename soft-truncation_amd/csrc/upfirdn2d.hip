@@ -74,7 +74,22 @@ __global__ __launch_bounds__(256) void upfirdn2d_direct(UfdParams p) {
 constexpr int UFD_MAX_TAPS = 8;
 constexpr int UFD_LDS_FLOATS = 12288;   // at most 48 KB of input windows per workgroup
 
-template <int UP, int DOWN>
+// Row pitch of a staged window of `cols` columns.  Plain / up-sampling: odd.  Down-sampling by 2: a window row is kept
+// de-interleaved -- its even columns, then (half a pitch on, a multiple of 16 bytes) its odd columns -- because an output
+// column reads window columns 2 ox .. 2 ox + 3: with interleaved rows the lanes of a wave, four outputs each, read single
+// floats 32 bytes apart (8 of the 64 banks; 4-way conflicts as soon as a wave spans 32 column groups, i.e. on rows of 128
+// outputs), de-interleaved they read 16-byte pieces that are contiguous from lane to lane.
+// (Rows of up to 64 outputs keep the interleaved form with an odd pitch: a wave then spans eight or more rows whose bank
+// offsets differ, the single-float reads are conflict-free and measured faster -- 57.8 vs 64.9 us on 16384 planes 64 -> 32.)
+__host__ __device__ inline bool ufd_deint(int down, int tow_log2) { return down == 2 && tow_log2 >= 7; }
+__host__ __device__ inline int ufd_pitch(int cols, bool deint) {
+  return deint ? 2 * ((((cols + 1) >> 1) + 3) & ~3) : (cols | 1);
+}
+__device__ __forceinline__ int ufd_col(int c, int pitch, bool deint) {
+  return deint ? ((c & 1) ? (pitch >> 1) : 0) + (c >> 1) : c;
+}
+
+template <int UP, int DOWN, bool DEINT>
 __global__ __launch_bounds__(256) void upfirdn2d_tiled(UfdParams p, int tow_log2, int toh_log2, int ppb_log2,
                                                        int nq, int tiles_x, int tiles_y, int whole, int vec, int k4) {
   extern __shared__ __attribute__((aligned(16))) float s_ufd[];
@@ -100,17 +115,22 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(UfdParams p, int tow_log2
   const int ix_lo = floor_div(ox0 * DOWN - p.pad_x0, UP);
   const int ix_hi = floor_div((ox0 + TOW - 1) * DOWN + p.kw - 1 - p.pad_x0, UP);
   const int rows = iy_hi - iy_lo + 1, cols = ix_hi - ix_lo + 1;
-  const int pitch = cols | 1;            // odd pitch keeps the column-strided reads of the down-2 case cheap
+  constexpr bool deint = DEINT;
+  const int pitch = ufd_pitch(cols, deint);
   const int win = rows * pitch;
   const unsigned plane_in = (unsigned)(p.in_h * p.in_w);
 
   if (whole) {
-    // Whole planes: the PPB input planes are one contiguous run.  Zero the windows (halo), then scatter the run.
+    // Full-width tiles: the input of the workgroup is one contiguous run -- the PPB whole planes of a small map, or
+    // (tiles_y > 1, PPB = 1) the band of input rows under TOH output rows of a large one.  Zero the windows (halo), then
+    // scatter the run.
     const int nz = (PPB * win + 3) >> 2;
     for (int i = threadIdx.x; i < nz; i += 256) reinterpret_cast<float4*>(s_in)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nplanes = min(PPB, p.major - plane0);
-    const unsigned total = (unsigned)nplanes * plane_in;
-    const float* src = p.in + (long)plane0 * plane_in;
+    const int ys = tiles_y > 1 ? max(iy_lo, 0) : 0;                   // first input row of the run
+    const int ye = tiles_y > 1 ? min(iy_hi, p.in_h - 1) : p.in_h - 1;
+    const unsigned total = tiles_y > 1 ? (unsigned)(max(ye - ys + 1, 0) * p.in_w) : (unsigned)nplanes * plane_in;
+    const float* src = p.in + (long)plane0 * plane_in + (long)ys * p.in_w;
     if (vec) {
       for (unsigned base = 0; base < total; base += 256 * 4 * 4) {
         float4 v[4];
@@ -128,14 +148,14 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(UfdParams p, int tow_log2
           const unsigned e = base + 4 * (threadIdx.x + 256 * j);
           if (e >= total) continue;
           const unsigned pl = e / plane_in, rem = e - pl * plane_in;
-          const int iy = (int)(rem / (unsigned)p.in_w), ix = (int)(rem - (unsigned)iy * p.in_w);
-          const int r = iy - iy_lo, c = ix - ix_lo;
+          const int ry = (int)(rem / (unsigned)p.in_w), ix = (int)(rem - (unsigned)ry * p.in_w);
+          const int r = ys + ry - iy_lo, c = ix - ix_lo;
           if (r < 0 || r >= rows) continue;
-          float* d = s_in + pl * win + r * pitch + c;
+          float* d = s_in + pl * win + r * pitch;
           const float t[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (c + q >= 0 && c + q < cols) d[q] = t[q];
+            if (c + q >= 0 && c + q < cols) d[ufd_col(c + q, pitch, deint)] = t[q];
         }
       }
     } else {
@@ -143,9 +163,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(UfdParams p, int tow_log2
       __syncthreads();
       for (unsigned e = threadIdx.x; e < total; e += 256) {
         const unsigned pl = e / plane_in, rem = e - pl * plane_in;
-        const int iy = (int)(rem / (unsigned)p.in_w), ix = (int)(rem - (unsigned)iy * p.in_w);
-        const int r = iy - iy_lo, c = ix - ix_lo;
-        if (r >= 0 && r < rows && c >= 0 && c < cols) s_in[pl * win + r * pitch + c] = src[e];
+        const int ry = (int)(rem / (unsigned)p.in_w), ix = (int)(rem - (unsigned)ry * p.in_w);
+        const int r = ys + ry - iy_lo, c = ix - ix_lo;
+        if (r >= 0 && r < rows && c >= 0 && c < cols) s_in[pl * win + r * pitch + ufd_col(c, pitch, deint)] = src[e];
       }
     }
   } else {
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(UfdParams p, int tow_log2
         const bool ok = e < total && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
         const float t = src[ok ? iy * p.in_w + ix : 0];
         v[j] = ok ? t : 0.f;
-        dst[j] = e < total ? (int)(r * pitch + c) : -1;
+        dst[j] = e < total ? (int)(r * pitch) + ufd_col((int)c, pitch, deint) : -1;
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j)
@@ -215,6 +235,21 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(UfdParams p, int tow_log2
         if (py == 0) { if (px == 0) { STK_UFD_UP(0, 0) } else { STK_UFD_UP(0, 1) } }
         else { if (px == 0) { STK_UFD_UP(1, 0) } else { STK_UFD_UP(1, 1) } }
 #undef STK_UFD_UP
+      } else if (DOWN == 2 && deint) {
+        // first tap of output ox = window column 2 (ox - ox0): even, so its four outputs read even columns tx .. tx + 4 and
+        // odd columns tx .. tx + 4 of the de-interleaved row (tx = ox - ox0, a multiple of 4: 16-byte reads)
+        const float* r0 = w_in + (oy * 2 - p.pad_y0 - iy_lo) * pitch + tx;
+        const int ph = pitch >> 1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float4 e4 = *reinterpret_cast<const float4*>(r0 + a * pitch);
+          const float4 o4v = *reinterpret_cast<const float4*>(r0 + a * pitch + ph);
+          const float v[10] = {e4.x, o4v.x, e4.y, o4v.y, e4.z, o4v.z, e4.w, o4v.w, r0[a * pitch + 4], r0[a * pitch + ph + 4]};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[j] += v[2 * j + b] * kr[a][b];
+        }
       } else {
         constexpr int NC = DOWN == 2 ? 10 : 7;
         const float* r0 = w_in + (oy * DOWN - p.pad_y0 - iy_lo) * pitch + (ox * DOWN - p.pad_x0 - ix_lo);
@@ -261,9 +296,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(UfdParams p, int tow_log2
     // only taps whose upsampled coordinate is a real sample: ky = (-uy0) mod UP, stepping by UP
     const int ky0 = (UP - (uy0 & (UP - 1))) & (UP - 1), kx0 = (UP - (ux0 & (UP - 1))) & (UP - 1);
     for (int ky = ky0; ky < p.kh; ky += UP) {
-      const float* row = w_in + (floor_div(uy0 + ky, UP) - iy_lo) * pitch - ix_lo;
+      const float* row = w_in + (floor_div(uy0 + ky, UP) - iy_lo) * pitch;
       for (int kx = kx0; kx < p.kw; kx += UP)
-        acc += row[floor_div(ux0 + kx, UP)] * s_k[ky * UFD_MAX_TAPS + kx];
+        acc += row[ufd_col(floor_div(ux0 + kx, UP) - ix_lo, pitch, deint)] * s_k[ky * UFD_MAX_TAPS + kx];
     }
     if (plane < p.major && oy < p.out_h && ox < p.out_w) {
       float* d = p.out + plane * plane_out + (long)oy * p.out_w + ox;
@@ -290,38 +325,53 @@ int launch(const float* input, const float* kernel, float* out, float beta, int 
                         ((up_x == 1 && (down_x == 1 || down_x == 2)) || (up_x == 2 && down_x == 1)) &&
                         (long)in_h * in_w < 0x7fffffffL;
   if (tiled_ok) {
-    // tile = TOH x TOW outputs (powers of two, <= 1024 in total, TOW <= 64), PPB planes per workgroup
+    // tile = TOH x TOW outputs (powers of two), PPB planes per workgroup.  Rows up to 256 outputs wide are taken whole
+    // (tiles_x = 1): the workgroup's input is then one contiguous run of memory -- whole planes of a small map, a band of
+    // rows of a large one -- staged with 16-byte loads (the 64-wide tiles of wider rows stage element by element: 24 % of
+    // the HBM rate on the 64x64 -> 128x128 up-sampling against 74 % for the run form, profiles/r04_upfirdn2d.txt).
+    // Outputs per workgroup: 1024 (4 per thread); 4096 for up-sampling, whose input is 4x smaller; 2048 for bands of
+    // a down-sampling (the halo rows of a band are read twice: fewer, taller bands).
+    static const int band_on = [] { const char* e = getenv("STK_UFD_BANDS"); return !e || atoi(e) != 0; }();
+    const int tow_max = band_on && p.out_w <= 256 ? 8 : 6;
     int tow_log2 = 2, toh_log2 = 2;
-    while (tow_log2 < 6 && (1 << tow_log2) < p.out_w) ++tow_log2;
-    while (toh_log2 + tow_log2 < 10 && (1 << toh_log2) < p.out_h) ++toh_log2;
-    const int TOW = 1 << tow_log2, TOH = 1 << toh_log2;
-    const int tiles_x = stk_cdiv(p.out_w, TOW), tiles_y = stk_cdiv(p.out_h, TOH);
-    const int whole = tiles_x * tiles_y == 1;
-    // outputs per workgroup: 1024 (4 per thread); 4096 for whole-plane upsampling, whose input is 4x smaller
-    int out_log2 = (whole && up_x == 2) ? 12 : 10;
-    int ppb_log2 = whole ? out_log2 - tow_log2 - toh_log2 : 0;
+    while (tow_log2 < tow_max && (1 << tow_log2) < p.out_w) ++tow_log2;
+    const bool wide = (1 << tow_log2) >= p.out_w;                    // tiles_x == 1
+    int out_log2 = 10;
+    if (wide && up_x == 2) out_log2 = 12;
+    else if (wide && down_x == 2 && p.out_h > (1 << (10 - tow_log2))) out_log2 = 11;
+    while (toh_log2 + tow_log2 < out_log2 && (1 << toh_log2) < p.out_h) ++toh_log2;
     // LDS budget: PPB windows of rows x (cols | 1) floats
     const int up = up_x, down = down_x;
+    auto win_floats = [&](int th_log2) {
+      const long r = (((1 << th_log2) - 1) * down + kh - 1) / up + 2, c = (((1 << tow_log2) - 1) * down + kw - 1) / up + 2;
+      return r * ufd_pitch((int)c, ufd_deint(down, tow_log2));
+    };
+    while (toh_log2 > 2 && win_floats(toh_log2) > UFD_LDS_FLOATS) --toh_log2;
+    const int TOW = 1 << tow_log2, TOH = 1 << toh_log2;
+    const int tiles_x = stk_cdiv(p.out_w, TOW), tiles_y = stk_cdiv(p.out_h, TOH);
+    const int whole = tiles_x == 1;                                  // contiguous-run staging (kernel: `whole`)
+    int ppb_log2 = tiles_x * tiles_y == 1 ? max(out_log2 - tow_log2 - toh_log2, 0) : 0;
     const int rows = ((TOH - 1) * down + kh - 1) / up + 2, cols = ((TOW - 1) * down + kw - 1) / up + 2;
-    while (ppb_log2 > 0 && ((long)(1 << ppb_log2) * rows * (cols | 1) > UFD_LDS_FLOATS || (1 << ppb_log2) > 2 * major))
+    const long win = (long)rows * ufd_pitch(cols, ufd_deint(down, tow_log2));
+    while (ppb_log2 > 0 && ((win << ppb_log2) > UFD_LDS_FLOATS || (1 << ppb_log2) > 2 * major))
       --ppb_log2;
     const int nq = (1 << (ppb_log2 + tow_log2 + toh_log2)) >> 8;
     const long groups = ((long)major + (1 << ppb_log2) - 1) >> ppb_log2;
     const long nblk = groups * tiles_x * tiles_y;
-    if ((long)rows * (cols | 1) <= UFD_LDS_FLOATS && nblk <= 0x7fffffffL && nq >= 1) {
+    if (win <= UFD_LDS_FLOATS && nblk <= 0x7fffffffL && nq >= 1) {
       const int vec = whole && (((long)in_h * in_w) & 3) == 0 && (in_w & 3) == 0 && stk_aligned16(input);
-      const size_t shm = (UFD_MAX_TAPS * UFD_MAX_TAPS + (((size_t)(1 << ppb_log2) * rows * (cols | 1) + 3) & ~(size_t)3)) *
-                         sizeof(float);
+      const size_t shm = (UFD_MAX_TAPS * UFD_MAX_TAPS + (((size_t)win << ppb_log2) + 3 & ~(size_t)3)) * sizeof(float);
       // four outputs per thread and trip (taps in registers) for the 4 x 4 FIR; windows are sized so that the reads of a
       // group that hangs over the tile edge stay inside the staged window (rows / cols above have one spare)
       const int k4 = kh == 4 && kw == 4 && (nq & 3) == 0 && tow_log2 >= 2;
       dim3 grid((unsigned)nblk), block(256);
-#define STK_UFD(U, D)                                                                                               \
-  hipLaunchKernelGGL((upfirdn2d_tiled<U, D>), grid, block, shm, stream, p, tow_log2, toh_log2, ppb_log2, nq, tiles_x, \
+#define STK_UFD(U, D, I)                                                                                               \
+  hipLaunchKernelGGL((upfirdn2d_tiled<U, D, I>), grid, block, shm, stream, p, tow_log2, toh_log2, ppb_log2, nq, tiles_x, \
                      tiles_y, whole, vec, k4)
-      if (up_x == 1 && down_x == 1) STK_UFD(1, 1);
-      else if (up_x == 1) STK_UFD(1, 2);
-      else STK_UFD(2, 1);
+      if (up_x == 1 && down_x == 1) STK_UFD(1, 1, false);
+      else if (up_x == 1 && ufd_deint(down_x, tow_log2)) STK_UFD(1, 2, true);
+      else if (up_x == 1) STK_UFD(1, 2, false);
+      else STK_UFD(2, 1, false);
 #undef STK_UFD
       STK_CHECK_LAUNCH();
       return STK_OK;

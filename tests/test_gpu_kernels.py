@@ -53,6 +53,17 @@ UFD_CASES = [
   (4, 17, 19, 2, 1, 2, 1, FIR * 4, 0.0),
   (2, 40, 40, 3, 2, 2, 3, np.arange(25, dtype=np.float32).reshape(5, 5) / 25., 0.0),   # generic factors
   (2, 24, 24, 1, 1, -1, -1, FIR, 0.0),        # negative padding (crop)
+  # rows up to 256 outputs wide are taken whole, in bands of rows (one contiguous run of input per workgroup)
+  (3, 64, 64, 2, 1, 2, 1, FIR * 4, 0.0),      # 64 -> 128: bands of 32 rows
+  (2, 128, 128, 2, 1, 2, 1, FIR * 4, 0.5),    # 128 -> 256
+  (2, 128, 128, 1, 2, 1, 1, FIR, 0.5),        # 128 -> 64: bands of 32 rows
+  (2, 128, 128, 1, 1, 2, 2, FIR, 0.0),        # 129 outputs per row in 256-wide bands
+  (2, 129, 129, 1, 1, 1, 1, FIR[::-1, ::-1].copy(), 0.5),
+  (2, 128, 64, 1, 2, 1, 1, FIR, 0.0),         # not square
+  (2, 48, 200, 2, 1, 2, 1, FIR * 4, 0.0),     # 400 outputs per row: the 64-wide tiles
+  (2, 70, 70, 2, 1, 2, 1, FIR * 4, 0.0),      # band whose run is not a whole number of 16-byte pieces
+  (2, 100, 202, 1, 2, 1, 1, FIR, 1.0),        # ragged band: last band short, odd 16-byte alignment of the rows
+  (1, 256, 256, 2, 1, 2, 1, FIR * 4, 0.0),    # 512 outputs per row: the 64-wide tiles
 ]
 
 

@@ -178,6 +178,24 @@ def main():
     dn, up = torch.empty(planes, H // 2, H // 2, device=d), torch.empty(planes, 2 * H, 2 * H, device=d)
     rec('upfirdn2d.down', f'{planes}x{H}x{H}', timeit(lambda: call(lib, 'upfirdn2d_f32', x, k, dn, planes, H, H, 1, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1), args.reps), nbytes=4 * (x.numel() + dn.numel()))
     rec('upfirdn2d.up', f'{planes}x{H}x{H}', timeit(lambda: call(lib, 'upfirdn2d_f32', x, k, up, planes, H, H, 1, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1), args.reps), nbytes=4 * (x.numel() + up.numel()))
+  if not args.only or 'upfirdn' in args.only:
+    # the FIR resampling calls of the 64x64 / batch-128 and 256x256 / batch-4 nets (planes = batch x channels), beside a plain
+    # device copy of the same number of bytes (what the HBM sustains for a read + write stream of that size)
+    k = torch.ones(4, 4, device=d) / 16
+    for planes, H in [(16384, 64), (32768, 32), (32768, 16), (512, 256), (512, 128), (1024, 64), (1024, 32), (1024, 16)]:
+      x = torch.randn(planes, H, H, device=d)
+      dn, up, same = torch.empty(planes, H // 2, H // 2, device=d), torch.empty(planes, 2 * H, 2 * H, device=d), torch.empty(planes, H + 1, H + 1, device=d)
+      shape = f'{planes}x{H}x{H}'
+      rec('upfirdn2d.down', shape, timeit(lambda: call(lib, 'upfirdn2d_f32', x, k, dn, planes, H, H, 1, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1), args.reps), nbytes=4 * (x.numel() + dn.numel()))
+      rec('upfirdn2d.up', shape, timeit(lambda: call(lib, 'upfirdn2d_f32', x, k, up, planes, H, H, 1, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1), args.reps), nbytes=4 * (x.numel() + up.numel()))
+      rec('upfirdn2d.fir', shape, timeit(lambda: call(lib, 'upfirdn2d_f32', x, k, same, planes, H, H, 1, 4, 4, 1, 1, 1, 1, 2, 2, 2, 2), args.reps), nbytes=4 * (x.numel() + same.numel()))
+      for name, n_in, n_out in (('copy.like.down', x.numel(), dn.numel()), ('copy.like.up', x.numel(), up.numel())):
+        n = (n_in + n_out) // 2
+        src, dst = torch.empty(n, device=d), torch.empty(n, device=d)
+        rec(name, shape, timeit(lambda: dst.copy_(src), args.reps), nbytes=8 * n)
+      del x, dn, up, same
+
+  if not args.only or 'misc' in args.only:
     P = 61804419
     p, g, m, v = (torch.randn(P, device=d) * 0.01 for _ in range(4))
     v = v.abs()
