@@ -524,7 +524,10 @@ __global__ __launch_bounds__(256) void gn_split_fwd_kernel(GnArgs a, const float
                                                            float* __restrict__ y, float* __restrict__ mean_out,
                                                            float* __restrict__ rstd_out, float eps) {
   __shared__ float red[16];
-  const int k = blockIdx.x % Sc, nc = blockIdx.x / Sc;
+  // chunks in the REVERSE of the order the statistics kernel read them in: what that pass read last is still in the
+  // Infinity Cache (256 MB) -- in the same order a tensor of about that size evicts each piece just before its reuse
+  const int bid = gridDim.x - 1 - blockIdx.x;
+  const int k = bid % Sc, nc = bid / Sc;
   const int C = a.C1 + a.C2, n = nc / C, c = nc - n * C, g = c / a.cpg;
   const float shift = gn_chan(a, n, g * a.cpg)[0];
   // fold the cpg * Sc partials of the group (fixed order inside block_sum)
@@ -600,7 +603,8 @@ __global__ __launch_bounds__(256) void gn_split_bwd_kernel(GnArgs a, const float
                                                            int Sc, float* __restrict__ dx1, float beta1,
                                                            float* __restrict__ dx2, float beta2, float* __restrict__ ws) {
   __shared__ float red[16];
-  const int k = blockIdx.x % Sc, nc = blockIdx.x / Sc;
+  const int bid = gridDim.x - 1 - blockIdx.x;          // reverse of gn_split_bwd_part_kernel's order (see gn_split_fwd_kernel)
+  const int k = bid % Sc, nc = bid / Sc;
   const int C = a.C1 + a.C2, n = nc / C, c = nc - n * C, g = c / a.cpg;
   const float mean = mean_in[n * a.G + g], rstd = rstd_in[n * a.G + g];
   // group sums of du*gamma and du*gamma*xhat from the partials (fixed order), and this channel's own sums

@@ -116,7 +116,8 @@ def main():
        rec('conv.wgrad', shape, timeit(lambda: call(lib, 'conv2d_wgrad_f32', x1, C1, x2, C2, dy, dw, 0, 1.0, ws, ws.numel() * 4, *dims), args.reps), flops)
 
   if not args.only or 'gn' in args.only:
-    for C, H, Nb in [(128, 32, N), (256, 16, N), (256, 8, N), (384, 32, N), (512, 16, N), (128, 256, 4), (256, 128, 4)]:
+    for C, H, Nb in [(128, 32, N), (256, 16, N), (256, 8, N), (384, 32, N), (512, 16, N), (128, 256, 4), (256, 128, 4),
+                     (128, 64, N), (256, 32, N), (384, 64, N), (512, 32, N), (256, 64, 4), (256, 256, 4)]:
       G = 32
       x = torch.randn(Nb, C, H, H, device=d)
       g, b = torch.ones(C, device=d), torch.zeros(C, device=d)
@@ -129,6 +130,15 @@ def main():
       shape = f'C{C} @{H}x{H} b{Nb}'
       rec('gn_silu.fwd', shape, timeit(lambda: call(lib, 'gn_fwd_f32', x, C, None, 0, g, b, y, mean, rstd, Nb, H * H, G, 1e-6, 1, 0.1, 1, None, ws), args.reps), nbytes=2 * nb)
       rec('gn_silu.bwd', shape, timeit(lambda: call(lib, 'gn_bwd_f32', dy, x, C, None, 0, g, b, mean, rstd, dx, 0.0, None, 0.0, dg, db, ws, Nb, H * H, G, 1, 0.1, 1, None), args.reps), nbytes=3 * nb)
+      ax = torch.zeros(256, device=d)
+      rec('amax_partial', shape, timeit(lambda: call(lib, 'amax_partial_f32', x, x.numel(), ax), args.reps), nbytes=nb)
+      if C % 32 == 0:
+        xp = torch.zeros(int(lib.planes_bytes(Nb, C, H * H)), dtype=torch.uint8, device=d)
+        rec('split_planes', shape, timeit(lambda: call(lib, 'split_planes_f32', x, Nb, C, H * H, ax, 256, xp), args.reps), nbytes=2 * nb)
+        del xp
+      src, dst = torch.empty(3 * x.numel() // 2, device=d), torch.empty(3 * x.numel() // 2, device=d)
+      rec('copy.like.gn_bwd', shape, timeit(lambda: dst.copy_(src), args.reps), nbytes=3 * nb)
+      del src, dst, x, y, dy, dx
 
   if not args.only or 'attn' in args.only:
     # attention core: fused kernels against the GEMM + softmax sequence they replace (engine/graph.py AttentionCore)
