@@ -672,7 +672,9 @@ class Linear(Op):
     # dX = dY W has M x N = B x fin outputs (a handful of tiles) and K = fout: for the stacked time-embedding projections
     # (46 Dense_0 layers, fout = 9984) one workgroup per tile would walk all of K alone.  Split K into slices computed as
     # one batched GEMM into slabs, summed in slice order by a second GEMM with a row of ones (deterministic).
-    self.ksplit = self.fout // self.KSLICE if (self.fout >= self.KSPLIT_MIN and self.fout % self.KSLICE == 0 and x.needs_grad) else 0
+    # (slices of 256 columns, or the largest of 128 / 64 / 32 that divides the width: the 256 x 256 net stacks 10880 = 85 x 128)
+    self.kslice = next((k for k in (self.KSLICE, 128, 64, 32) if self.fout % k == 0), 0)
+    self.ksplit = self.fout // self.kslice if (self.fout >= self.KSPLIT_MIN and self.kslice and x.needs_grad) else 0
     self.ones = g.const(np.ones(self.ksplit, dtype=np.float32)) if self.ksplit else None
 
   def forward(self, rt):
@@ -686,7 +688,7 @@ class Linear(Op):
     lib = rt.lib
     gx = rt.g(self.x)
     if gx is not None and self.ksplit:
-      S, ks = self.ksplit, self.KSLICE
+      S, ks = self.ksplit, self.kslice
       lib.gemm_f32(gy, fout, 1, ks, rt.v(self.w), fin, 1, ks * fin, rt.ws, fin, 1, B * fin, None, 0,
                    B, fin, ks, S, 1.0, 0.0, rt.stream)
       lib.gemm_f32(rt.v(self.ones), S, 1, 0, rt.ws, B * fin, 1, 0, gx, B * fin, 1, 0, None, 0,

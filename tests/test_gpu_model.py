@@ -190,6 +190,25 @@ def test_two_streams_are_deterministic(st, hip_lib):
   print('two-stream backward passes checked:', runs)
 
 
+def test_side_stream_runs_beside_the_main_stream(st, hip_lib):
+  """Every fourth pooled torch stream shares the hardware queue of the current stream and runs strictly after it; the engine's
+  side stream is the checked one (engine/executor.py: checked_side_stream), shared by all engines of the process."""
+  import torch
+  if os.environ.get('STK_SELFCHECK'):
+    pytest.skip('needs the HIP library')
+  from importlib import import_module
+  ex = import_module('soft-truncation_amd.engine.executor')
+  dev = torch.device('cuda', 0)
+  s = ex.checked_side_stream(dev)
+  main = torch.cuda.current_stream(dev)
+  ratios = [ex._overlap_ratio(main, torch.cuda.Stream(dev)) for _ in range(8)]
+  picked = ex._overlap_ratio(main, s)
+  print('overlap ratios of eight pooled streams:', [round(r, 2) for r in ratios], 'picked stream:', round(picked, 2))
+  assert picked < 1.5, picked
+  assert ex.checked_side_stream(dev) is s
+  assert ex.SideStream(dev).stream is s
+
+
 def test_product_fails_loudly_without_gpu_tensors(st, hip_lib):
   """The HIP backend refuses CPU tensors instead of falling back."""
   import torch
