@@ -179,6 +179,9 @@ FORM_KERNEL(form_fma_lo_from_hi1, "v_pk_fma_f32 v[6:7], v[32:33], v[26:27], v[20
 FORM_KERNEL(form_fma_lo_from_hi0, "v_pk_fma_f32 v[6:7], v[32:33], v[26:27], v[20:21] op_sel:[1,0,0] op_sel_hi:[1,1,1]", __fmaf_rn(a1, b0, c0), __fmaf_rn(a1, b1, c1), __fmaf_rn(0.f, b0, c0), c1)
 FORM_KERNEL(form_mul_lo_from_hi0, "v_pk_mul_f32 v[6:7], v[32:33], v[26:27] op_sel:[1,0]", a1 * b0, a1 * b1, 0.f * b0, 0.f)
 FORM_KERNEL(form_mov_lo_from_hi, "v_pk_mov_b32 v[6:7], v[32:33], v[26:27] op_sel:[1,1]", a1, b1, 0.f, 0.f)
+// the forms found in RCCL's gfx950 kernels (src0 broadcast into the HI result)
+FORM_KERNEL(form_fma_hi_from_lo0, "v_pk_fma_f32 v[6:7], v[32:33], v[26:27], v[20:21] op_sel_hi:[0,1,1]", __fmaf_rn(a0, b0, c0), __fmaf_rn(a0, b1, c1), __fmaf_rn(a0, 0.f, c0), __fmaf_rn(a0, 0.f, c1))
+FORM_KERNEL(form_mul_hi_from_lo0, "v_pk_mul_f32 v[6:7], v[32:33], v[26:27] op_sel_hi:[0,1]", a0 * b0, a0 * b1, a0 * 0.f, a0 * 0.f)
 FORM_KERNEL(form_add_both_from_hi1, "v_pk_add_f32 v[6:7], v[32:33], v[26:27] op_sel:[0,1] op_sel_hi:[1,1]", a0 + b1, a1 + b1, a0, a1)
 FORM_KERNEL(form_add_swap1, "v_pk_add_f32 v[6:7], v[32:33], v[26:27] op_sel:[0,1] op_sel_hi:[1,0]", a0 + b1, a1 + b0, a0, a1)
 
@@ -274,6 +277,7 @@ int main(int argc, char** argv) {
         FORM_CASE(form_mul_lo_from_hi1) FORM_CASE(form_fma_lo_from_hi2) FORM_CASE(form_fma_hi_from_lo2) FORM_CASE(form_add_plain)
         FORM_CASE(form_add_lo_from_hi1_b28) FORM_CASE(form_mul_sgpr_bcast) FORM_CASE(form_mul_sgpr_pair) FORM_CASE(form_mul_sgpr_src1_bcast)
         FORM_CASE(form_add_both_from_hi1) FORM_CASE(form_add_swap1)
+        FORM_CASE(form_fma_hi_from_lo0) FORM_CASE(form_mul_hi_from_lo0)
         FORM_CASE(form_fma_lo_from_hi1) FORM_CASE(form_fma_lo_from_hi0) FORM_CASE(form_mul_lo_from_hi0) FORM_CASE(form_mov_lo_from_hi)
         else { fprintf(stderr, "unknown victim %s\n", vc.c_str()); return 2; }
       }
