@@ -307,6 +307,108 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(UfdParams p, int tow_log2
   }
 }
 
+// ---- plain 4 x 4 FIR whose rows are not a whole number of 16-byte pieces (round 4) ----------------------------------
+// The pre-filter of conv_downsample_2d (models/up_or_down_sampling.py:144-178: pad (2, 2), no resampling) turns an H x H map
+// into (H + 1) x (H + 1): rows of 65 / 33 / 17 floats.  In the tiled kernel that shape half-fills a power-of-two tile and its
+// four-outputs-per-thread stores fall back to single floats 16 bytes apart (0.17-0.30 of HBM).  Here a workgroup owns PPB whole
+// planes or a band of TOH rows (any multiple of four), staged like the tiled kernel's contiguous run, and walks its outputs in
+// FLAT order along the rows: consecutive lanes = consecutive addresses of the output (the band is one contiguous piece of the
+// plane), stores coalesce whatever the row length, LDS reads are stride-1; taps in registers.
+__global__ __launch_bounds__(256) void upfirdn2d_fir_flat(UfdParams p, int toh, int ppb, int tiles_y, int vec) {
+  extern __shared__ __attribute__((aligned(16))) float s_ufd[];
+  float* s_k = s_ufd;
+  float* s_in = s_ufd + UFD_MAX_TAPS * UFD_MAX_TAPS;
+  const int ty_tile = blockIdx.x % tiles_y;
+  const int plane0 = (blockIdx.x / tiles_y) * ppb;
+  const int oy0 = ty_tile * toh;
+  const int th = min(toh, p.out_h - oy0);                 // output rows of this band
+  float kv = 0.f;
+  const int tky = threadIdx.x >> 2, tkx = threadIdx.x & 3;
+  if (threadIdx.x < 16) kv = p.k[(3 - tky) * 4 + (3 - tkx)];
+  const int iy_lo = oy0 - p.pad_y0, ix_lo = -p.pad_x0;
+  const int rows = ((th + 3) & ~3) + 3, cols = p.out_w + 3;      // whole quads of output rows (see below)
+  const int pitch = cols | 1;
+  const int win = rows * pitch;
+  const unsigned plane_in = (unsigned)(p.in_h * p.in_w);
+  const int nz = (ppb * win + 3) >> 2;
+  for (int i = threadIdx.x; i < nz; i += 256) reinterpret_cast<float4*>(s_in)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nplanes = min(ppb, p.major - plane0);
+  const int ys = tiles_y > 1 ? max(iy_lo, 0) : 0;
+  const int ye = tiles_y > 1 ? min(iy_lo + rows - 1, p.in_h - 1) : p.in_h - 1;
+  const unsigned total_in = tiles_y > 1 ? (unsigned)(max(ye - ys + 1, 0) * p.in_w) : (unsigned)nplanes * plane_in;
+  const float* src = p.in + (long)plane0 * plane_in + (long)ys * p.in_w;
+  if (threadIdx.x < 16) s_k[tky * UFD_MAX_TAPS + tkx] = kv;
+  __syncthreads();                                        // zero fill done before the scatter
+  if (vec) {
+    for (unsigned base = 0; base < total_in; base += 256 * 4 * 4) {
+      float4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned e = base + 4 * (threadIdx.x + 256 * j);
+        v[j] = *reinterpret_cast<const float4*>(src + (e < total_in ? e : 0));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned e = base + 4 * (threadIdx.x + 256 * j);
+        if (e >= total_in) continue;
+        const unsigned pl = e / plane_in, rem = e - pl * plane_in;
+        const int ry = (int)(rem / (unsigned)p.in_w), ix = (int)(rem - (unsigned)ry * p.in_w);
+        const int r = ys + ry - iy_lo, c = ix - ix_lo;
+        if (r < 0 || r >= rows) continue;
+        float* d = s_in + pl * win + r * pitch + c;
+        const float t[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (c + q >= 0 && c + q < cols) d[q] = t[q];
+      }
+    }
+  } else {
+    for (unsigned e = threadIdx.x; e < total_in; e += 256) {
+      const unsigned pl = e / plane_in, rem = e - pl * plane_in;
+      const int ry = (int)(rem / (unsigned)p.in_w), ix = (int)(rem - (unsigned)ry * p.in_w);
+      const int r = ys + ry - iy_lo, c = ix - ix_lo;
+      if (r >= 0 && r < rows && c >= 0 && c < cols) s_in[pl * win + r * pitch + c] = src[e];
+    }
+  }
+  __syncthreads();
+  float kr[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) kr[a][b] = s_k[a * UFD_MAX_TAPS + b];
+  // a thread owns FOUR vertically adjacent outputs (rows 4 tq .. 4 tq + 3 of the band, one column): 7 x 4 window values serve
+  // 64 FMAs (7 LDS reads per output instead of 16), and each of its four stores is lane-contiguous along the row
+  const int nq = (th + 3) >> 2;                           // row quads of the band (the window has 4 nq + 3 rows)
+  const int per_plane = nq * p.out_w;
+  const int total = nplanes * per_plane;
+  const float inv_pp = 1.f / (float)per_plane, inv_ow = 1.f / (float)p.out_w;
+  const long plane_out = (long)p.out_h * p.out_w;
+  for (int f = threadIdx.x; f < total; f += 256) {
+    // f = (pl, tq, tx): quotients by float reciprocal, corrected by one step (exact: f < 2^21)
+    int pl = (int)((float)f * inv_pp);
+    int r = f - pl * per_plane;
+    if (r < 0) { --pl; r += per_plane; } else if (r >= per_plane) { ++pl; r -= per_plane; }
+    int tq = (int)((float)r * inv_ow);
+    int tx = r - tq * p.out_w;
+    if (tx < 0) { --tq; tx += p.out_w; } else if (tx >= p.out_w) { ++tq; tx -= p.out_w; }
+    const float* w = s_in + pl * win + 4 * tq * pitch + tx;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+      const float v0 = w[a * pitch], v1 = w[a * pitch + 1], v2 = w[a * pitch + 2], v3 = w[a * pitch + 3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (a - j >= 0 && a - j < 4) {
+          acc[j] += v0 * kr[a - j][0]; acc[j] += v1 * kr[a - j][1]; acc[j] += v2 * kr[a - j][2]; acc[j] += v3 * kr[a - j][3];
+        }
+    }
+    float* d = p.out + (plane0 + pl) * plane_out + (long)(oy0 + 4 * tq) * p.out_w + tx;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * tq + j < th) d[(long)j * p.out_w] = (p.beta != 0.f ? p.beta * d[(long)j * p.out_w] : 0.f) + acc[j];
+  }
+}
+
 int launch(const float* input, const float* kernel, float* out, float beta, int major, int in_h, int in_w, int minor,
            int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
            int pad_y1, hipStream_t stream) {
@@ -324,6 +426,37 @@ int launch(const float* input, const float* kernel, float* out, float beta, int 
   const bool tiled_ok = minor == 1 && up_x == up_y && down_x == down_y && kh <= UFD_MAX_TAPS && kw <= UFD_MAX_TAPS &&
                         ((up_x == 1 && (down_x == 1 || down_x == 2)) || (up_x == 2 && down_x == 1)) &&
                         (long)in_h * in_w < 0x7fffffffL;
+  // plain 4 x 4 FIR with rows that are not a whole number of 16-byte pieces: flat-order kernel (STK_UFD_FLAT=0: off)
+  static const int flat_on = [] { const char* e = getenv("STK_UFD_FLAT"); return !e || atoi(e) != 0; }();
+  if (flat_on && tiled_ok && up_x == 1 && down_x == 1 && kh == 4 && kw == 4 && (p.out_w & 3) != 0 && p.out_w + 3 <= 1024 &&
+      (long)p.out_h * p.out_w < (1L << 21)) {
+    const int pitch = (p.out_w + 3) | 1;
+    // ~2048 outputs per workgroup: whole planes while they fit the LDS budget, else bands of rows
+    int toh = p.out_h, ppb = 1;
+    const long plane_win = (long)(((p.out_h + 3) & ~3) + 3) * pitch;
+    if (plane_win <= UFD_LDS_FLOATS) {
+      ppb = (int)(2048 / ((long)p.out_h * p.out_w));
+      if (ppb < 1) ppb = 1;
+      while (ppb > 1 && (ppb * plane_win > UFD_LDS_FLOATS || ppb > 2 * major)) --ppb;
+      if ((long)ppb * p.out_h * p.out_w >= (1L << 21)) ppb = 1;
+    } else {
+      toh = 2048 / p.out_w;
+      if (toh < 1) toh = 1;
+      toh &= ~3;                                           // bands of whole row quads
+      if (toh < 4) toh = 4;
+      while (toh > 4 && (long)(toh + 3) * pitch > UFD_LDS_FLOATS) toh -= 4;
+    }
+    const int tiles_y = stk_cdiv(p.out_h, toh);
+    const long win = (long)(((toh + 3) & ~3) + 3) * pitch;
+    const long nblk = (long)stk_cdiv(major, ppb) * tiles_y;
+    if (win * ppb <= UFD_LDS_FLOATS && nblk <= 0x7fffffffL) {
+      const int vec = (((long)in_h * in_w) & 3) == 0 && (in_w & 3) == 0 && stk_aligned16(input);
+      const size_t shm = (UFD_MAX_TAPS * UFD_MAX_TAPS + (((size_t)win * ppb + 3) & ~(size_t)3)) * sizeof(float);
+      hipLaunchKernelGGL(upfirdn2d_fir_flat, dim3((unsigned)nblk), dim3(256), shm, stream, p, toh, ppb, tiles_y, vec);
+      STK_CHECK_LAUNCH();
+      return STK_OK;
+    }
+  }
   if (tiled_ok) {
     // tile = TOH x TOW outputs (powers of two), PPB planes per workgroup.  Rows up to 256 outputs wide are taken whole
     // (tiles_x = 1): the workgroup's input is then one contiguous run of memory -- whole planes of a small map, a band of

@@ -64,6 +64,13 @@ UFD_CASES = [
   (2, 70, 70, 2, 1, 2, 1, FIR * 4, 0.0),      # band whose run is not a whole number of 16-byte pieces
   (2, 100, 202, 1, 2, 1, 1, FIR, 1.0),        # ragged band: last band short, odd 16-byte alignment of the rows
   (1, 256, 256, 2, 1, 2, 1, FIR * 4, 0.0),    # 512 outputs per row: the 64-wide tiles
+  # plain FIR with rows that are not a whole number of 16-byte pieces: the flat-order kernel
+  (3, 64, 64, 1, 1, 2, 2, FIR, 0.0),          # 65 x 65, one plane per workgroup
+  (5, 16, 16, 1, 1, 2, 2, FIR, 0.5),          # 17 x 17, several planes per workgroup, accumulate
+  (9, 8, 8, 1, 1, 2, 2, FIR, 0.0),            # 9 x 9: more planes per workgroup than the last group holds
+  (2, 30, 30, 1, 1, 2, 2, FIR, 1.0),          # input rows not in 16-byte pieces either
+  (2, 40, 64, 1, 1, 2, 2, FIR, 0.0),          # 41 x 65
+  (1, 256, 256, 1, 1, 2, 2, FIR, 0.0),        # 257 x 257: bands of 7 rows
 ]
 
 
