@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--first', default='')
 ap.add_argument('--gc', type=int, default=1)
 ap.add_argument('--sampler', type=int, default=0)
+ap.add_argument('--second', default='celebahq256')
 args = ap.parse_args()
 device = torch.device('cuda', 0)
 torch.cuda.set_device(0)
@@ -60,5 +61,7 @@ if args.first:
   torch.cuda.empty_cache()
 if not args.gc:
   gc.collect(); gc.freeze(); gc.disable()
-cfg, sde, state, fn, batch, B = build('celebahq256')
-measure('celebahq256', state, fn, batch, B)
+cfg, sde, state, fn, batch, B = build(args.second)
+print('allocated GB', torch.cuda.memory_allocated() / 2**30, 'reserved GB', torch.cuda.memory_reserved() / 2**30)
+measure(args.second, state, fn, batch, B)
+print('allocated GB', torch.cuda.memory_allocated() / 2**30, 'reserved GB', torch.cuda.memory_reserved() / 2**30)
