@@ -140,6 +140,8 @@ def parse():
                   help='N = 1, default workload only: skip the `workloads` object (BASELINE configs[2] / configs[4] nets, each with its '
                        'own step time, roofline, bounded CPU baseline, and the configs[4] PC sampler at N = 1000 / 2000)')
   ap.add_argument('--extra-steps', type=int, default=12, help='timed steps of each extra workload')
+  ap.add_argument('--full-sampler-n', type=int, default=1000,
+                  help='celebahq256 workload: one COMPLETE PC-sampler run on an N-point ladder (BASELINE configs[4] "1000-step"; 0 = skip)')
   ap.add_argument('--cpu-big-batch', type=int, default=128, help='batch of the single like-for-like CPU step (0 = skip)')
   ap.add_argument('--force-exchange', action='store_true',
                   help='N = 1: run the WHOLE benchmark (the reported value too) with the exchange forced on')
@@ -276,11 +278,14 @@ def sampler_rate(st, cfg, sde, score_model, batch, steps, device):
           'corrector': cfg.sampling.corrector, 'ms_per_eval': 1e3 * dt / evals}
 
 
-def roofline_of(summ, prof_steps, ms_per_step):
-  """The `roofline` / `kernels` objects from a KernelTimer summary (dominant contraction kernel by total time)."""
+def roofline_of(summ, prof_steps, ms_per_step, pmc_workload=True):
+  """The `roofline` / `kernels` objects from a KernelTimer summary (dominant contraction kernel by total time).
+  pmc_workload: the committed PMC summary (profiles/rNN_traffic.json) was taken on THIS workload's launch shapes; for any
+  other workload `traffic` is null -- a kernel's bytes per launch depend on the shape, and a figure measured on the CIFAR
+  launches says nothing about a 64x64 or 256x256 launch of the same symbol."""
   dom = max(summ, key=lambda k: summ[k]['total_ms'])
   a = summ[dom]
-  traffic, traffic_src = traffic_of(dom)
+  traffic, traffic_src = traffic_of(dom) if pmc_workload else (None, None)
   roof = {'bound': 'mfma', 'achieved': a['tflops'], 'peak': kernel_peak(dom), 'unit': 'TFLOP/s',
           'frac': a['tflops'] / kernel_peak(dom), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
           'traffic_source': traffic_src, 'kernel': dom, 'symbol': KERNEL_SYMBOL.get(dom),
@@ -344,15 +349,20 @@ def extra_workload(st, name, device, args):
     eng.profiler = None
     summ = timer.summary()
     if summ:
-      out['roofline'], out['kernels'] = roofline_of(summ, args.prof_steps, ms)
+      out['roofline'], out['kernels'] = roofline_of(summ, args.prof_steps, ms, pmc_workload=False)
   if name == 'celebahq256':
     out['sampler'] = {}
-    for n_grid in (1000, 2000):
+    sb = cfg.sampling.batch_size if hasattr(cfg.sampling, 'batch_size') else 16
+    if args.full_sampler_n > 0:
+      # BASELINE configs[4] "1000-step PC sampler throughput": ONE COMPLETE run of sampling.get_sampling_fn on an N-point
+      # sigma ladder (model.num_scales = N), every iteration and the denoising step, measured -- not extrapolated
       try:
-        sde_n = copy.copy(sde)
-        sde_n.N = n_grid
-        sb = cfg.sampling.batch_size if hasattr(cfg.sampling, 'batch_size') else 16
-        out['sampler'][f'N{n_grid}'] = pc_rate(st, cfg, sde_n, score_model, sb, 12, device)
+        out['sampler'][f'N{args.full_sampler_n}'] = pc_full_run(st, cfg, score_model, sb, args.full_sampler_n, device)
+      except Exception as e:
+        out['sampler'][f'N{args.full_sampler_n}'] = {'error': repr(e)[:200]}
+    for n_grid in (2000,):
+      try:
+        out['sampler'][f'N{n_grid}'] = pc_rate(st, cfg, sde, score_model, sb, 12, device)
       except Exception as e:
         out['sampler'][f'N{n_grid}'] = {'error': repr(e)[:200]}
   del state, optimizer, ema, score_model, eng, step_fn
@@ -363,6 +373,33 @@ def extra_workload(st, name, device, args):
     except Exception as e:
       out['cpu_baseline'] = {'error': repr(e)[:200]}
   return out
+
+
+def pc_full_run(st, cfg, score_model, batch, n_scales, device):
+  """One complete run of the config's PC sampler (sampling.get_sampling_fn -> get_pc_sampler, sampling.py:365-433) with an
+  `n_scales`-point noise ladder: N corrector + predictor iterations and the denoising step on a batch of `batch` images,
+  timed between device syncs (the first call of the inference program -- eager run + hipGraph capture -- is made before)."""
+  import copy
+  cfg_n = copy.deepcopy(cfg)
+  cfg_n.model.num_scales = n_scales
+  sde_n = st.sde_lib.get_sde(cfg_n, None)
+  shape = (batch, cfg.data.num_channels, cfg.data.image_size, cfg.data.image_size)
+  eps = 1e-3 if cfg.training.sde == 'vpsde' else 1e-5
+  inverse_scaler = st.datasets.get_data_inverse_scaler(cfg_n)
+  warm = copy.copy(sde_n)
+  warm.N = 2
+  st.sampling.get_sampling_fn(cfg_n, warm, shape, inverse_scaler, eps)(score_model)     # builds / captures the inference program
+  torch.cuda.synchronize()
+  fn = st.sampling.get_sampling_fn(cfg_n, sde_n, shape, inverse_scaler, eps)
+  t0 = time.perf_counter()
+  x, nfe = fn(score_model)
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  evals = nfe + 1
+  return {'measured': 'complete run', 'grid_points': n_scales, 'batch': batch, 'network_evals': evals, 'full_run_s': dt,
+          'images_per_s_full_run': batch / dt, 'score_evals_per_s': evals / dt, 'image_evals_per_s': evals * batch / dt,
+          'ms_per_eval': 1e3 * dt / evals, 'predictor': cfg.sampling.predictor, 'corrector': cfg.sampling.corrector,
+          'finite': bool(torch.isfinite(x).all()), 'sample_min': float(x.min()), 'sample_max': float(x.max())}
 
 
 def pc_rate(st, cfg, sde, score_model, batch, iterations, device):
@@ -400,6 +437,50 @@ def pc_rate(st, cfg, sde, score_model, batch, iterations, device):
           'grid_points': sde.N, 'iterations_timed': iterations, 'network_evals_timed': evals, 'network_evals_full_run': full,
           'full_run_s_extrapolated': full * dt / evals, 'images_per_s_full_run': batch / (full * dt / evals),
           'predictor': cfg.sampling.predictor, 'corrector': cfg.sampling.corrector, 'finite': bool(torch.isfinite(x).all())}
+
+
+def ordered_line(out, workload):
+  """Key order of the JSON line: the contract's scalars, then `headline` -- (images/s, ms/step, fraction of the matrix-pipe
+  ceiling) of EVERY workload measured in this run -- then roofline / cpu_baseline / the other objects, the per-kernel tables
+  last; `headline` is repeated as the last key, so that a reader who keeps only the head or only the tail of a long line
+  still sees every workload's result."""
+  def triple(o):
+    t = {'images_per_s': round(o['value'], 1), 'ms_per_step': round(o['ms_per_step'], 3)}
+    if 'step_roofline' in o:
+      t['step_frac_of_x2_ceiling'] = round(o['step_roofline']['frac'], 4)
+    if 'roofline' in o:
+      t['dominant_kernel_frac'] = round(o['roofline']['frac'], 4)
+    return t
+  head = {workload: triple(out)}
+  for name, w in (out.get('workloads') or {}).items():
+    if 'value' in w:
+      head[name] = triple(w)
+      for key, smp in (w.get('sampler') or {}).items():
+        if isinstance(smp, dict) and 'ms_per_eval' in smp:
+          head[name]['sampler_' + key] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in smp.items()
+                                          if k in ('measured', 'full_run_s', 'full_run_s_extrapolated', 'ms_per_eval', 'batch')}
+    else:
+      head[name] = w
+  first = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+           'dtype', 'data', 'config')
+  line = {k: out[k] for k in first if k in out}
+  line['headline'] = head
+  tables = {}
+  for k, v in out.items():
+    if k in line or k == 'kernels':
+      continue
+    if k == 'workloads':
+      v = {n: dict(w) for n, w in v.items()}
+      for n, w in v.items():
+        if 'kernels' in w:
+          tables[n] = w.pop('kernels')
+    line[k] = v
+  if 'kernels' in out:
+    line['kernels'] = out['kernels']
+  if tables:
+    line['workload_kernels'] = tables
+  line['headline_repeat'] = head
+  return line
 
 
 def arithmetic_check(device):
@@ -706,7 +787,7 @@ def main():
           out['workloads'][name] = extra_workload(st, name, device, args)
         except Exception as e:
           out['workloads'][name] = {'error': repr(e)[:300]}
-    real_stdout.write(json.dumps(out) + '\n')
+    real_stdout.write(json.dumps(ordered_line(out, args.workload)) + '\n')
     real_stdout.flush()
   if world > 1 or (args.force_exchange and dist.is_initialized()):
     dist.destroy_process_group()

@@ -193,13 +193,91 @@ def pc_sampler_steps(st, lib, family, n=3):
   assert rel_err(xs, xr) <= 5 * TOL, f'sampler mismatch {rel_err(xs, xr):.3e}'
 
 
-def ode_sampler(st, lib):
+def pc_sampler_full_length(st, lib, family, N=None, B=2, tol=1e-3, seed=11):
+  """The WHOLE predictor-corrector trajectory (sampling.py:365-433: the config's own N -- 1000 for VP, 2000 for the VE
+  nets -- from t = T down to eps, corrector first, then predictor, then the denoising step), product engine against RefNet in
+  lockstep: both sides run the reference's update rules on their own state with the SAME injected noise, and the relative
+  difference of the two states is recorded after every iteration (sigma runs from 348 down to 0.01 on the VE ladder, so the
+  network is evaluated over its whole conditioning range).  Final samples within `tol`; the lockstep product trajectory
+  must also be what get_sampling_fn()'s own loop returns, bit for bit.  N: shorten the grid (CPU suite only)."""
+  from _model_util import _Draws
+  base = tiny_config(st, family)
+  if family == 'vp':
+    base.sampling.method, base.sampling.predictor, base.sampling.corrector = 'pc', 'euler_maruyama', 'none'
+  else:
+    base.sampling.method, base.sampling.predictor, base.sampling.corrector = 'pc', 'reverse_diffusion', 'langevin'
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, base, lib)
+  if N is not None:
+    sde.N = N
+  S = st.sampling
+  shape = (B, cfg.data.num_channels, cfg.data.image_size, cfg.data.image_size)
+  inv = st.datasets.get_data_inverse_scaler(cfg)
+  s = cfg.sampling
+  pred, corr = S.get_predictor(s.predictor), S.get_corrector(s.corrector)
+  eps = 1e-3
+  names = ('rand', 'randn', 'randn_like', 'randint_like')
+
+  class using:
+    def __init__(self, d):
+      self.d = d
+    def __enter__(self):
+      self.saved = [getattr(torch, n) for n in names]
+      for n in names:
+        setattr(torch, n, getattr(self.d, n))
+    def __exit__(self, *a):
+      for n, f in zip(names, self.saved):
+        setattr(torch, n, f)
+
+  sides = []
+  for c, m in ((cfg, model), (cfg_cpu, ref)):
+    d = _Draws(seed)
+    with using(d):
+      x = sde.prior_sampling(shape).to(c.device)
+    sides.append(dict(cfg=c, model=m, draws=d, x=x, x_mean=x, grid=torch.linspace(sde.T, eps, sde.N, device=c.device)))
+  errs = []
+  threads = torch.get_num_threads()
+  torch.set_num_threads(min(threads, 8))
+  try:
+    with torch.no_grad():
+      for i in range(sde.N):
+        for sd in sides:
+          c = sd['cfg']
+          vec_t = torch.ones(shape[0], device=c.device) * sd['grid'][i]
+          with using(sd['draws']):
+            x, x_mean = S.shared_corrector_update_fn(sd['x'], vec_t, sde, sd['model'], corr, c.training.continuous, s.snr,
+                                                     s.n_steps_each, c)
+            x, x_mean = S.shared_predictor_update_fn(x, vec_t, sde, sd['model'], pred, s.probability_flow,
+                                                     c.training.continuous, c)
+          sd['x'], sd['x_mean'] = x, x_mean
+        errs.append(rel_err(sides[0]['x'], sides[1]['x']))
+        assert np.isfinite(errs[-1]) and errs[-1] <= 10 * tol, f'iteration {i}: states differ by {errs[-1]:.3e}'
+      outs = []
+      for sd in sides:
+        with using(sd['draws']):
+          xm = S._denoiser(sd['cfg'], sde, probability_flow=True)(sd['model'], sd['x_mean'] if s.noise_removal else sd['x'])
+        outs.append(inv(xm))
+  finally:
+    torch.set_num_threads(threads)
+  final = rel_err(outs[0], outs[1])
+  assert final <= tol, f'final samples differ by {final:.3e} after {sde.N} iterations'
+  # the sampler's own loop (frozen weights, tqdm) gives the lockstep trajectory's result
+  with patched_rng(seed):
+    xs, nfe = S.get_sampling_fn(cfg, sde, shape, inv, eps)(model)
+  assert nfe == sde.N * (s.n_steps_each + 1)
+  assert torch.equal(xs, outs[0]), float((xs - outs[0]).abs().max())
+  errs = np.array(errs)
+  k = max(1, sde.N // 10)
+  return dict(N=sde.N, nfe=nfe, final=final, worst_iteration=float(errs.max()), at=int(errs.argmax()),
+              trace=[float(f'{e:.2e}') for e in errs[::k]])
+
+
+def ode_sampler(st, lib, tol=1e-3):
   base = tiny_config(st, 'vp')
   cfg, cfg_cpu, sde, model, ref = build_pair(st, base, lib)
   shape = (2, 3, cfg.data.image_size, cfg.data.image_size)
   inv = st.datasets.get_data_inverse_scaler(cfg)
-  fn = st.sampling.get_ode_sampler(cfg, sde, shape, inv, denoise=True, rtol=1e-3, atol=1e-3, eps=1e-3, device=cfg.device)
-  rfn = st.sampling.get_ode_sampler(cfg_cpu, sde, shape, inv, denoise=True, rtol=1e-3, atol=1e-3, eps=1e-3, device='cpu')
+  fn = st.sampling.get_ode_sampler(cfg, sde, shape, inv, denoise=True, rtol=tol, atol=tol, eps=1e-3, device=cfg.device)
+  rfn = st.sampling.get_ode_sampler(cfg_cpu, sde, shape, inv, denoise=True, rtol=tol, atol=tol, eps=1e-3, device='cpu')
   with patched_rng(3):
     xs, nfe = fn(model)
   with patched_rng(3):
@@ -209,6 +287,7 @@ def ode_sampler(st, lib):
   # solver tolerance.
   assert nfe == rnfe, (nfe, rnfe)
   assert rel_err(xs, xr) <= 1e-3, rel_err(xs, xr)
+  return dict(rtol=tol, nfe=nfe, err=rel_err(xs, xr))
 
 
 def checkpoint_roundtrip(st, lib, tmp_path):

@@ -57,6 +57,13 @@ def test_pc_sampler(st, ref_lib, family):
   cases.pc_sampler_steps(st, ref_lib, family)
 
 
+@pytest.mark.parametrize('family', ['vp', 've'])
+def test_pc_sampler_lockstep_on_the_checker(st, ref_lib, family):
+  """The harness of the GPU suite's full-length trajectory test (tests/_model_cases.pc_sampler_full_length) on a 60-point
+  grid: lockstep states, final samples, and equality with the sampler's own loop."""
+  cases.pc_sampler_full_length(st, ref_lib, family, N=60)
+
+
 def test_ode_sampler(st, ref_lib):
   cases.ode_sampler(st, ref_lib)
 

@@ -62,8 +62,23 @@ def test_pc_sampler(st, hip_lib, family):
   cases.pc_sampler_steps(st, hip_lib, family)
 
 
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize('family', ['vp', 've'])
+def test_pc_sampler_full_length(st, hip_lib, family):
+  """The config's whole time grid (VP euler_maruyama N = 1000; VE reverse_diffusion + langevin N = 2000, sigma 348 -> 0.01)
+  on the HIP engine against RefNet in lockstep with injected noise: per-iteration relative error recorded, final samples
+  within 1e-3, and the lockstep result equal to get_sampling_fn()'s own loop bit for bit (sampling.py:365-433)."""
+  print('full-length PC sampler:', cases.pc_sampler_full_length(st, hip_lib, family))
+
+
 def test_ode_sampler(st, hip_lib):
   cases.ode_sampler(st, hip_lib)
+
+
+def test_ode_sampler_at_reference_tolerance(st, hip_lib):
+  """The probability-flow ODE sampler at the reference's own rtol = atol = 1e-5 (sampling.py:437): same number of function
+  evaluations as the oracle's run, samples within 1e-3."""
+  print('ODE sampler at 1e-5:', cases.ode_sampler(st, hip_lib, tol=1e-5))
 
 
 def test_checkpoint_roundtrip(st, hip_lib, tmp_path):
@@ -188,6 +203,92 @@ def test_two_streams_are_deterministic(st, hip_lib):
     pytest.skip('needs the HIP library')
   runs = cases.two_streams_deterministic(st, hip_lib)
   print('two-stream backward passes checked:', runs)
+
+
+def test_backward_window_launches_library_kernels_only(st, hip_lib, monkeypatch):
+  """The hazard argument of DESIGN.md ("no third-party kernel runs while the side stream carries weight gradients") as a
+  check: one default two-stream training step is traced -- every C-ABI launch with its stream, the side stream's first fork
+  and its join, and every ATen operator dispatched in between.  Between the fork and the join the main stream must carry
+  libstk.so launches only (and really carry some, beside real side-stream work); a torch kernel injected into the window
+  must be refused by the engine's own guard (engine/executor.py: LibraryKernelsOnly, on under STK_POISON)."""
+  if os.environ.get('STK_SELFCHECK'):
+    pytest.skip('needs the HIP library')
+  from importlib import import_module
+  from _model_util import build_pair, make_state, patched_rng, tiny_config
+  import numpy as np
+  E = import_module('soft-truncation_amd.engine.executor')
+  G = import_module('soft-truncation_amd.engine.graph')
+  L = import_module('soft-truncation_amd.engine.lib')
+  cfg, cfg_cpu, sde, model, ref = build_pair(st, tiny_config(st, 'wide'), hip_lib)
+  ex = model.module.engine()
+  if not ex.use_side:
+    pytest.skip('side stream switched off (STK_WGRAD_STREAM=0)')
+  assert E._LIB_ONLY, 'the test suite runs with STK_POISON=1, which arms the guard'
+  state = make_state(st, cfg, model)
+  step_fn = st.losses.get_step_fn(cfg, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg))
+  batch = st.datasets.synthetic_batch(cfg_cpu, 24, generator=torch.Generator().manual_seed(1)).to(cfg.device)
+
+  def step():
+    np.random.seed(3)
+    with patched_rng(5):
+      return step_fn(state, batch)
+
+  step()                                                  # builds the program, first (eager) use of its context
+  log = []
+
+  class Recording:
+    def __init__(self, lib):
+      self._lib = lib
+    def __getattr__(self, name):
+      f = getattr(self._lib, name)
+      if not callable(f) or name in ('backend',):
+        return f
+      def call(*a):
+        log.append((name, a[-1] if a else None))
+        return f(*a)
+      return call
+
+  real_begin, real_join = E.SideStream.begin, E.SideStream.join
+  monkeypatch.setattr(E.SideStream, 'begin', lambda self: (log.append(('<fork>', None)), real_begin(self))[1])
+  monkeypatch.setattr(E.SideStream, 'join', lambda self: (log.append(('<join>', None)), real_join(self))[1])
+  rec = E.LibraryKernelsOnly(record=True)
+  monkeypatch.setattr(E, '_LIB_ONLY_RECORDER', rec)
+  ex.lib = Recording(hip_lib)                              # ops launch through rt.lib = the executor's library handle
+  try:
+    step()
+  finally:
+    ex.lib = hip_lib
+  torch.cuda.synchronize()
+  names = [n for n, _ in log]
+  assert '<fork>' in names and '<join>' in names
+  first, last = names.index('<fork>'), len(names) - 1 - names[::-1].index('<join>')
+  # launches only: every launching entry of include/stk.h takes its stream as the last argument (queries end in an int)
+  window = [(n, s) for n, s in log[first:last] if not n.startswith('<') and L.SIGNATURES['stk_' + n][-1] is L.S]
+  main = torch.cuda.current_stream(cfg.device).cuda_stream
+  side = ex._side.stream.cuda_stream
+  on_side = [n for n, s in window if s == side]
+  on_main = [n for n, s in window if s == main]
+  assert len(on_side) >= 5 and len(on_main) >= 20, (len(on_side), len(on_main))
+  assert len(on_side) + len(on_main) == len(window), 'a launch of the window went to a third stream'
+  assert all('stk_' + n in L.SIGNATURES for n, _ in window)
+  assert rec.seen == [], f'torch kernels inside the backward window: {rec.seen}'
+  print(f'backward window: {len(on_main)} library launches on the main stream beside {len(on_side)} on the side stream, '
+        f'0 torch operators')
+  # negative control: a torch kernel inside the window is refused (the raising guard, as the suite runs it)
+  monkeypatch.setattr(E, '_LIB_ONLY_RECORDER', None)
+  real_flush = G.Runtime.flush_folds
+
+  def flush_with_a_torch_kernel(self):
+    torch.zeros(8, device=cfg.device).add_(1.0)
+    return real_flush(self)
+
+  monkeypatch.setattr(G.Runtime, 'flush_folds', flush_with_a_torch_kernel)
+  with pytest.raises(RuntimeError, match='only libstk.so kernels may run'):
+    step()
+  monkeypatch.setattr(G.Runtime, 'flush_folds', real_flush)
+  torch.cuda.synchronize()
+  ex.programs.clear()                                     # contexts of the aborted step are dropped with their programs
+  step()                                                  # and the engine still works
 
 
 def test_side_stream_runs_beside_the_main_stream(st, hip_lib):
