@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(UfdParams p, int tow_log2
     const int ye = tiles_y > 1 ? min(iy_hi, p.in_h - 1) : p.in_h - 1;
     const unsigned total = tiles_y > 1 ? (unsigned)(max(ye - ys + 1, 0) * p.in_w) : (unsigned)nplanes * plane_in;
     const float* src = p.in + (long)plane0 * plane_in + (long)ys * p.in_w;
-    if (vec) {
+    if (vec && total > 0) {             // (a band that lies wholly in the padding has total == 0: the plain branch stores the taps)
       for (unsigned base = 0; base < total; base += 256 * 4 * 4) {
         float4 v[4];
 #pragma unroll

@@ -121,6 +121,17 @@ class OverlappedExchange:
 
 
 _armed = {}      # id(FlatParams) -> OverlappedExchange armed for the current step
+# Set when a step raised on this rank WHILE bucket all-reduces were in flight (disarm_overlap(wait=False)): the dropped
+# collectives may still be writing into flat.grad, and the ranks no longer agree on which buckets were issued, so the next
+# collective could pair with the wrong peer call or hang with no pointer to the cause.  Under data parallelism such an
+# exception is fatal for the process group: every later exchange raises this message instead.
+_poisoned = None
+
+
+def _check_poison():
+  if _poisoned is not None:
+    raise RuntimeError('gradient exchange unusable: ' + _poisoned + ' -- destroy and re-create the process group (all ranks) '
+                       'before training on')
 
 
 def _default_bucket_mb():
@@ -134,6 +145,7 @@ def arm_overlap(model, bucket_mb=None):
   models that are not on the engine."""
   if not is_distributed():
     return None
+  _check_poison()
   net = getattr(model, 'module', model)
   engine = getattr(net, 'engine', None)
   if engine is None:
@@ -158,7 +170,10 @@ def disarm_overlap(model, wait=True):
   """Drop whatever :func:`arm_overlap` left armed for `model`: the executor's hook is cleared and outstanding handles are
   waited for, so the next step starts clean.  `wait=False` (a step that RAISED on this rank): the handles are dropped
   without waiting -- the peers may never issue the matching collective, and a wait here would hang the process and hide
-  the exception that is about to surface."""
+  the exception that is about to surface.  If any were in flight the exchange is marked unusable (`_poisoned`): a caller
+  that catches the exception and keeps training gets a clear error from the next arm_overlap / sync_gradients instead of
+  mismatched collectives later (a new process group -- dist.destroy_process_group + init on all ranks -- clears it through
+  `reset_poison`)."""
   net = getattr(model, 'module', model)
   engine = getattr(net, 'engine', None)
   if engine is None:
@@ -170,7 +185,17 @@ def disarm_overlap(model, wait=True):
     if wait:
       for h in x.handles:
         h.wait()
+    elif x.handles:
+      global _poisoned
+      _poisoned = (f'a training step raised on rank {rank()} with {len(x.handles)} bucket all-reduce(s) in flight, which '
+                   f'were dropped without waiting (their peers may never issue the matching calls)')
     x.handles, x.covered = [], []
+
+
+def reset_poison():
+  """After the process group has been re-created on every rank."""
+  global _poisoned
+  _poisoned = None
 
 
 def sync_gradients(optimizer, params=None, bucket_mb=64.0):
@@ -181,6 +206,7 @@ def sync_gradients(optimizer, params=None, bucket_mb=64.0):
   flattened into one temporary bucket."""
   if not is_distributed():
     return
+  _check_poison()
   flat = getattr(optimizer, '_flat', None)
   if flat is None and hasattr(optimizer, '_bind'):
     try:

@@ -116,7 +116,7 @@ def _launch_window(active):
     yield mode
 
 
-_SIDE_STREAMS = {}     # device index -> (stream, overlap ratio): one checked side stream per device and process
+_SIDE_STREAMS = {}     # (device index, launch stream handle) -> (side stream, overlap ratio, checked)
 
 
 def _overlap_ratio(main, cand, cycles=400000):
@@ -149,23 +149,32 @@ def checked_side_stream(device):
   (4 by default) and torch hands out pooled streams round robin: every fourth one shares the current stream's queue, and a
   "second stream" on that queue runs strictly after the first -- measured on the 32x32 net 41.75 instead of 38.8 ms per step,
   on the 256x256 net 44.7 instead of 40.8 (profiles/r04_side_stream_queue.txt).  Candidates are tried with a pair of spin
-  kernels until one overlaps; the result is cached per device, so every engine of the process shares it."""
+  kernels until one overlaps.  The result is cached per (device, current stream): every engine of the process that launches
+  from that stream shares it, and an engine driven from ANOTHER stream (a user's stream context) gets a side stream checked
+  against that one.  An unchecked pick (STK_SIDE_CHECK=0, or asked for during a capture) is never cached as checked: the
+  first call outside a capture replaces it."""
   dev = torch.device(device)
-  key = dev.index if dev.index is not None else torch.cuda.current_device()
-  hit = _SIDE_STREAMS.get(key)
-  if hit is not None:
-    return hit[0]
+  index = dev.index if dev.index is not None else torch.cuda.current_device()
   main = torch.cuda.current_stream(dev)
-  best, best_ratio = None, 1e9
-  check = os.environ.get('STK_SIDE_CHECK', '1') != '0' and not torch.cuda.is_current_stream_capturing()
-  for _ in range(8 if check else 1):
+  key = (index, main.cuda_stream)
+  hit = _SIDE_STREAMS.get(key)
+  capturing = torch.cuda.is_current_stream_capturing()
+  want_check = os.environ.get('STK_SIDE_CHECK', '1') != '0'
+  if hit is not None and (hit[2] or not want_check or capturing):
+    return hit[0]
+  check = want_check and not capturing
+  best, best_ratio = (hit[0], 1e9) if (hit is not None and not check) else (None, 1e9)
+  for _ in range(8 if check else (0 if best is not None else 1)):
     cand = torch.cuda.Stream(dev)
     ratio = _overlap_ratio(main, cand) if check else 0.0
     if ratio < best_ratio:
       best, best_ratio = cand, ratio
     if ratio < 1.5:
       break
-  _SIDE_STREAMS[key] = (best, best_ratio)
+  _SIDE_STREAMS[key] = (best, best_ratio, check)
+  if check and os.environ.get('STK_SIDE_VERBOSE', '0') == '1':
+    print(f'[stk] side stream of device {index}: overlap ratio {best_ratio:.2f} (1 = beside the launch stream, 2 = behind it)',
+          flush=True)
   return best
 
 

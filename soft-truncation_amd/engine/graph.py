@@ -1166,6 +1166,12 @@ class Graph:
       KH = KW = 1
     if pad is None:
       pad = KH // 2
+    # the kernels take the channel counts from the tensors, the weight's own width is never read: a mismatch (hand-kept
+    # channel bookkeeping of the emitters) would convolve with the wrong rows of w silently -- the reference raises here
+    cin_w = weight.shape[1] if w_layout == 0 else weight.shape[0]
+    cin_x = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
+    if cin_w != cin_x:
+      raise RuntimeError(f'{name}: expected input with {cin_w} channels (weight {tuple(weight.shape)}), got {cin_x}')
     H, W = x1.shape[2], x1.shape[3]
     if out_hw is None:
       OH = (H + 2 * pad - KH) // stride + 1
@@ -1179,6 +1185,8 @@ class Graph:
   def conv1x1_t(self, x1, w_tensor, b_tensor, Cout, name='conv'):
     """1x1 convolution (NIN layout, w[Cin][Cout]) on graph tensors that stand for SEVERAL stacked parameters."""
     H, W = x1.shape[2], x1.shape[3]
+    if w_tensor.shape[0] != x1.shape[1]:
+      raise RuntimeError(f'{name}: expected input with {w_tensor.shape[0]} channels, got {x1.shape[1]}')
     return self.add(Conv(self, x1, None, w_tensor, b_tensor, 1, Cout, 1, 1, 1, 0, H, W, name=name))
 
   def linear(self, x, weight, bias, name='linear'):

@@ -117,6 +117,10 @@ class NCSNpp(nn.Module):
     channels = config.data.num_channels
     if progressive_input != 'none':
       input_pyramid_ch = channels
+    if fourier_feature and channels != 3:
+      # the reference hard-codes the stem width as channels + 12 (= 4 x 3 sin / cos channels, models/ncsnpp.py:156-159) while its
+      # FixedFouriereProjection emits 5 x channels: the two only agree for RGB, and the reference fails on its first forward
+      raise ValueError(f'model.fourier_feature needs data.num_channels == 3 (stem of channels + 12 inputs), got {channels}')
     modules.append(conv3x3(channels + 12 if fourier_feature else channels, nf))      # (models/ncsnpp.py:156-159: 12 = 4 x 3 channels)
     hs_c = [nf]
     in_ch = nf

@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import soft_truncation_amd as st
-lib = st.engine.lib.load()
+import os
+lib = st.engine.lib.load_path(os.environ['STK_LIB']) if os.environ.get('STK_LIB') else st.engine.lib.load()
 B, C, T = 128, 256, 256
 d = torch.device('cuda:0')
 q, k, v = (torch.randn(B, C, T, device=d) for _ in range(3))
