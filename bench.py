@@ -67,6 +67,8 @@ KERNEL_SYMBOL = {
   'conv3x3.fwd.x2p.k': 'x2d::gemm_kernel<9, 128, EpSlab, 1, 0>',
   'conv3x3.dgrad.x2p.k': 'x2d::gemm_kernel<9, 128, EpSlab, 1, 0>',
   'conv1x1.fwd.x2p': 'x2d::gemm_kernel<1, 128, EpFwd, 1, 0>',
+  'conv1x1.dgrad.x2p': 'x2d::gemm_kernel<1, 128, EpDgrad, 1, 0>',      # round 5: shortcut convolutions read their peer's dy planes
+  'conv1x1.dgrad.x2p.k': 'x2d::gemm_kernel<1, 128, EpSlab, 1, 0>',
   # round 3: the halo-tile GEMM (one staged halo tile of the activations per channel group serves the nine taps)
   'conv3x3.fwd.x2p.h16': 'x2d::gemm_halo_kernel<16, EpFwd, 1>', 'conv3x3.dgrad.x2p.h16': 'x2d::gemm_halo_kernel<16, EpDgrad, 1>',
   'conv3x3.fwd.x2p.h32': 'x2d::gemm_halo_kernel<32, EpFwd, 1>', 'conv3x3.dgrad.x2p.h32': 'x2d::gemm_halo_kernel<32, EpDgrad, 1>',
@@ -536,8 +538,13 @@ def exchange_proxy(st, step_fn, state, batch, steps, device, init_group=True):
   measured is everything around it, which every rank of an N-GPU run pays on top of the wire time."""
   ddp = st.engine.ddp
   made = False
+  stream_report = None
   if init_group and not dist.is_initialized():
-    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{free_port()}', rank=0, world_size=1, device_id=device)
+    # a communicator whose stream shares a hardware queue with the launch or the side stream would serialise the exchange
+    # behind the backward: probe it, and re-create the group until it runs beside both (engine/ddp.py)
+    stream_report = ddp.init_with_overlapping_exchange(
+      lambda: dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{free_port()}', rank=0, world_size=1,
+                                      device_id=device), device)
     made = True
   calls = []
   real = dist.all_reduce
@@ -547,6 +554,7 @@ def exchange_proxy(st, step_fn, state, batch, steps, device, init_group=True):
     return real(*a, **k)
 
   ddp.FORCE_SINGLE_RANK = True
+  ddp.PROXY_TRAFFIC = True        # every bucket also crosses the communicator's stream as a real device copy (ddp.py)
   dist.all_reduce = counting
   try:
     for _ in range(4):                     # first forced step runs the segments eagerly, the second captures them
@@ -561,12 +569,16 @@ def exchange_proxy(st, step_fn, state, batch, steps, device, init_group=True):
   finally:
     dist.all_reduce = real
     ddp.FORCE_SINGLE_RANK = False
+    ddp.PROXY_TRAFFIC = False
     if made:
       dist.destroy_process_group()
   per_step = len(calls) // max(steps, 1)
   return {'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'all_reduces_per_step': per_step,
           'bucket_MB': [round(4 * n / 2 ** 20, 1) for n in calls[:per_step]],
-          'backend': 'nccl (RCCL), world_size 1', 'overlapped': bool(st.losses.OVERLAP_EXCHANGE)}
+          'backend': 'nccl (RCCL), world_size 1', 'overlapped': bool(st.losses.OVERLAP_EXCHANGE),
+          'traffic': 'every bucket also copied once through the communicator\'s stream (one-rank all-gather = device copy): '
+                     'read + write of the 247 MB beside the backward',
+          'exchange_stream': stream_report}
 
 
 def free_port():
@@ -637,6 +649,7 @@ def main():
     return launch_check(world, rank, local_rank, real_stdout)
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
+  exchange_stream = None
   if world > 1:
     dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
 
@@ -663,6 +676,13 @@ def main():
   step_fn = st.losses.get_step_fn(cfg, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg))
   batch = st.datasets.synthetic_batch(cfg, per_gpu_batch, device=device,
                                       generator=torch.Generator().manual_seed(1234 + rank))
+  if world > 1:
+    # does the communicator's stream run beside the engine's launch and side streams on every rank?  (reported; a torchrun
+    # rendezvous cannot be re-created from here, so a serialised exchange shows up in the line instead of being repaired)
+    try:
+      exchange_stream = st.engine.ddp.check_exchange_stream(device)
+    except Exception as e:
+      exchange_stream = {'error': repr(e)[:200]}
 
   def sync():
     torch.cuda.synchronize()
@@ -725,6 +745,8 @@ def main():
                  'parallelism': f'dp{world}', 'loss_mean': float(losses_.mean()),
                  'hipgraph_replays': score_model.module.engine().graph_replays},
     }
+    if exchange_stream is not None:
+      out['exchange_stream'] = exchange_stream
     if proxy is not None:
       out['exchange_proxy'] = proxy
     if args.force_exchange and world == 1:

@@ -25,6 +25,12 @@ import torch.distributed as dist
 # STK_DDP_FORCE=1: run the exchange (segmented backward, bucket all-reduces, averaging) in a process group of ONE rank
 # too -- the fixed per-step cost every rank of a multi-GPU run pays, measurable on a single GPU (bench.py --force-exchange)
 FORCE_SINGLE_RANK = False
+# bench.py's exchange proxy (one rank): a one-rank all-reduce moves nothing, so nothing would stand beside the backward.  With
+# PROXY_TRAFFIC every bucket handed over also travels once through the communicator's stream as an out-of-place collective
+# (a one-rank all-gather = a device copy of the bucket: read + write of its bytes, about what a ring step's reduce-copy kernels
+# move per bucket), so the backward really shares HBM and the chip with the exchange stream.  Never set outside the proxy.
+PROXY_TRAFFIC = False
+_proxy_scratch = {}
 
 
 def is_distributed():
@@ -99,6 +105,12 @@ class OverlappedExchange:
     if hi > lo:
       self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
       self.covered.append((lo, hi))
+      if PROXY_TRAFFIC and dist.get_world_size(self.group) == 1:
+        g = self.flat.grad
+        buf = _proxy_scratch.get(g.device)
+        if buf is None or buf.numel() < self.flat.n_train:
+          buf = _proxy_scratch[g.device] = torch.empty(self.flat.n_train, dtype=g.dtype, device=g.device)
+        self.handles.append(dist.all_gather_into_tensor(buf[lo:hi], g[lo:hi], group=self.group, async_op=True))
 
   def finish(self, average=True):
     """Reduce the ranges no segment handed over (a backward that never ran, unused parameters), wait, average."""
@@ -196,6 +208,109 @@ def reset_poison():
   """After the process group has been re-created on every rank."""
   global _poisoned
   _poisoned = None
+
+
+# ---- does the exchange really run BESIDE the backward? ---------------------------------------------------------------------
+# HIP serves its streams from a few hardware queues; two streams on one queue run strictly one after the other (engine/
+# executor.py: checked_side_stream, profiles/r04_side_stream_queue.txt).  ProcessGroupNCCL draws the stream its collectives run
+# on from the same torch pool as the engine's side stream, and it offers no handle on it -- a communicator whose stream landed
+# on the launch stream's queue (or the side stream's) would serialise every "overlapped" bucket all-reduce behind the
+# backward it is meant to hide under, invisibly on one GPU and at the cost of the whole design on eight.  The probe below
+# needs no handle: it keeps one stream busy with a spin kernel and asks whether a collective issued meanwhile (from a third,
+# idle stream) completes before the spin ends.
+
+def _spin_cycles(device, ms):
+  """torch.cuda._sleep argument for about `ms` milliseconds on this device (calibrated once per call)."""
+  s = torch.cuda.current_stream(device)
+  a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  torch.cuda._sleep(1000)
+  a.record(s)
+  torch.cuda._sleep(2_000_000)
+  b.record(s)
+  b.synchronize()
+  per_ms = 2_000_000 / max(a.elapsed_time(b), 1e-3)
+  return int(per_ms * ms)
+
+
+def collective_runs_beside(busy, device, group=None, numel=8 << 20, spin_ms=40.0):
+  """True when a collective of the process group completes WHILE `busy` (a torch stream) is occupied by a spin kernel, i.e.
+  the communicator's stream is served by another hardware queue.  Every rank of the group must call this together (the probe
+  is an all-gather of `numel` floats -- with one rank RCCL turns it into a device copy on the communicator's stream, with
+  several into its usual kernels).  Returns (beside, seconds the collective took to complete, spin seconds)."""
+  import time
+  from .executor import _overlap_ratio
+  ws = dist.get_world_size(group)
+  src = torch.ones(numel, device=device)
+  dst = torch.empty(numel * ws, device=device)
+  issue = None
+  for _ in range(16):                       # an idle stream that itself runs beside `busy`
+    cand = torch.cuda.Stream(device)
+    if cand.cuda_stream != busy.cuda_stream and _overlap_ratio(busy, cand) < 1.5:
+      issue = cand
+      break
+  if issue is None:
+    raise RuntimeError('no pooled stream runs beside the given one: cannot probe the exchange stream')
+  with torch.cuda.stream(issue):            # first use creates the communicator's stream / connections: not timed
+    dist.all_gather_into_tensor(dst, src, group=group)
+  torch.cuda.synchronize(device)
+  cycles = _spin_cycles(device, spin_ms)
+  spin_done, coll_done = torch.cuda.Event(), torch.cuda.Event()
+  with torch.cuda.stream(busy):
+    torch.cuda._sleep(cycles)
+    spin_done.record(busy)
+  t0 = time.perf_counter()
+  with torch.cuda.stream(issue):
+    work = dist.all_gather_into_tensor(dst, src, group=group, async_op=True)
+    work.wait()                             # stream-level: `issue` waits for the communicator's stream
+    coll_done.record(issue)
+  beside, t_coll = False, None
+  while True:
+    c, sdone = coll_done.query(), spin_done.query()
+    if c and t_coll is None:
+      t_coll = time.perf_counter() - t0
+      beside = not sdone
+    if sdone and c:
+      break
+    if time.perf_counter() - t0 > 30.0:
+      raise RuntimeError('exchange-stream probe timed out')
+  t_spin = time.perf_counter() - t0
+  torch.cuda.synchronize(device)
+  return beside, t_coll, t_spin
+
+
+def check_exchange_stream(model_or_device, group=None):
+  """The communicator's stream against the engine's launch stream and its side stream: {'beside_main', 'beside_side', 'ok'}
+  (agreed over all ranks: `ok` is the minimum).  Call once after init_process_group, on every rank, before training."""
+  from .executor import checked_side_stream
+  if isinstance(model_or_device, torch.device):
+    device = model_or_device
+  else:
+    device = next(model_or_device.parameters()).device
+  main = torch.cuda.current_stream(device)
+  side = checked_side_stream(device)
+  bm, tm, sm = collective_runs_beside(main, device, group)
+  bs, ts, ss = collective_runs_beside(side, device, group)
+  flag = torch.tensor([1.0 if (bm and bs) else 0.0], device=device)
+  dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+  return {'beside_main': bool(bm), 'beside_side': bool(bs), 'ok': bool(flag.item() > 0.5),
+          'collective_ms': [round(1e3 * tm, 3), round(1e3 * ts, 3)], 'spin_ms': [round(1e3 * sm, 2), round(1e3 * ss, 2)]}
+
+
+def init_with_overlapping_exchange(init_fn, device, tries=6):
+  """init_fn() -> creates the default process group (dist.init_process_group(...), same call on every rank).  Creates it, probes
+  the communicator's stream, and -- while some rank reports that it shares a hardware queue with the engine's launch or side
+  stream -- destroys the group, draws one pooled stream (so the next communicator gets the next one of torch's round robin)
+  and creates it again.  Returns the last report with the number of attempts."""
+  report = None
+  for attempt in range(1, tries + 1):
+    init_fn()
+    report = check_exchange_stream(device)
+    report['attempts'] = attempt
+    if report['ok'] or attempt == tries:
+      return report
+    dist.destroy_process_group()
+    torch.cuda.Stream(device)               # shift the pool's round robin by one
+  return report
 
 
 def sync_gradients(optimizer, params=None, bucket_mb=64.0):

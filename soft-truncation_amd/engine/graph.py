@@ -466,6 +466,11 @@ class Conv(Op):
   # (stk_gn_bwd_out_f32 dx1_add), so this layer's backward does not touch d(res)
   res_via = None
   x_from = None        # Graph._plan_x_records: the GroupNorm whose forward leaves this layer's |x1| / |x2| records behind
+  # Graph._plan_shared_dy: a 1x1 shortcut convolution differentiates from its peer's output gradient -- and that gradient
+  # already exists as planes (the peer's 3x3 data / weight gradient made them): its data gradient reads THOSE through the LDS-
+  # DMA kernel instead of splitting the fp32 tensor again in its loader.  'own' = the peer keeps its dy planes (two streams),
+  # 'scratch' = the context's shared scratch, still holding them when this layer's backward runs right after the peer's
+  peer_planes = None
 
   # planes (include/stk.h "Planes"): decided by Graph.finalize
   dypl_off = None      # byte offset of this layer's own dy planes in the planes arena (side-stream weight gradients)
@@ -616,7 +621,14 @@ class Conv(Op):
       dypl = rt.pl + self.dypl_off if self.dypl_off is not None else rt.dypl
       lib.split_planes_f32(gy, self.N, self.Cout, self.OH * self.OW, rec, 256, dypl, rt.stream)
       have |= 2
-    if pl_dgrad:
+    if src is not None and self.peer_planes is not None and (g1 is not None or g2 is not None):
+      # the peer's dy planes (and the record they were scaled with) serve this 1x1 data gradient too
+      ppl = rt.pl + src.dypl_off if self.peer_planes == 'own' else rt.dypl
+      rt.timed(self._label_pl(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_pl_f32,
+               ppl, rt.v(self.amax) + 4 * 512, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
+               g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
+               alpha, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self._wp(rt, 1), rt.ws, rt.ws_bytes, rt.stream)
+    elif pl_dgrad:
       rt.timed(self._label_pl(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_pl_f32,
                dypl, rec, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
@@ -1388,6 +1400,13 @@ class Graph:
       if P.pl_dgrad or P.pl_wgrad or P.Cout != op.Cout:
         continue
       op.dy_peer, P.dy_from = P, op
+      if (os.environ.get('STK_SC_PEER_PLANES', '1') != '0' and (P.x1.needs_grad or (P.x2 is not None and P.x2.needs_grad)) and
+          hasattr(lib, 'conv2d_pl_ok') and
+          int(lib.conv2d_pl_ok(1, P.C1, P.C2, P.N, P.H, P.W, P.Cout, P.KH, P.KW, 1, P.pad))):
+        if op.dypl_off is not None:
+          P.peer_planes = 'own'
+        elif not self.own_dypl and self.ops.index(P) + 1 == self.ops.index(op):
+          P.peer_planes = 'scratch'
 
   def _plan_f32_copies(self, lib):
     """For every GroupNorm output that is made as planes: who still reads its fp32 NCHW copy?  A convolution whose

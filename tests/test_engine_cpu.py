@@ -294,6 +294,8 @@ def test_shortcut_convolution_shares_the_block_output_gradient(st, ref_lib, monk
   convs = [op for pr in model.module.engine().programs.values() for op in pr.graph.ops if isinstance(op, G.Conv)]
   pairs = [(op, op.dy_peer) for op in convs if op.dy_peer is not None]
   assert pairs and all(p.dy_from is c and p.KH == 1 and c.KH == 3 for c, p in pairs)
+  # round 5: the shortcut's data gradient reads the dy planes its peer's split pass made (Conv.peer_planes; 'scratch' on one stream)
+  assert any(p.peer_planes == 'scratch' for c, p in pairs), [p.peer_planes for c, p in pairs]
   shared = [p.grad.clone() for p in model.parameters()]
   monkeypatch.setenv('STK_SHARED_DY', '0')
   model.module.engine().programs.clear()

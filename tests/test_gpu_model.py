@@ -127,10 +127,18 @@ def test_train_steps_with_rccl_process_group(st, hip_lib, monkeypatch):
   import torch.distributed as dist
   from importlib import import_module
   ddp = import_module('soft-truncation_amd.engine.ddp')
-  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-  dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
-                          device_id=torch.device('cuda:0'))
+  def init():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                            device_id=torch.device('cuda:0'))
+
+  # Exchange-stream readiness: the communicator's stream must run BESIDE the engine's launch stream and its side stream (a
+  # shared hardware queue would serialise every overlapped bucket all-reduce behind the backward); the group is re-created
+  # until the probe says so (engine/ddp.py: init_with_overlapping_exchange).
+  report = ddp.init_with_overlapping_exchange(init, torch.device('cuda:0'))
+  print('exchange stream:', report)
   try:
+    assert report['ok'] and report['beside_main'] and report['beside_side'], report
     calls = []
     real = dist.all_reduce
 
