@@ -296,20 +296,50 @@ def check_exchange_stream(model_or_device, group=None):
           'collective_ms': [round(1e3 * tm, 3), round(1e3 * ts, 3)], 'spin_ms': [round(1e3 * sm, 2), round(1e3 * ss, 2)]}
 
 
-def init_with_overlapping_exchange(init_fn, device, tries=6):
-  """init_fn() -> creates the default process group (dist.init_process_group(...), same call on every rank).  Creates it, probes
-  the communicator's stream, and -- while some rank reports that it shares a hardware queue with the engine's launch or side
-  stream -- destroys the group, draws one pooled stream (so the next communicator gets the next one of torch's round robin)
-  and creates it again.  Returns the last report with the number of attempts."""
+def _steer_stream_pool(device, main, side):
+  """Leave torch's stream pool in a state where the NEXT stream it hands out runs beside both `main` and `side`.  The pool is a
+  ring (32 streams per priority, handed out round robin) and HIP fixes a stream's hardware queue when it creates it, so:
+  draw until a candidate overlaps with both, then draw (ring period - 1) more -- the next draw returns that very stream
+  again.  ProcessGroupNCCL takes its stream from this ring when it creates a communicator.  (Re-creating the group and
+  hoping does not work: every attempt advances the ring by a fixed number of draws -- the probe's own candidates, the
+  communicator's, the burn -- and four draws land on the same hardware queue again: measured, six attempts, six times the
+  side stream's queue.)  Returns True when a candidate was found."""
+  from .executor import _overlap_ratio
+  first = torch.cuda.Stream(device)
+  period = None
+  for i in range(1, 129):                   # ring period: draws until the first handle comes back
+    if torch.cuda.Stream(device).cuda_stream == first.cuda_stream:
+      period = i
+      break
+  if period is None:
+    return False
+  for _ in range(period):
+    c = torch.cuda.Stream(device)
+    if c.cuda_stream in (main.cuda_stream, side.cuda_stream):
+      continue
+    if _overlap_ratio(main, c) < 1.5 and _overlap_ratio(side, c) < 1.5:
+      for _ in range(period - 1):
+        torch.cuda.Stream(device)
+      return True
+  return False
+
+
+def init_with_overlapping_exchange(init_fn, device, tries=3):
+  """init_fn() -> creates the default process group (dist.init_process_group(...), same call on every rank).  Steers torch's
+  stream pool so that the communicator's stream lands on a hardware queue of its own (_steer_stream_pool), creates the group
+  and probes it; while some rank still reports a shared queue the group is destroyed and the procedure repeated.  Returns
+  the last report with the number of attempts."""
+  from .executor import checked_side_stream
   report = None
   for attempt in range(1, tries + 1):
+    steered = _steer_stream_pool(device, torch.cuda.current_stream(device), checked_side_stream(device))
     init_fn()
     report = check_exchange_stream(device)
     report['attempts'] = attempt
+    report['pool_steered'] = bool(steered)
     if report['ok'] or attempt == tries:
       return report
     dist.destroy_process_group()
-    torch.cuda.Stream(device)               # shift the pool's round robin by one
   return report
 
 

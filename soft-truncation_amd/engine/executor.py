@@ -61,6 +61,8 @@ class _GnFoldDesc(ctypes.Structure):       # StkGnFoldDesc of include/stk.h
 # gradients.  The guard turns that launch-order argument into a check: any ATen operator on a device tensor dispatched
 # inside the window (a hook, a logging op, a future torch call inside an op) raises.
 _LIB_ONLY = os.environ.get('STK_LIB_ONLY', '1' if _POISON else '0') == '1'
+# STK_WP_SIDE=0: the data-gradient weight blocks are prepared in front of the forward with the forward blocks (A/B switch)
+_WP_SIDE = os.environ.get('STK_WP_SIDE', '1') != '0'
 
 from torch.utils._python_dispatch import TorchDispatchMode
 
@@ -255,6 +257,7 @@ class Program:
     self.gnpart = None
     self.gn_table = None
     self.gn_maxc = 0
+    self.wp_dgrad_ready = None   # event of the side-stream preparation of the data-gradient weight blocks (Executor._prepare_weights)
 
   def build_gn_folds(self, gparam_base):
     g = self.graph
@@ -477,7 +480,23 @@ class Executor:
     n = prog.wp_counts[1 if need_dgrad else 0]
     if n == 0 or (self._frozen and prog.wp_frozen >= n):
       return
-    self.lib.conv2d_wprep_batch(prog.wp_table.data_ptr(), n, prog.wp_items, stk_lib.stream_ptr(self.flat.device))
+    n_fwd = prog.wp_counts[0]
+    dev = self.flat.device
+    if (need_dgrad and n > n_fwd > 0 and self.use_side and _WP_SIDE and not self._frozen and
+        not torch.cuda.is_current_stream_capturing()):
+      # the data-gradient blocks are first read by the backward: prepare them on the side stream, beside the forward
+      # (an HBM-bound re-layout of 250 MB beside matrix-pipe-bound GEMMs) instead of in front of it; the backward waits
+      # for the event (Program.wp_dgrad_ready) before its first launch
+      if self._side is None or self._side.device != dev:
+        self._side = SideStream(dev)
+      self.lib.conv2d_wprep_batch(prog.wp_table.data_ptr(), n_fwd, prog.wp_items, stk_lib.stream_ptr(dev))
+      s = self._side.begin()              # behind everything launched so far: the optimizer update of the last step
+      self.lib.conv2d_wprep_batch(prog.wp_table.data_ptr() + ctypes.sizeof(_WprepDesc) * n_fwd, n - n_fwd, prog.wp_items, s)
+      prog.wp_dgrad_ready = self._side.end()
+      self._side.last = None              # not a join target of the backward's fork / join: the event is waited for explicitly
+    else:
+      prog.wp_dgrad_ready = None
+      self.lib.conv2d_wprep_batch(prog.wp_table.data_ptr(), n, prog.wp_items, stk_lib.stream_ptr(dev))
     prog.wp_frozen = n if self._frozen else 0
 
   @contextlib.contextmanager
@@ -622,6 +641,8 @@ class Executor:
       c.gact = _arena(g.gact_size, prog.device)
     o = g.output
     c.gact[o.goff:o.goff + o.numel].view(o.shape).copy_(gout)
+    if prog.wp_dgrad_ready is not None:                 # data-gradient weight blocks prepared on the side stream
+      torch.cuda.current_stream(flat.device).wait_event(prog.wp_dgrad_ready)
     done = False
     hook = self.grad_hook if param_grads else None      # nothing to exchange after an input-gradient-only backward
     if hook is not None and len(self._awaiting) > 0:
