@@ -53,12 +53,15 @@ def main():
   ap.add_argument('--batch', type=int, default=128)
   ap.add_argument('--tag', default=os.environ.get('STK_PL_KERNEL', 'default'))
   ap.add_argument('--only', default='')
+  ap.add_argument('--shapes', default='', help='comma-separated C1xHxCout 3x3 shapes instead of the built-in list, e.g. 256x32x256,512x8x256')
   args = ap.parse_args()
   lib = st.engine.lib.load()
   d = torch.device('cuda:0')
   N = args.batch
   shapes = [(128, 32, 128, 3), (256, 16, 256, 3), (384, 32, 128, 3), (512, 16, 256, 3), (128, 16, 256, 3),
             (256, 8, 256, 3), (512, 8, 256, 3), (256, 4, 256, 3), (512, 4, 256, 3), (256, 16, 768, 1)]
+  if args.shapes:
+    shapes = [tuple(int(v) for v in t.split('x')) + (3,) for t in args.shapes.split(',')]
   lines = []
   for C1, H, Cout, K in shapes:
     if args.only and f'{C1}x{H}' not in args.only.split(','):
