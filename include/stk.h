@@ -272,6 +272,9 @@ int stk_conv2d_fwd_pl_f32(const void* xpl, const float* xamax, int C, const floa
 /* K splits of the plane-operand forward (dir 0) / data-gradient (dir 1) call of a shape: 1 = one GEMM launch, > 1 =
  * partial slabs + a slab-sum launch (small maps), 0 = the shape does not take plane operands (diagnostic: kernel labels) */
 int stk_conv2d_pl_ksplit(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW);
+/* output-channel x pixel tile of that call's kernel: 128, or 64 = the small-tile halo GEMM of the problems whose 128 x 128
+ * tiles would not fill the chip (8x8 / 4x4 maps; every level below 64x64 at batch 4), 0 = no plane operands (diagnostic) */
+int stk_conv2d_pl_tile(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW);
 /* map width W when that call runs on the halo-tile GEMM (one staged halo tile of the activations per channel group serves the
  * nine taps: 16 / 32 / 64-wide maps of whole 128-pixel tiles, no K split), else 0 (diagnostic: kernel labels) */
 int stk_conv2d_pl_halo(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW);

@@ -981,9 +981,9 @@ inline int fill_common(ConvP& p, int N, int H, int W, int C1, int C2, int Cout, 
 // 192 tiles of 128 x 128 a workgroup owns a whole output tile.  Smaller problems (the 8x8 and 4x4 maps: 128 / 32
 // tiles at batch 128, where one workgroup per CU has nothing to overlap with) are split over K into partial slabs
 // that a second kernel sums in a fixed order and finishes with the usual epilogue.
-struct X3Plan { int ok; int splits; int chunks_per_split; long slab; };
+struct X3Plan { int ok; int splits; int chunks_per_split; long slab; int t64; int gps; };
 inline X3Plan x3_plan(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
-  X3Plan r = {0, 1, 0, 0};
+  X3Plan r = {0, 1, 0, 0, 0, 0};
   const long big = (long)p.N * p.HW * 4 * (S1 > S2 ? S1 : S2);       // buffer loads: 32-bit byte offsets, bit 31 = dead lane
   const bool geom = (p.taps == 9 && p.pad == 1) || (p.taps == 1 && p.pad == 0);
   if (!(big < 0x7fffffffL && geom && p.stride == 1 && p.OH == p.H && p.OW == p.W && Kc % 32 == 0 &&
@@ -1009,6 +1009,20 @@ inline X3Plan x3_plan(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
   r.splits = (nch + r.chunks_per_split - 1) / r.chunks_per_split;
   r.slab = (long)M * Ng;
   r.ok = 1;
+  return r;
+}
+// Plan of a PLANE-operand call (single source): the small-tile kernel (x2d::gemm_halo64_kernel, conv_x2d.h) where 128 x 128
+// tiles would not fill the chip, else the plan above.  Only shapes the plan above takes (stk_conv2d_pl_ok stays as it was).
+inline X3Plan x3_plan_pl(const ConvP& p, int Kc, int M, long Ng) {
+  X3Plan r = x3_plan(p, Kc, Kc, 0, M, Ng);
+  if (!r.ok) return r;
+  const x2d::T64Plan t = x2d::t64_plan(p, p.taps, Kc, M, Ng);
+  if (!t.ok) return r;
+  r.splits = t.splits;
+  r.gps = t.groups_per_split;
+  r.chunks_per_split = t.groups_per_split * 9;
+  r.slab = t.splits > 1 ? (long)M * Ng : 0;
+  r.t64 = 1;
   return r;
 }
 inline long x3_ws_bytes(const X3Plan& r, int M, int Kc, int taps) {
@@ -1143,6 +1157,29 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
   if (planes) { if (p.taps == 9) { STK_PL_LAUNCH(E, 9); } else { STK_PL_LAUNCH(E, 1); } }                         \
   else if (p.taps == 9) { if (S2 > 0) STK_X2_LAUNCH(E, true, 9); else STK_X2_LAUNCH(E, false, 9); }               \
   else { if (S2 > 0) STK_X2_LAUNCH(E, true, 1); else STK_X2_LAUNCH(E, false, 1); }
+    if (planes && r.t64) {
+      // small tiles (64 x 64), K split over whole channel groups (conv_x2d.h)
+      const int tm6 = stk_cdiv(M, 64), tn6 = stk_cdiv((int)Ng, 64), ngroups = q.Kc / x3::KC;
+      const dim3 g6((unsigned)(tm6 * tn6 * r.splits));
+#define STK_T64_LAUNCH(E)                                                                                         \
+  switch (p.W) {                                                                                                  \
+    case 4: hipLaunchKernelGGL((x2d::gemm_halo64_kernel<4, E>), g6, dim3(256), 0, s, p, q, M, (int)Ng, tm6, tn6, ngroups, r.gps, xpart, nx); break; \
+    case 8: hipLaunchKernelGGL((x2d::gemm_halo64_kernel<8, E>), g6, dim3(256), 0, s, p, q, M, (int)Ng, tm6, tn6, ngroups, r.gps, xpart, nx); break; \
+    case 16: hipLaunchKernelGGL((x2d::gemm_halo64_kernel<16, E>), g6, dim3(256), 0, s, p, q, M, (int)Ng, tm6, tn6, ngroups, r.gps, xpart, nx); break; \
+    default: hipLaunchKernelGGL((x2d::gemm_halo64_kernel<32, E>), g6, dim3(256), 0, s, p, q, M, (int)Ng, tm6, tn6, ngroups, r.gps, xpart, nx); break; \
+  }
+      if (r.splits == 1) {
+        STK_T64_LAUNCH(EP)
+        STK_CHECK_LAUNCH();
+        return STK_OK;
+      }
+      STK_T64_LAUNCH(EpSlab)
+#undef STK_T64_LAUNCH
+      STK_CHECK_LAUNCH();
+      launch_slab_sum(p, r.splits, M, Ng, dgrad, s);
+      STK_CHECK_LAUNCH();
+      return STK_OK;
+    }
     if (r.splits == 1) {
       STK_X2_LAUNCH_E(EP)
       STK_CHECK_LAUNCH();
@@ -1487,7 +1524,17 @@ int stk_conv2d_pl_ksplit(int dir, int C1, int C2, int N, int H, int W, int Cout,
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, 1, KH / 2)) return 0;
   const long Ng = (long)N * p.HW;
-  return dir == 0 ? x3_plan(p, p.Cin, C1, 0, Cout, Ng).splits : x3_plan(p, Cout, Cout, 0, p.Cin, Ng).splits;
+  return dir == 0 ? x3_plan_pl(p, p.Cin, Cout, Ng).splits : x3_plan_pl(p, Cout, p.Cin, Ng).splits;
+}
+
+/* output-channel x pixel tile of the plane-operand forward (dir 0) / data-gradient (dir 1) kernel of this shape: 128 (x2d::gemm_kernel,
+ * gemm_halo_kernel) or 64 (x2d::gemm_halo64_kernel, the small-tile form of the small problems); 0 = no plane operands.  Diagnostic. */
+int stk_conv2d_pl_tile(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW) {
+  if (!stk_conv2d_pl_ok(dir, C1, C2, N, H, W, Cout, KH, KW, 1, KH / 2)) return 0;
+  ConvP p = {};
+  if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, 1, KH / 2)) return 0;
+  const long Ng = (long)N * p.HW;
+  return (dir == 0 ? x3_plan_pl(p, p.Cin, Cout, Ng).t64 : x3_plan_pl(p, Cout, p.Cin, Ng).t64) ? 64 : 128;
 }
 
 int stk_conv2d_fwd_pl_f32(const void* xpl, const float* xamax, int C, const float* w, int w_layout, const float* bias,
@@ -1501,7 +1548,7 @@ int stk_conv2d_fwd_pl_f32(const void* xpl, const float* xamax, int C, const floa
   p.w = w; p.w_layout = w_layout; p.bias = bias; p.temb = temb; p.temb_stride = temb_stride; p.res = res;
   p.inv_div = 1.f / out_div; p.use_div = out_div != 1.f; p.y = y;
   const long Ng = (long)N * p.HW;
-  const X3Plan xr = x3_plan(p, C, C, 0, Cout, Ng);
+  const X3Plan xr = x3_plan_pl(p, C, Cout, Ng);
   if (!ws || ws_bytes < x3_ws_bytes(xr, Cout, C, p.taps)) return STK_EINVAL;
   return launch_x3<EpFwd>(p, xr, nullptr, C, nullptr, 0, Cout, Ng, 0, ws, (hipStream_t)stream, wp, nullptr, xpl, xamax);
 }
@@ -1517,7 +1564,7 @@ int stk_conv2d_dgrad_pl_f32(const void* dypl, const float* dyamax, const float* 
   p.w = w; p.w_layout = w_layout; p.dx1 = dx1; p.dx2 = C2 > 0 ? dx2 : nullptr;
   p.beta1 = beta1; p.beta2 = beta2; p.alpha = alpha;
   const long Ng = (long)N * p.HW;
-  const X3Plan xr = x3_plan(p, Cout, Cout, 0, p.Cin, Ng);
+  const X3Plan xr = x3_plan_pl(p, Cout, p.Cin, Ng);
   if (!ws || ws_bytes < x3_ws_bytes(xr, p.Cin, Cout, p.taps)) return STK_EINVAL;
   return launch_x3<EpDgrad>(p, xr, nullptr, Cout, nullptr, 0, p.Cin, Ng, 1, ws, (hipStream_t)stream, wp, nullptr, dypl, dyamax);
 }
@@ -1572,7 +1619,7 @@ int stk_conv2d_wgrad_pl_f32(const void* xpl, const float* xrec, const void* dypl
  * shape runs on, 0 = x2d::gemm_kernel (diagnostic: one profiler label per kernel symbol) */
 int stk_conv2d_pl_halo(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW) {
   const int ks = stk_conv2d_pl_ksplit(dir, C1, C2, N, H, W, Cout, KH, KW);
-  if (ks <= 0 || pl::kernel_choice() != 4) return 0;
+  if (ks <= 0 || pl::kernel_choice() != 4 || stk_conv2d_pl_tile(dir, C1, C2, N, H, W, Cout, KH, KW) == 64) return 0;
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, 1, KH / 2)) return 0;
   return x2d::halo_ok(p, p.taps, ks) ? x2d::halo_cols(W) : 0;
@@ -1656,13 +1703,17 @@ int stk_conv2d_wprep_batch(const StkWprepDesc* descs_dev, int n, long max_items,
 long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, stride, pad)) return 0;
-  return x3_ws_bytes(x3_plan(p, C1 + C2, C1, C2, Cout, (long)N * H * W), Cout, C1 + C2, p.taps);
+  const long a = x3_ws_bytes(x3_plan(p, C1 + C2, C1, C2, Cout, (long)N * H * W), Cout, C1 + C2, p.taps);
+  const long b = C2 == 0 ? x3_ws_bytes(x3_plan_pl(p, C1, Cout, (long)N * H * W), Cout, C1, p.taps) : 0;      // the plane-operand plan
+  return a > b ? a : b;
 }
 
 long stk_conv2d_dgrad_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, stride, pad)) return 0;
-  return x3_ws_bytes(x3_plan(p, Cout, Cout, 0, C1 + C2, (long)N * H * W), C1 + C2, Cout, p.taps);
+  const long a = x3_ws_bytes(x3_plan(p, Cout, Cout, 0, C1 + C2, (long)N * H * W), C1 + C2, Cout, p.taps);
+  const long b = x3_ws_bytes(x3_plan_pl(p, Cout, C1 + C2, (long)N * H * W), C1 + C2, Cout, p.taps);
+  return a > b ? a : b;
 }
 
 long stk_conv2d_wgrad_ws_bytes(int C1, int C2, int N, int Cout, int OH, int OW, int KH, int KW) {

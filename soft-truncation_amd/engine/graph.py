@@ -416,9 +416,12 @@ class Conv(Op):
       elif hasattr(lib, 'conv2d_pl_ksplit'):
         d = 0 if direction == 'fwd' else 1
         c2 = 0 if d == 0 else self.C2
+        t64 = hasattr(lib, 'conv2d_pl_tile') and int(lib.conv2d_pl_tile(d, self.C1, c2, self.N, self.H, self.W, self.Cout, self.KH, self.KW)) == 64
+        if t64:
+          k += '.t64'                # x2d::gemm_halo64_kernel (round 5): 64 x 64 tiles where the large ones would not fill the chip
         if int(lib.conv2d_pl_ksplit(d, self.C1, c2, self.N, self.H, self.W, self.Cout, self.KH, self.KW)) > 1:
           k += '.k'
-        elif hasattr(lib, 'conv2d_pl_halo'):
+        elif not t64 and hasattr(lib, 'conv2d_pl_halo'):
           hw = int(lib.conv2d_pl_halo(d, self.C1, c2, self.N, self.H, self.W, self.Cout, self.KH, self.KW))
           if hw:
             k += f'.h{hw}'

@@ -39,6 +39,7 @@ SIGNATURES = {
   'stk_gn_bwd_out_ok': [I, I, I, I],
   'stk_conv2d_pl_ksplit': [I, I, I, I, I, I, I, I, I],
   'stk_conv2d_pl_halo': [I, I, I, I, I, I, I, I, I],
+  'stk_conv2d_pl_tile': [I, I, I, I, I, I, I, I, I],
   'stk_gn_bwd_out_f32': [P, P, I, P, I, P, P, P, P, P, F, P, F, P, P, P, I, I, I, I, F, U64, P, P, F, P, F, P, I, P, S],
   'stk_gn_param_grad_batch': [P, I, I, S],
   'stk_conv2d_variant': [I, I, I, I, I, I, I, I, I, I, I, I, I, I],
@@ -110,7 +111,7 @@ SIGNATURES = {
 _RESTYPE = {'stk_strerror': c_char_p, 'stk_backend': c_char_p, 'stk_conv2d_wgrad_ws_bytes': c_long,
             'stk_conv2d_fwd_ws_bytes': c_long, 'stk_conv2d_dgrad_ws_bytes': c_long, 'stk_gn_ws_bytes': c_long,
             'stk_conv2d_wp_bytes': c_long, 'stk_conv2d_wp_desc': c_long, 'stk_planes_bytes': c_long, 'stk_conv2d_wgrad_pl_ws_bytes': c_long}
-_NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant', 'stk_conv2d_pl_ok', 'stk_gn_fwd_pl_fused', 'stk_conv2d_wgrad_pl_ok', 'stk_attention_ok', 'stk_gn_bwd_out_ok', 'stk_conv2d_pl_ksplit', 'stk_conv2d_pl_halo'}
+_NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant', 'stk_conv2d_pl_ok', 'stk_gn_fwd_pl_fused', 'stk_conv2d_wgrad_pl_ok', 'stk_attention_ok', 'stk_gn_bwd_out_ok', 'stk_conv2d_pl_ksplit', 'stk_conv2d_pl_halo', 'stk_conv2d_pl_tile'}
 
 
 class StkMissingError(RuntimeError):

@@ -103,6 +103,16 @@ PL_CONV_CASES = [
   (96, 256, 16, 16, 256, 1, 1, 0, 0, 0),    # NIN
   (5, 128, 12, 20, 160, 3, 0, 0, 0, 0),     # ragged map, 160 rows
 ]
+# round 5: shapes of the small-tile kernel (x2d::gemm_halo64_kernel: 64 x 64 tiles, halo staging, K split over channel groups)
+T64_CASES = [
+  (128, 256, 8, 8, 256, 3, 0, 1, 1, 1),     # 8x8 at batch 128: 512 tiles, no K split
+  (4, 256, 32, 32, 256, 3, 0, 1, 0, 1),     # 32x32 at batch 4 (two map rows per tile): 256 tiles, no split
+  (4, 512, 16, 16, 256, 3, 0, 0, 1, 0),     # 16x16 at batch 4: K split over channel groups
+  (37, 256, 4, 4, 192, 3, 0, 1, 1, 1),      # 4x4: four images per tile, a ragged last tile (592 pixels), 192 rows
+  (6, 128, 8, 16, 128, 3, 0, 0, 0, 0),      # 16 wide, 8 high
+  (2, 96, 8, 8, 96, 3, 0, 1, 1, 1),         # the 'wide' test family's channel count (96 rows: a half-empty second row tile)
+]
+PL_CONV_CASES = PL_CONV_CASES + T64_CASES
 
 
 @pytest.mark.gpu
@@ -122,6 +132,8 @@ def test_conv_from_planes(ref_lib, hip_lib, case):
   assert int(hip_lib.conv2d_pl_ok(0, C, 0, N, H, W, Cout, K, K, 1, K // 2)) == 1
   assert int(ref_lib.conv2d_pl_ok(0, C, 0, N, H, W, Cout, K, K, 1, K // 2)) == 1
   assert int(hip_lib.conv2d_pl_ok(1, C, 0, N, H, W, Cout, K, K, 1, K // 2)) == 1
+  if case in T64_CASES:
+    assert int(hip_lib.conv2d_pl_tile(0, C, 0, N, H, W, Cout, K, K)) == 64 and int(hip_lib.conv2d_pl_tile(1, C, 0, N, H, W, Cout, K, K)) == 64
 
   def run(lib):
     d = dev_of(lib)
@@ -156,6 +168,35 @@ def test_conv_from_planes(ref_lib, hip_lib, case):
     scale = r[k].abs().max().item()
     assert (h[k] - r[k]).abs().max().item() <= 1e-4 * scale, k
     assert (h[k] - h[k + '32']).abs().max().item() <= 2e-5 * scale, k + ' vs the fp32-input call'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(16, 128, 128, 8, 8, 256), (5, 256, 128, 4, 4, 128), (4, 128, 256, 16, 16, 256)], ids=str)
+def test_small_tile_data_gradient_into_two_sources(ref_lib, hip_lib, case):
+  """The small-tile kernel's data gradient with the rows routed to the two sources of a concatenation (the first convolution of
+  an up-path block, ncsnpp.py:368): dx1 overwritten, dx2 accumulated, against the oracle."""
+  N, C1, C2, H, W, Cout = case
+  dy = rnd(N, Cout, H, W, seed=7)
+  w = rnd(Cout, C1 + C2, 3, 3, seed=3) / np.sqrt((C1 + C2) * 9.)
+  g2 = rnd(N, C2, H, W, seed=9)
+  assert int(hip_lib.conv2d_pl_tile(1, C1, C2, N, H, W, Cout, 3, 3)) == 64
+  out = {}
+  for name, lib in (('ref', ref_lib), ('hip', hip_lib)):
+    d = dev_of(lib)
+    shape = (C1, C2, N, H, W, Cout, 3, 3, 1, 1)
+    fb = max(int(lib.conv2d_dgrad_ws_bytes(*shape)), 256)
+    ws = torch.zeros(fb // 4 + 64, device=d)
+    ay = torch.zeros(256, device=d)
+    dyd = dy.to(d)
+    call(lib, 'amax_partial_f32', dyd, dyd.numel(), ay)
+    yp = torch.zeros(int(lib.planes_bytes(N, Cout, H * W)), dtype=torch.uint8, device=d)
+    call(lib, 'split_planes_f32', dyd, N, Cout, H * W, ay, 256, yp)
+    dx1 = torch.full((N, C1, H, W), float('nan'), device=d)
+    dx2 = g2.clone().to(d)
+    call(lib, 'conv2d_dgrad_pl_f32', yp, ay, w.to(d), 0, dx1, C1, 0.0, dx2, C2, 1.0, 0.7, N, H, W, Cout, 3, 3, None, ws, fb)
+    out[name] = (dx1.cpu(), dx2.cpu())
+  for a, b in zip(out['hip'], out['ref']):
+    assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
 
 
 @pytest.mark.gpu
