@@ -116,7 +116,9 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
  *           up to two bias gradients (a convolution's and its shortcut peer's) are one more entry of that fold;
  *   dtemb   [n*temb_stride + c] = out_scale * sum_hw dx1[n,c,:]  (the time-embedding projection's gradient, written);
  *   dx_amax [256]: a planes scale record of dx1 by atomic maximum -- the caller ZEROES it before the launch
- *           (stk_fill_strided_f32), max(dx_amax[0..256)) = max |dx1| afterwards.
+ *           (stk_fill_strided_f32), max(dx_amax[0..256)) = max |dx1| afterwards.  Slot n mod 256 receives the maximum over
+ *           the images n, n + 256, ...: with N <= 256 the record holds one maximum PER IMAGE (the engine's dynamic-range
+ *           report reads them: one scale per tensor serves every image only within ~five decades of the largest).
  * Shapes: stk_gn_bwd_out_ok (the register-resident backward: H*W a power of two >= 16, groups of at most 16384
  * elements); 16-byte aligned tensors. */
 int stk_gn_bwd_out_ok(int C1, int C2, int HW, int G);

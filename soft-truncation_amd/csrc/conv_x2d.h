@@ -546,13 +546,21 @@ inline T64Plan t64_plan(const ConvP& p, int taps, int Kc, int M, long Ng) {
   if (t128 >= 192) return r;                              // the large tiles fill the chip: their kernels are the faster ones
   const long tiles = (long)stk_cdiv(M, 64) * stk_cdiv(Ng, 64);
   const int ngroups = Kc / 32;
-  // STK_T64_WGS: workgroups worth splitting K for (default 256 = one per CU); at least two channel groups (18 chunks) per split
-  static const long target = [] { const char* e = getenv("STK_T64_WGS"); return e && atol(e) > 0 ? atol(e) : 256L; }();
+  // STK_T64_WGS: workgroups worth splitting K for (default 512 = two per CU); at least two channel groups (18 chunks) per split
+  static const long target = [] { const char* e = getenv("STK_T64_WGS"); return e && atol(e) > 0 ? atol(e) : 512L; }();
   long splits = tiles >= target ? 1 : stk_cdiv(target, tiles);
   if (splits > ngroups / 2) splits = ngroups / 2;
   if (splits < 1) splits = 1;
   r.groups_per_split = (int)stk_cdiv((long)ngroups, splits);
   r.splits = stk_cdiv(ngroups, r.groups_per_split);
+  // Per unit of work the small tiles are about half as efficient as the large ones (8 fragment reads per 6 MFMAs, a barrier per
+  // 6 MFMAs): they win by what they save -- the second launch, the slabs, idle CUs -- only while a workgroup's share of K is
+  // short.  Measured (profiles/r05_t64_ab.txt, us, 128-tile K-split form -> small tiles): 256 -> 256 at 8x8, batch 128 (72 chunks, no
+  // split) 47.3 -> 43.1; at 4x4 (18 chunks) 24.3 -> 20.0; 512 -> 256 at 4x4 (36) 34.0 -> 28.9; 256 -> 256 at 16x16, batch 16 (36)
+  // 33.9 -> 26.4; but 512 -> 256 at 8x8, batch 128 (144 chunks) 69.2 -> 99.3 and at 16x16, batch 16 (72 chunks + slabs) 44.6 -> 53.8.
+  // STK_X2D_T64=2 lifts the limit (A/B).
+  const int chunks = r.groups_per_split * 9;
+  if (t64_mode() != 2 && chunks > (r.splits == 1 ? 72 : 36)) return r;
   r.ok = 1;
   return r;
 }

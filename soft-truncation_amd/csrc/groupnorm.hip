@@ -485,7 +485,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
       // separate pass).  Non-negative floats order like their bit patterns: an integer max is exact and order-independent
       float m = 0.f;
       for (int w = 0; w < (T >> 6); ++w) m = fmaxf(m, s_mx[w]);
-      atomicMax(reinterpret_cast<unsigned*>(out.amax) + (blockIdx.x & 255), __float_as_uint(m));
+      // slot = image mod 256: per-IMAGE maxima for batches of up to 256 (include/stk.h; the engine's dynamic-range report)
+      atomicMax(reinterpret_cast<unsigned*>(out.amax) + (n & 255), __float_as_uint(m));
     }
   }
 }

@@ -637,6 +637,7 @@ class Executor:
     rt.param_grads = param_grads
     flat = self.flat
     self._awaiting.discard(c)
+    self._last_ctx = c              # dynamic_range_report reads its records (they live until the context's next backward)
     if c.gact is None:
       c.gact = _arena(g.gact_size, prog.device)
     o = g.output
@@ -699,6 +700,33 @@ class Executor:
       gx = c.gact[xin.goff:xin.goff + xin.numel].view(xin.shape).clone()
     prog.release(c)
     return gx
+
+  def dynamic_range_report(self):
+    """Per-image dynamic range of the output gradients of the LAST backward: the split convolutions scale a tensor by ONE power
+    of two (include/stk.h "Planes"), which keeps every image at fp32 accuracy only while its own maximum lies within about five
+    decades of the batch maximum (tests/test_gpu_kernels.py::test_conv_split_per_image_accuracy: 2e-7 down to 1e-4 of the
+    maximum, 9e-7 at 1e-5, 8e-6 at 1e-6).  The GroupNorm backward leaves max |dy| PER IMAGE in the records it writes
+    (stk_gn_bwd_out_f32, slot n mod 256), so the spread costs nothing to know.  Returns [(layer, max over images, smallest
+    non-zero image maximum, decades between them)] for the convolutions served that way, worst first.  Synchronises."""
+    c = getattr(self, '_last_ctx', None)
+    if c is None or c.prog.graph.amax_block is None:
+      return []
+    g = c.prog.graph
+    n = len(g.conv_amax)
+    blk = c.act[g.amax_block.off:g.amax_block.off + 768 * n].view(n, 768).detach().cpu()
+    rows = []
+    for op in g.ops:
+      if not isinstance(op, Conv) or op.dy_prod is None:
+        continue
+      holder = op.dy_peer if op.dy_peer is not None else op
+      per = blk[(holder.amax.off - g.amax_block.off) // 768, 512:512 + min(op.N, 256)]
+      per = per[torch.isfinite(per) & (per > 0)]
+      if per.numel() < 2:
+        continue
+      hi, lo = float(per.max()), float(per.min())
+      rows.append((op.y.name, hi, lo, float(np.log10(hi / lo))))
+    rows.sort(key=lambda r: -r[3])
+    return rows
 
   def apply(self, x, emb_in, sigma=None):
     """Differentiable network evaluation (forward now, backward when autograd asks)."""

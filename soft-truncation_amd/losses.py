@@ -285,8 +285,32 @@ def _pick_loss_fn(config, sde, train):
 
 # STK_DDP_OVERLAP=0: exchange the gradients after the backward (one bucketed all-reduce) instead of during it
 OVERLAP_EXCHANGE = os.environ.get('STK_DDP_OVERLAP', '1') != '0'
+# STK_RANGE_CHECK=K: every K-th training step (and the first) the per-image maxima of the output gradients are read back
+# (Executor.dynamic_range_report) and a warning is issued when an image lies more than RANGE_DECADES below the batch maximum
+# of some layer -- beyond that the one-scale-per-tensor split convolutions no longer give that image fp32 accuracy
+# (likelihood-weighted VE losses with g^2 weights are the candidate, reference losses.py:126-129).  0 = off.
+RANGE_CHECK_EVERY = int(os.environ.get('STK_RANGE_CHECK', '1000'))
+RANGE_DECADES = 5.0
 # STK_ASYNC_LOSS=0: fetch the per-sample losses with a blocking .cpu() after the backward, as the reference does (A/B switch)
 ASYNC_LOSS_COPY = os.environ.get('STK_ASYNC_LOSS', '1') != '0'
+
+
+def _warn_dynamic_range(model, step):
+  """See RANGE_CHECK_EVERY."""
+  net = getattr(model, 'module', model)
+  engine = getattr(net, 'engine', None)
+  if engine is None:
+    return None
+  rows = engine().dynamic_range_report()
+  if rows and rows[0][3] > RANGE_DECADES:
+    import warnings
+    name, hi, lo, dec = rows[0]
+    warnings.warn(f'step {step}: the output gradients of {sum(r[3] > RANGE_DECADES for r in rows)} convolution(s) span more than '
+                  f'{RANGE_DECADES:g} decades across the images of the batch (worst: {name}, image maxima {lo:.3e} ... {hi:.3e}, '
+                  f'{dec:.1f} decades): the split convolutions scale a tensor by one power of two, so the gradient contribution of '
+                  f'the faintest images is no longer fp32-accurate (DESIGN.md section 3); a smaller spread of the per-sample loss '
+                  f'weights, or STK_PLANES=0 for an exact-fp32 check, tells whether it matters')
+  return rows
 
 
 def get_step_fn(config, sde, train, optimize_fn=None):
@@ -358,6 +382,8 @@ def get_step_fn(config, sde, train, optimize_fn=None):
       ddp.disarm_overlap(model, wait=False)      # a step that raised must not leave its hook armed -- nor wait for its peers
       raise
     ddp.disarm_overlap(model)        # no-op after optimize_fn
+    if RANGE_CHECK_EVERY > 0 and state['step'] % RANGE_CHECK_EVERY == 0:
+      _warn_dynamic_range(model, state['step'])
     state['step'] += 1
     state['ema'].update(model.parameters())
     if pinned is not None:

@@ -443,3 +443,29 @@ def test_conv_emitter_checks_the_weight_width(st, ref_lib):
   conv = next(m for m in net.all_modules if getattr(m, 'weight', None) is not None and m.weight.dim() == 4)
   with pytest.raises(RuntimeError, match='expected input with 3 channels'):
     g.conv(x, None, conv.weight, conv.bias, name='stem')
+
+
+def test_dynamic_range_report_flags_faint_images(st, ref_lib):
+  """Executor.dynamic_range_report: the GroupNorm backward leaves max |dy| per IMAGE in the records of the convolutions it
+  serves (slot n mod 256); a batch whose loss gradient spans seven decades across images is reported as such and
+  losses._warn_dynamic_range turns it into a warning, an even batch is not."""
+  import torch
+  import warnings
+  cfg, cfg_cpu, sde, model, ref = cases.build_pair(st, cases.tiny_config(st, 'wide'), ref_lib)
+  ex = model.module.engine()
+  B = 4
+  x, t = torch.randn(B, 3, 16, 16, generator=torch.Generator().manual_seed(1)), torch.rand(B) * 999
+  go = torch.randn(B, 3, 16, 16, generator=torch.Generator().manual_seed(2))
+  model(x, t).mul(go).sum().backward()
+  rows = ex.dynamic_range_report()
+  assert len(rows) >= 4 and rows[0][3] < 2.0, rows[:3]
+  with warnings.catch_warnings():
+    warnings.simplefilter('error')
+    st.losses._warn_dynamic_range(model, 0)                     # no warning for an even batch
+  scale = torch.tensor([1.0, 1e-7, 1.0, 1.0]).view(B, 1, 1, 1)
+  model.zero_grad()
+  model(x, t).mul(go * scale).sum().backward()
+  rows = ex.dynamic_range_report()
+  assert rows[0][3] > 6.0 and all(r[1] >= r[2] > 0 for r in rows), rows[:3]
+  with pytest.warns(UserWarning, match='decades across the images'):
+    st.losses._warn_dynamic_range(model, 0)
