@@ -536,7 +536,13 @@ __global__ __launch_bounds__(256, 2) void gemm_halo64_kernel(ConvP p, x3::Src q,
 // The small-tile plan of a plane-operand 3x3 call (STK_X2D_T64=0: off): shapes gemm_halo64_kernel takes and for which 128 x 128
 // tiles would not fill the chip.  K is split over whole 32-channel groups, and only while the tiles alone leave CUs idle.
 struct T64Plan { int ok; int splits; int groups_per_split; };
-inline int t64_mode() { static const int v = [] { const char* e = getenv("STK_X2D_T64"); return e ? atoi(e) : 1; }(); return v; }
+// OFF by default (STK_X2D_T64=1 switches it on): the kernel-level gains below did not survive inside the training step.  Measured with
+// bench.py's event brackets on the eager steps (profiles/r05_t64_in_situ.txt): the 8x8 layers at batch 128 take 66.5 us on the small
+// tiles against 43.1 us in the back-to-back micro-benchmark -- and 44 us on the 128-tile K-split form, which measures the same in both
+// settings; the step went 39.3-39.5 -> 40.0 ms (CIFAR-10 net), 39.64 -> 39.62 (256x256 net, batch 4), 124.0 -> 124.8 (64x64 net).  A
+// kernel that is bound by LDS reads and barriers rather than by the matrix pipe runs at whatever clock its neighbours leave: alone it
+// enjoys the boost clock, inside a step of power-limited GEMMs it does not, while the matrix-bound kernels are power-limited either way.
+inline int t64_mode() { static const int v = [] { const char* e = getenv("STK_X2D_T64"); return e ? atoi(e) : 0; }(); return v; }
 inline T64Plan t64_plan(const ConvP& p, int taps, int Kc, int M, long Ng) {
   T64Plan r = {0, 1, 0};
   if (!t64_mode() || taps != 9 || p.H * p.W != p.HW || p.stride != 1) return r;

@@ -113,6 +113,11 @@ T64_CASES = [
   (2, 96, 8, 8, 96, 3, 0, 1, 1, 1),         # the 'wide' test family's channel count (96 rows: a half-empty second row tile)
 ]
 PL_CONV_CASES = PL_CONV_CASES + T64_CASES
+# The small-tile kernel is off by default (measured slower inside the training step, csrc/conv_x2d.h: t64_mode): the library reads
+# STK_X2D_T64 once per process, so its cases exercise it when the suite is run as `STK_X2D_T64=2 pytest tests/test_planes.py -m gpu`
+# (2 = every shape it can take) and the default kernels of the same shapes otherwise.
+import os
+T64_ON = os.environ.get('STK_X2D_T64', '0') == '2'
 
 
 @pytest.mark.gpu
@@ -132,7 +137,7 @@ def test_conv_from_planes(ref_lib, hip_lib, case):
   assert int(hip_lib.conv2d_pl_ok(0, C, 0, N, H, W, Cout, K, K, 1, K // 2)) == 1
   assert int(ref_lib.conv2d_pl_ok(0, C, 0, N, H, W, Cout, K, K, 1, K // 2)) == 1
   assert int(hip_lib.conv2d_pl_ok(1, C, 0, N, H, W, Cout, K, K, 1, K // 2)) == 1
-  if case in T64_CASES:
+  if case in T64_CASES and T64_ON:
     assert int(hip_lib.conv2d_pl_tile(0, C, 0, N, H, W, Cout, K, K)) == 64 and int(hip_lib.conv2d_pl_tile(1, C, 0, N, H, W, Cout, K, K)) == 64
 
   def run(lib):
@@ -179,7 +184,8 @@ def test_small_tile_data_gradient_into_two_sources(ref_lib, hip_lib, case):
   dy = rnd(N, Cout, H, W, seed=7)
   w = rnd(Cout, C1 + C2, 3, 3, seed=3) / np.sqrt((C1 + C2) * 9.)
   g2 = rnd(N, C2, H, W, seed=9)
-  assert int(hip_lib.conv2d_pl_tile(1, C1, C2, N, H, W, Cout, 3, 3)) == 64
+  if T64_ON:
+    assert int(hip_lib.conv2d_pl_tile(1, C1, C2, N, H, W, Cout, 3, 3)) == 64
   out = {}
   for name, lib in (('ref', ref_lib), ('hip', hip_lib)):
     d = dev_of(lib)
