@@ -38,6 +38,7 @@ struct ConvP {
   float* y;
   const float* dy; float* dx1; float* dx2; float beta1, beta2, alpha;
   float* part; long part_stride;
+  float* dxmax;               // EpDgrad by-product (stk_conv2d_dgrad_pl_max_f32): per-image max |dx1| by atomic maximum, or NULL
   int N, H, W, Cin, Cout, OH, OW, KH, KW, stride, pad, sshift;
   int HW, OHW, taps;
   int ohw_shift, ow_shift;    // log2 when OHW / OW are powers of two, else -1
@@ -526,9 +527,21 @@ struct EpDgrad {      // dx{1,2} = beta*dx + alpha*acc, rows routed to the two s
         old[e] = (d[e] && beta != 0.f) ? beta * *d[e] : 0.f;
       }
     }
+    float mx = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e)
-      if (d[e]) *d[e] = ((acc1 || acc2) ? old[e] : 0.f) + p.alpha * acc[e];
+      if (d[e]) {
+        const float v = ((acc1 || acc2) ? old[e] : 0.f) + p.alpha * acc[e];
+        *d[e] = v;
+        mx = fmaxf(mx, fabsf(v));
+      }
+    if (p.dxmax) {
+      // the 32 pixels of a strip lie in one image (maps of >= 32 pixels in whole 32-pixel blocks: the entry point checks): one
+      // atomic per strip into that image's slot -- exact and order-independent, non-negative floats order like their bit patterns
+      mx = wave_max(mx);
+      const int img = __builtin_amdgcn_readfirstlane(b);
+      if ((threadIdx.x & 63) == 0 && nok) atomicMax(reinterpret_cast<unsigned*>(p.dxmax) + (img & 255), __float_as_uint(mx));
+    }
   }
 };
 struct EpWgrad {      // partial slab of split zs as [tap][Cout][Cin] (coalesced); the reduce kernel re-lays it out
@@ -1563,6 +1576,28 @@ int stk_conv2d_dgrad_pl_f32(const void* dypl, const float* dyamax, const float* 
   fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, 1, KH / 2);
   p.w = w; p.w_layout = w_layout; p.dx1 = dx1; p.dx2 = C2 > 0 ? dx2 : nullptr;
   p.beta1 = beta1; p.beta2 = beta2; p.alpha = alpha;
+  const long Ng = (long)N * p.HW;
+  const X3Plan xr = x3_plan_pl(p, Cout, p.Cin, Ng);
+  if (!ws || ws_bytes < x3_ws_bytes(xr, p.Cin, Cout, p.taps)) return STK_EINVAL;
+  return launch_x3<EpDgrad>(p, xr, nullptr, Cout, nullptr, 0, p.Cin, Ng, 1, ws, (hipStream_t)stream, wp, nullptr, dypl, dyamax);
+}
+
+/* stk_conv2d_dgrad_pl_f32 into ONE source (C2 = 0) that also leaves max |dx1| PER IMAGE behind: dxmax[n mod 256] by atomic maximum
+ * (caller-zeroed).  The GroupNorm backward that reads dx1 next derives the scale of the planes it writes from it
+ * (stk_gn_bwd_pl_f32).  Shapes: those of the plain call that run unsplit over K, maps of whole 32-pixel blocks. */
+int stk_conv2d_dgrad_pl_max_ok(int C1, int N, int H, int W, int Cout, int KH, int KW) {
+  if (!stk_conv2d_pl_ok(1, C1, 0, N, H, W, Cout, KH, KW, 1, KH / 2) || (H * W) % 32) return 0;
+  return stk_conv2d_pl_ksplit(1, C1, 0, N, H, W, Cout, KH, KW) == 1 ? 1 : 0;
+}
+int stk_conv2d_dgrad_pl_max_f32(const void* dypl, const float* dyamax, const float* w, int w_layout, float* dx1, int C1,
+                                float beta1, float alpha, int N, int H, int W, int Cout, int KH, int KW, const void* wp,
+                                void* ws, long ws_bytes, float* dxmax, void* stream) {
+  if (!dypl || !dyamax || !w || !dx1 || !dxmax || (w_layout != 0 && w_layout != 1) || (w_layout == 1 && KH != 1)) return STK_EINVAL;
+  if (!stk_conv2d_dgrad_pl_max_ok(C1, N, H, W, Cout, KH, KW)) return STK_EUNSUPPORTED;
+  ConvP p = {};
+  fill_common(p, N, H, W, C1, 0, Cout, H, W, KH, KW, 1, KH / 2);
+  p.w = w; p.w_layout = w_layout; p.dx1 = dx1; p.dx2 = nullptr;
+  p.beta1 = beta1; p.beta2 = 0.f; p.alpha = alpha; p.dxmax = dxmax;
   const long Ng = (long)N * p.HW;
   const X3Plan xr = x3_plan_pl(p, Cout, p.Cin, Ng);
   if (!ws || ws_bytes < x3_ws_bytes(xr, p.Cin, Cout, p.taps)) return STK_EINVAL;

@@ -713,13 +713,15 @@ class Executor:
       return []
     g = c.prog.graph
     n = len(g.conv_amax)
-    blk = c.act[g.amax_block.off:g.amax_block.off + 768 * n].view(n, 768).detach().cpu()
+    from .graph import AMAX
+    blk = c.act[g.amax_block.off:g.amax_block.off + AMAX * n].view(n, AMAX).detach().cpu()
     rows = []
     for op in g.ops:
       if not isinstance(op, Conv) or op.dy_prod is None:
         continue
       holder = op.dy_peer if op.dy_peer is not None else op
-      per = blk[(holder.amax.off - g.amax_block.off) // 768, 512:512 + min(op.N, 256)]
+      first = 1024 if op.dy_pl_from is not None else 512       # the true maxima live beside an a-priori bound (stk_gn_bwd_pl_f32)
+      per = blk[(holder.amax.off - g.amax_block.off) // AMAX, first:first + min(op.N, 256)]
       per = per[torch.isfinite(per) & (per > 0)]
       if per.numel() < 2:
         continue

@@ -256,6 +256,8 @@ def test_backward_window_launches_library_kernels_only(st, hip_lib, monkeypatch)
         return f(*a)
       return call
 
+  real_bwd = E.Executor._run_backward
+  monkeypatch.setattr(E.Executor, '_run_backward', lambda self, *a, **k: (log.append(('<backward>', None)), real_bwd(self, *a, **k))[1])
   real_begin, real_join = E.SideStream.begin, E.SideStream.join
   monkeypatch.setattr(E.SideStream, 'begin', lambda self: (log.append(('<fork>', None)), real_begin(self))[1])
   monkeypatch.setattr(E.SideStream, 'join', lambda self: (log.append(('<join>', None)), real_join(self))[1])
@@ -269,7 +271,8 @@ def test_backward_window_launches_library_kernels_only(st, hip_lib, monkeypatch)
   torch.cuda.synchronize()
   names = [n for n, _ in log]
   assert '<fork>' in names and '<join>' in names
-  first, last = names.index('<fork>'), len(names) - 1 - names[::-1].index('<join>')
+  # (the forward has a fork of its own: the data-gradient weight blocks are prepared on the side stream beside it)
+  first, last = names.index('<fork>', names.index('<backward>')), len(names) - 1 - names[::-1].index('<join>')
   # launches only: every launching entry of include/stk.h takes its stream as the last argument (queries end in an int)
   window = [(n, s) for n, s in log[first:last] if not n.startswith('<') and L.SIGNATURES['stk_' + n][-1] is L.S]
   main = torch.cuda.current_stream(cfg.device).cuda_stream

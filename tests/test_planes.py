@@ -430,3 +430,121 @@ def test_wgrad_from_planes(ref_lib, hip_lib, case):
   scale = (r - dw0).abs().max().item()
   assert (h - r).abs().max().item() <= 1e-4 * scale
   assert (h - h32).abs().max().item() <= 2e-5 * scale
+
+
+# ---- round 5: planes of a convolution's output gradient written by the GroupNorm backward itself -----------------------------
+def _decode_planes(pl_u8, rec, N, C, HW):
+  """(hi + lo) / scale of a planes buffer as [N, C, HW] float64, with the scale of its record."""
+  m = float(rec.max())
+  s = 1.0 if m == 0 else 2.0 ** (13 - int(np.floor(np.log2(m))))
+  p = pl_u8.cpu().numpy().view(np.float16).reshape(2, N, (C + 31) // 32, HW, 32)
+  dec = (p[0].astype(np.float64) + p[1].astype(np.float64)) / s
+  return dec.transpose(0, 1, 3, 2).reshape(N, -1, HW)[:, :C], s
+
+
+GN_BWD_PL_CASES = [
+  # N, C, HW, G, act, drop
+  (5, 128, 1024, 32, 1, 0.1),     # 4 channels per group: two groups per workgroup, 32x32
+  (3, 256, 256, 32, 1, 0.0),      # 8 per group, 16x16
+  (9, 128, 256, 32, 1, 0.0),      # 4 per group, 16x16; 36 row sets (not a multiple of 8)
+  (2, 256, 1024, 32, 3, 0.0),     # LeakyReLU
+  (300, 128, 256, 32, 1, 0.0),    # more than 256 images: record slots shared by images n, n + 256
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', GN_BWD_PL_CASES, ids=str)
+def test_gn_backward_to_planes(ref_lib, hip_lib, case):
+  """stk_gn_bwd_pl_f32 (+ the forward that leaves its records, stk_gn_fwd_pl_rec_f32): the planes decoded back against the fp32
+  gradient of the plain backward (oracle, and the HIP library's own stk_gn_bwd_f32), the by-product sums, the parameter-gradient
+  partials, the per-image true maxima; and the a-priori bound: never below the true maximum, within a small factor of it."""
+  N, C, HW, G, act, drop = case
+  x = rnd(N, C, HW, seed=1) * 2 + 0.3
+  x = x * torch.logspace(-1, 1, N)[:, None, None]              # images of different magnitude
+  dy = rnd(N, C, HW, seed=2) * torch.logspace(0, -3, N)[:, None, None]
+  gamma, beta = rnd(C, seed=3) * 0.5 + 1.0, rnd(C, seed=4) * 0.2
+  dymax = torch.zeros(256)
+  for n in range(N):
+    dymax[n & 255] = max(float(dymax[n & 255]), float(dy[n].abs().max()))
+  out = {}
+  for name, lib in (('ref', ref_lib), ('hip', hip_lib)):
+    d = dev_of(lib)
+    assert int(lib.gn_bwd_pl_ok(C, HW, G)) == 1 and int(lib.gn_fwd_rec_ok(C, 0, HW, G)) == 1
+    xd, dyd, ga, be = x.to(d), dy.to(d), gamma.to(d), beta.to(d)
+    mean, rstd = torch.zeros(N * G, device=d), torch.zeros(N * G, device=d)
+    rec_y = torch.zeros(256, device=d)
+    gnrec = torch.zeros(512, device=d)
+    ypl = torch.zeros(int(lib.planes_bytes(N, C, HW)), dtype=torch.uint8, device=d)
+    wsf = torch.zeros(int(lib.gn_ws_bytes(N, C, HW, G)) // 4 + 64, device=d)
+    call(lib, 'gn_fwd_pl_rec_f32', xd, C, None, 0, ga, be, None, ypl, rec_y, mean, rstd, N, HW, G, 1e-6, act, drop, 77, None, wsf,
+         None, None, gnrec)
+    ws = torch.full((2 * N * C + 64,), float('nan'), device=d)
+    dx_sum = torch.full((N, C, 2), float('nan'), device=d)
+    dtemb = torch.zeros(N, C + 8, device=d)
+    pl = torch.full((int(lib.planes_bytes(N, C, HW)),), 0xAA, dtype=torch.uint8, device=d)
+    rec = torch.full((256,), -1.0, device=d)
+    amax_true = torch.zeros(256, device=d)
+    call(lib, 'gn_bwd_pl_f32', dyd, xd, C, ga, be, mean, rstd, ws, N, HW, G, act, drop, 77, None, dx_sum, 0.5, dtemb, C + 8,
+         dymax.to(d), gnrec, pl, rec, amax_true)
+    # the plain backward of the same library
+    dx = torch.zeros(N, C, HW, device=d)
+    ws2 = torch.zeros(2 * N * C + 64, device=d)
+    call(lib, 'gn_bwd_f32', dyd, xd, C, None, 0, ga, be, mean, rstd, dx, 0.0, None, 0.0, None, None, ws2, N, HW, G, act, drop, 77, None)
+    dec, s = _decode_planes(pl, rec.cpu().numpy(), N, C, HW)
+    out[name] = dict(dec=dec, dx=dx.cpu().double().numpy(), rec=rec.cpu(), gnrec=gnrec.cpu(), ws=ws.cpu()[:2 * N * C],
+                     ws2=ws2.cpu()[:2 * N * C], dx_sum=dx_sum.cpu(), dtemb=dtemb.cpu(), amax_true=amax_true.cpu(), scale=s)
+  r, h = out['ref'], out['hip']
+  top = np.abs(r['dx']).max()
+  for o in (r, h):
+    # planes carry this library's own fp32 gradient to the split's accuracy; the bound holds and is not absurdly loose
+    assert np.abs(o['dec'] - o['dx']).max() <= max(4e-6 * top, 2.0 ** -24 / o['scale']), float(np.abs(o['dec'] - o['dx']).max() / top)
+    assert float(o['rec'][0]) >= np.abs(o['dx']).max() and float(o['rec'][1:].abs().max()) == 0.0
+    assert float(o['rec'][0]) <= 64.0 * np.abs(o['dx']).max(), (float(o['rec'][0]), np.abs(o['dx']).max())
+    per = np.zeros(256)
+    for n in range(N):
+      per[n & 255] = max(per[n & 255], np.abs(o['dx'][n]).max())
+    assert np.allclose(o['amax_true'].numpy(), per, rtol=2e-5, atol=0)
+  # HIP against the oracle
+  assert np.abs(h['dec'] - r['dx']).max() <= 1e-5 * top
+  assert (h['ws'] - r['ws']).abs().max().item() <= 1e-4 * r['ws'].abs().max().item()
+  assert (h['ws'] - h['ws2']).abs().max().item() <= 1e-5 * h['ws2'].abs().max().item()
+  scale = r['dx_sum'].abs().max().item()
+  assert (h['dx_sum'] - r['dx_sum']).abs().max().item() <= 2e-5 * scale + 1e-6 * top * HW
+  assert (h['dtemb'][:, :C] - r['dtemb'][:, :C]).abs().max().item() <= 2e-5 * scale + 1e-6 * top * HW
+  assert float(h['dtemb'][:, C:].abs().max()) == 0.0
+  # the forward's records: max rstd per image, and max |xhat| per image (the HIP kernel's carries a factor 1.0001)
+  assert np.allclose(h['gnrec'][:256].numpy(), r['gnrec'][:256].numpy(), rtol=1e-5)
+  hx, rx = h['gnrec'][256:].numpy(), r['gnrec'][256:].numpy()
+  assert np.all(hx >= rx * (1 - 1e-5)) and np.all(hx <= 1.001 * rx + 1e-30)
+  print('bound / true maximum:', float(h['rec'][0]) / np.abs(h['dx']).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(6, 128, 32, 32, 128), (3, 256, 16, 16, 256), (130, 256, 16, 16, 128)], ids=str)
+def test_data_gradient_leaves_per_image_maxima(ref_lib, hip_lib, case):
+  """stk_conv2d_dgrad_pl_max_f32: the data gradient of the plain call bit for bit, plus max |dx1| per image in a caller-zeroed
+  record (exact: it is a maximum of the stored values)."""
+  N, C, H, W, Cout = case
+  dy = rnd(N, Cout, H, W, seed=7) * torch.logspace(0, -2, N)[:, None, None, None]
+  w = rnd(Cout, C, 3, 3, seed=3) / np.sqrt(C * 9.)
+  for lib in (ref_lib, hip_lib):
+    d = dev_of(lib)
+    assert int(lib.conv2d_dgrad_pl_max_ok(C, N, H, W, Cout, 3, 3)) == 1
+    shape = (C, 0, N, H, W, Cout, 3, 3, 1, 1)
+    fb = max(int(lib.conv2d_dgrad_ws_bytes(*shape)), 256)
+    ws = torch.zeros(fb // 4 + 64, device=d)
+    ay = torch.zeros(256, device=d)
+    dyd = dy.to(d)
+    call(lib, 'amax_partial_f32', dyd, dyd.numel(), ay)
+    yp = torch.zeros(int(lib.planes_bytes(N, Cout, H * W)), dtype=torch.uint8, device=d)
+    call(lib, 'split_planes_f32', dyd, N, Cout, H * W, ay, 256, yp)
+    dx0 = torch.zeros(N, C, H, W, device=d)
+    call(lib, 'conv2d_dgrad_pl_f32', yp, ay, w.to(d), 0, dx0, C, 0.0, None, 0, 0.0, 0.7, N, H, W, Cout, 3, 3, None, ws, fb)
+    dx1 = torch.full((N, C, H, W), float('nan'), device=d)
+    dxmax = torch.zeros(256, device=d)
+    call(lib, 'conv2d_dgrad_pl_max_f32', yp, ay, w.to(d), 0, dx1, C, 0.0, 0.7, N, H, W, Cout, 3, 3, None, ws, fb, dxmax)
+    assert torch.equal(dx0, dx1)
+    per = torch.zeros(256)
+    for n in range(N):
+      per[n & 255] = max(float(per[n & 255]), float(dx1[n].abs().max()))
+    assert torch.equal(dxmax.cpu(), per)
