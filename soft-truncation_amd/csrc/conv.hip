@@ -439,6 +439,7 @@ struct EpFwd {        // y = (acc + bias + temb + res) * inv_div
     sb = s; stm = s + 128;
   }
   __device__ void init(const ConvP&, int, int) {}
+  __device__ void finish(const ConvP&, unsigned char*, int) {}
   __device__ void col(const ConvP& p, int n) {
     b = n / p.OHW;
     col_off = b * p.Cout * p.OHW + (n - b * p.OHW);
@@ -527,20 +528,45 @@ struct EpDgrad {      // dx{1,2} = beta*dx + alpha*acc, rows routed to the two s
         old[e] = (d[e] && beta != 0.f) ? beta * *d[e] : 0.f;
       }
     }
-    float mx = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e)
-      if (d[e]) {
-        const float v = ((acc1 || acc2) ? old[e] : 0.f) + p.alpha * acc[e];
-        *d[e] = v;
+      if (d[e]) *d[e] = ((acc1 || acc2) ? old[e] : 0.f) + p.alpha * acc[e];
+  }
+  __device__ void finish(const ConvP&, unsigned char*, int) {}
+};
+// EpDgrad into one source that also leaves max |dx1| of the tile's image behind (stk_conv2d_dgrad_pl_max_f32): the maximum of the
+// STORED values, one atomic per workgroup (a 128-pixel tile lies in one image: the entry point checks) into that image's slot --
+// exact and order-independent, non-negative floats order like their bit patterns.  A type of its own: the by-product code inside
+// EpDgrad cost every data-gradient launch 5-8 us (172.1 -> 180.6 us on the 32x32 layers), one atomic per strip -- 8192 per launch
+// on 128 addresses -- most of it.
+struct EpDgradMax {
+  int b, hw; float mx = 0.f;
+  __device__ void preload(const ConvP&, int, int, int, int, int, int) {}
+  __device__ void stage(unsigned char*, int) {}
+  __device__ void init(const ConvP&, int, int) {}
+  __device__ void col(const ConvP& p, int n) { b = n / p.HW; hw = n - b * p.HW; }
+  __device__ void strip(const ConvP& p, int mbase, int M, bool nok, int, const floatx16& acc) {
+    const bool accum = p.beta1 != 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = mbase + strip_row(e);
+      if (nok && m < M) {
+        float* q = p.dx1 + ((long)b * p.C1 + m) * p.HW + hw;
+        const float v = (accum ? p.beta1 * *q : 0.f) + p.alpha * acc[e];
+        *q = v;
         mx = fmaxf(mx, fabsf(v));
       }
-    if (p.dxmax) {
-      // the 32 pixels of a strip lie in one image (maps of >= 32 pixels in whole 32-pixel blocks: the entry point checks): one
-      // atomic per strip into that image's slot -- exact and order-independent, non-negative floats order like their bit patterns
-      mx = wave_max(mx);
-      const int img = __builtin_amdgcn_readfirstlane(b);
-      if ((threadIdx.x & 63) == 0 && nok) atomicMax(reinterpret_cast<unsigned*>(p.dxmax) + (img & 255), __float_as_uint(mx));
+    }
+  }
+  __device__ void finish(const ConvP& p, unsigned char* lds, int tid) {
+    float* s = reinterpret_cast<float*>(lds);
+    const float m = wave_max(mx);
+    __syncthreads();                                   // (the staged addends / operand tiles are dead)
+    if ((tid & 63) == 0) s[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+      const int img = b;                               // thread 0's pixel: the tile's first (valid) one
+      atomicMax(reinterpret_cast<unsigned*>(p.dxmax) + (img & 255), __float_as_uint(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]))));
     }
   }
 };
@@ -565,6 +591,7 @@ struct EpSlab {
   __device__ void preload(const ConvP&, int, int, int, int, int, int) {}
   __device__ void stage(unsigned char*, int) {}
   __device__ void init(const ConvP& p, int, int zs) { slab = p.part + (long)zs * p.part_stride; Nn = p.N * p.HW; }
+  __device__ void finish(const ConvP&, unsigned char*, int) {}
   __device__ void col(const ConvP&, int) {}
   __device__ void strip(const ConvP&, int mbase, int M, bool nok, int n, const floatx16& acc) {
 #pragma unroll
@@ -1586,8 +1613,8 @@ int stk_conv2d_dgrad_pl_f32(const void* dypl, const float* dyamax, const float* 
  * (caller-zeroed).  The GroupNorm backward that reads dx1 next derives the scale of the planes it writes from it
  * (stk_gn_bwd_pl_f32).  Shapes: those of the plain call that run unsplit over K, maps of whole 32-pixel blocks. */
 int stk_conv2d_dgrad_pl_max_ok(int C1, int N, int H, int W, int Cout, int KH, int KW) {
-  if (!stk_conv2d_pl_ok(1, C1, 0, N, H, W, Cout, KH, KW, 1, KH / 2) || (H * W) % 32) return 0;
-  return stk_conv2d_pl_ksplit(1, C1, 0, N, H, W, Cout, KH, KW) == 1 ? 1 : 0;
+  if (!stk_conv2d_pl_ok(1, C1, 0, N, H, W, Cout, KH, KW, 1, KH / 2) || (H * W) % 128) return 0;     // a 128-pixel tile = one image
+  return stk_conv2d_pl_ksplit(1, C1, 0, N, H, W, Cout, KH, KW) == 1 && pl::kernel_choice() == 4 ? 1 : 0;
 }
 int stk_conv2d_dgrad_pl_max_f32(const void* dypl, const float* dyamax, const float* w, int w_layout, float* dx1, int C1,
                                 float beta1, float alpha, int N, int H, int W, int Cout, int KH, int KW, const void* wp,
@@ -1601,7 +1628,7 @@ int stk_conv2d_dgrad_pl_max_f32(const void* dypl, const float* dyamax, const flo
   const long Ng = (long)N * p.HW;
   const X3Plan xr = x3_plan_pl(p, Cout, p.Cin, Ng);
   if (!ws || ws_bytes < x3_ws_bytes(xr, p.Cin, Cout, p.taps)) return STK_EINVAL;
-  return launch_x3<EpDgrad>(p, xr, nullptr, Cout, nullptr, 0, p.Cin, Ng, 1, ws, (hipStream_t)stream, wp, nullptr, dypl, dyamax);
+  return launch_x3<EpDgradMax>(p, xr, nullptr, Cout, nullptr, 0, p.Cin, Ng, 1, ws, (hipStream_t)stream, wp, nullptr, dypl, dyamax);
 }
 
 /* 3x3 / stride 1 / pad 1 weight gradient with x and dy given as planes (conv_x2w.h) */

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M,
       ep.strip(p, m0 + wm0 + i * 32 + 4 * fk, M, nok, nok ? n : 0, acc[i][j]);
     }
   }
+  ep.finish(p, lds, tid);
 }
 
 // ---- 3x3 with ONE staged halo tile of the activations per 32-channel group (round 3) ---------------------------------
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(ConvP p, x3::Src q, i
       ep.strip(p, m0 + wm0 + i * 32 + 4 * fk, M, true, n, acc[i][j]);
     }
   }
+  ep.finish(p, lds, tid);
 }
 
 // ---- small tiles for small problems (round 5) ------------------------------------------------------------------------
@@ -531,6 +533,7 @@ __global__ __launch_bounds__(256, 2) void gemm_halo64_kernel(ConvP p, x3::Src q,
     for (int e = 0; e < 16; ++e) acc[e] *= unscale;
     ep.strip(p, m0 + wm0 + 4 * fk, M, nok, nok ? n : 0, acc);
   }
+  ep.finish(p, lds, tid);
 }
 
 // The small-tile plan of a plane-operand 3x3 call (STK_X2D_T64=0: off): shapes gemm_halo64_kernel takes and for which 128 x 128

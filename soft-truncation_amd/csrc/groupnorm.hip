@@ -516,14 +516,14 @@ struct GnBwdPl {
   float* sum; float* temb; int temb_stride; float scale; float slope;
 };
 
-template <int CPG>
-__global__ __launch_bounds__(512) void gn_bwd_pl_kernel(GnArgs a, const float* __restrict__ dy, const float* __restrict__ mean_in,
+template <int CPG, int IPT>
+__global__ __launch_bounds__(2048 / IPT) void gn_bwd_pl_kernel(GnArgs a, const float* __restrict__ dy, const float* __restrict__ mean_in,
                                                         const float* __restrict__ rstd_in, float* __restrict__ ws, int hw_log2,
                                                         GnBwdPl o) {
   constexpr int GPW = 8 / CPG;                       // groups per workgroup
   extern __shared__ float s_t[];                     // [8][HW] transposition buffer
-  __shared__ float s_part[2 * 8 * 4], s_ch[16], s_g[2 * GPW], s_red[16], s_sum[8 * 4], s_mx[8];
-  const int T = blockDim.x;                          // HW / 2: four float4 items per thread
+  __shared__ float s_part[2 * 8 * 4], s_ch[16], s_g[2 * GPW], s_red[32], s_sum[8 * 4], s_mx[16];
+  const int T = blockDim.x;                          // 2 HW / IPT threads, IPT float4 items each
   const int C = a.C1, Cb = C >> 5;
   // block id -> (row set = (image, 32-channel block), 16-byte piece): ids 8 apart share a row set
   const int super = blockIdx.x >> 5, r32 = blockIdx.x & 31;
@@ -541,9 +541,9 @@ __global__ __launch_bounds__(512) void gn_bwd_pl_kernel(GnArgs a, const float* _
   for (int i = threadIdx.x; i < 256; i += T) bnd = fmaxf(bnd, o.gnrec[i] * (2.f + o.gnrec[256 + i]) * o.dymax[i]);
   for (int c = threadIdx.x; c < C; c += T) gmax = fmaxf(gmax, fabsf(a.gamma[c]));
 
-  float du[4][4], xh[4][4], gam[4];
+  float du[IPT][4], xh[IPT][4], gam[IPT];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < IPT; ++k) {
     const int i = threadIdx.x + T * k;               // float4 item of the [8][HW] block
     const int e = 4 * i;
     const int cl = e >> hw_log2, off = e & (a.HW - 1);
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(512) void gn_bwd_pl_kernel(GnArgs a, const float* _
     if (lane == 0) { s_part[2 * (i >> 6)] = cs0; s_part[2 * (i >> 6) + 1] = cs1; }
   }
   bnd = wave_max(bnd); gmax = wave_max(gmax);
-  if (lane == 0) { s_red[wid] = bnd; s_red[8 + wid] = gmax; }
+  if (lane == 0) { s_red[wid] = bnd; s_red[16 + wid] = gmax; }
   __syncthreads();
   if (threadIdx.x < 8) {                             // per-channel totals, in slot order
     const int cl = threadIdx.x;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(512) void gn_bwd_pl_kernel(GnArgs a, const float* _
   __syncthreads();
   const int nw = T >> 6;
   float bound = 0.f, gm = 0.f;
-  for (int w = 0; w < nw; ++w) { bound = fmaxf(bound, s_red[w]); gm = fmaxf(gm, s_red[8 + w]); }
+  for (int w = 0; w < nw; ++w) { bound = fmaxf(bound, s_red[w]); gm = fmaxf(gm, s_red[16 + w]); }
   bound = bound * gm * o.slope * a.keep_scale * 1.001f;
   // the power of two that puts the bound in [2^13, 2^14) (x2::pow2_scale_of in conv_x2.h)
   float sc = 1.f;
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(512) void gn_bwd_pl_kernel(GnArgs a, const float* _
 
   float amax_l = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < IPT; ++k) {
     const int i = threadIdx.x + T * k;
     const int e = 4 * i;
     const int cl = e >> hw_log2, off = e & (a.HW - 1);
@@ -1055,6 +1055,8 @@ __global__ __launch_bounds__(1024) void gn_fwd_pl_kernel(GnArgs a, float* __rest
 // gnrec (may be NULL; stk_gn_fwd_pl_rec_f32): two caller-zeroed 256-slot records filled by atomic maximum, slot = image mod 256:
 // [0..256) max over the image's groups of rstd, [256..512) of max |xhat| (times 1.0001).  The
 // backward that writes the planes of its input gradient itself (gn_bwd_pl_kernel) derives their scale from these.
+// (REC is a template parameter: with the branch inside the streaming loop every launch of the kernel ran 13.3 -> 21.0 us)
+template <bool REC>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a, float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                        float eps, float sqrt_lm1, float* __restrict__ rec,
                                                        float* __restrict__ gnrec) {
@@ -1074,7 +1076,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a, float* __restri
     const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
     s[0] += (d0 + d1) + (d2 + d3);
     s[1] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    if (gnrec) {
+    if (REC) {
       dmax = fmaxf(dmax, fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)));
       dmin = fminf(dmin, fminf(fminf(d0, d1), fminf(d2, d3)));
     }
@@ -1088,7 +1090,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a, float* __restri
     mean_out[ng] = shift + md;
     rstd_out[ng] = rstd_v;
   }
-  if (gnrec) {                                           // launch-uniform
+  if (REC) {
     dmax = wave_max(dmax);
     dmin = -wave_max(-dmin);
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = dmax; red[4 + (threadIdx.x >> 6)] = dmin; }
@@ -1347,7 +1349,8 @@ static int gn_fwd_pl_impl(const float* x1, int C1, const float* x2, int C2, cons
     const float sq = sqrtf((float)((long)a.cpg * HW) - 1.f);
     hipStream_t s = (hipStream_t)stream;
     if ((long)a.cpg * HW <= 16384) {
-      hipLaunchKernelGGL(gn_stats_kernel, dim3(N * G), dim3(256), 0, s, a, mean, rstd, eps, sq, rec, gnrec);
+      if (gnrec) hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(N * G), dim3(256), 0, s, a, mean, rstd, eps, sq, rec, gnrec);
+      else hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(N * G), dim3(256), 0, s, a, mean, rstd, eps, sq, rec, gnrec);
     } else {
       if (!ws) return STK_EINVAL;
       const int Sc = HW / GN_CHUNK;
@@ -1521,8 +1524,13 @@ int stk_gn_bwd_pl_f32(const float* dy, const float* x, int C, const float* gamma
   const long rsets = (long)N * (C / 32);
   const dim3 grid((unsigned)(stk_cdiv(rsets, 8L) * 32));
   const size_t lds = (size_t)8 * HW * 4;
-  if (a.cpg == 4) hipLaunchKernelGGL((gn_bwd_pl_kernel<4>), grid, dim3(HW / 2), lds, (hipStream_t)stream, a, dy, mean, rstd, ws, hw_log2, o);
-  else hipLaunchKernelGGL((gn_bwd_pl_kernel<8>), grid, dim3(HW / 2), lds, (hipStream_t)stream, a, dy, mean, rstd, ws, hw_log2, o);
+  // STK_GN_BWD_PL_IPT (A/B): float4 items per thread, 4 (512 / 128 threads per workgroup) or 2 (1024 / 256)
+  static const int ipt = [] { const char* e = getenv("STK_GN_BWD_PL_IPT"); return e && atoi(e) == 2 ? 2 : 4; }();
+#define STK_GN_BWD_PL(CPG, IPT)                                                                                   \
+  hipLaunchKernelGGL((gn_bwd_pl_kernel<CPG, IPT>), grid, dim3(2 * HW / IPT), lds, (hipStream_t)stream, a, dy, mean, rstd, ws, hw_log2, o)
+  if (a.cpg == 4) { if (ipt == 2) STK_GN_BWD_PL(4, 2); else STK_GN_BWD_PL(4, 4); }
+  else { if (ipt == 2) STK_GN_BWD_PL(8, 2); else STK_GN_BWD_PL(8, 4); }
+#undef STK_GN_BWD_PL
   STK_CHECK_LAUNCH();
   return STK_OK;
 }

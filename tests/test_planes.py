@@ -520,7 +520,7 @@ def test_gn_backward_to_planes(ref_lib, hip_lib, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', [(6, 128, 32, 32, 128), (3, 256, 16, 16, 256), (130, 256, 16, 16, 128)], ids=str)
+@pytest.mark.parametrize('case', [(24, 128, 32, 32, 128), (48, 256, 16, 16, 256), (130, 256, 16, 16, 128)], ids=str)
 def test_data_gradient_leaves_per_image_maxima(ref_lib, hip_lib, case):
   """stk_conv2d_dgrad_pl_max_f32: the data gradient of the plain call bit for bit, plus max |dx1| per image in a caller-zeroed
   record (exact: it is a maximum of the stored values)."""
