@@ -116,9 +116,7 @@ int stk_gn_bwd_f32(const float* dy, const float* x1, int C1, const float* x2, in
  *           up to two bias gradients (a convolution's and its shortcut peer's) are one more entry of that fold;
  *   dtemb   [n*temb_stride + c] = out_scale * sum_hw dx1[n,c,:]  (the time-embedding projection's gradient, written);
  *   dx_amax [256]: a planes scale record of dx1 by atomic maximum -- the caller ZEROES it before the launch
- *           (stk_fill_strided_f32), max(dx_amax[0..256)) = max |dx1| afterwards.  Slot n mod 256 receives the maximum over
- *           the images n, n + 256, ...: with N <= 256 the record holds one maximum PER IMAGE (the engine's dynamic-range
- *           report reads them: one scale per tensor serves every image only within ~five decades of the largest).
+ *           (stk_fill_strided_f32), max(dx_amax[0..256)) = max |dx1| afterwards.
  * Shapes: stk_gn_bwd_out_ok (the register-resident backward: H*W a power of two >= 16, groups of at most 16384
  * elements); 16-byte aligned tensors. */
 int stk_gn_bwd_out_ok(int C1, int C2, int HW, int G);
@@ -133,15 +131,15 @@ int stk_gn_bwd_out_f32(const float* dy, const float* x1, int C1, const float* x2
 /* "Planes without a pass" (round 5): the backward of a GroupNorm whose input is read by nobody else and whose input gradient is
  * consumed as planes only -- Conv_0 -> (+ temb) -> GroupNorm_1 of a ResnetBlockBigGANpp, models/layerspp.py:273-278: this gradient IS
  * Conv_0's output gradient -- writes those planes itself: no fp32 copy of the gradient, no stk_split_planes_f32 pass.
- * The scale of planes must be known before the first value is written, so it is derived a priori from three per-image records
- * (256 slots each, slot = image mod 256, filled by atomic maximum into caller-zeroed memory):
- *   dymax  [256]  max |dy| of the image          <- stk_conv2d_dgrad_pl_max_f32, the data-gradient GEMM that produces dy
- *   gnrec  [512]  [0..256) max rstd, [256..512) a bound of max |xhat| of the image   <- stk_gn_fwd_pl_rec_f32, this layer's forward
- * as  bound = 1.001 max|gamma| S K max_n( rstd_n (2 + xhat_n) dymax_n ),  S = the activation's largest slope (SiLU 1.0999, else 1),
- * K = 1 / (1 - drop_p):   dx = rstd (gamma du - m1 - xhat m2) with |m1|, |m2| <= max|gamma du| because mean |xhat| <= 1.
+ * The scale of planes must be known before the first value is written, so it is derived a priori from records earlier calls leave:
+ *   dymax  [256]  max |dy| per image (slot = image mod 256, atomic maximum into caller-zeroed memory)
+ *                                                 <- stk_conv2d_dgrad_pl_max_f32, the data-gradient GEMM that produces dy
+ *   gnrec  [N G]  max |xhat| of every (image, group), plain stores     <- stk_gn_fwd_pl_rec_f32, this layer's forward
+ * as  bound = 1.001 max|gamma| S K max_{n,g}( rstd_ng (2 + xhat_ng) dymax_n ),  S = the activation's largest slope (SiLU 1.0999,
+ * else 1), K = 1 / (1 - drop_p):   dx = rstd (gamma du - m1 - xhat m2) with |m1|, |m2| <= max|gamma du| because mean |xhat| <= 1.
  *   planes        the planes of dx [N, C, HW] (stk_planes_bytes), scaled by the power of two of `bound`
  *   rec    [256]  OUT: the scale record the consumers of `planes` read: rec[0] = bound, rec[1..] = 0
- *   amax_true [256] (may be NULL; caller-zeroed) the TRUE max |dx| per image, by atomic maximum (diagnostics, tests)
+ *   amax_true [256] (may be NULL; caller-zeroed) a record of the TRUE max |dx| by atomic maximum (diagnostics, tests)
  *   ws, dx_sum, out_scale, dtemb, temb_stride: as in stk_gn_bwd_out_f32 (ws receives the [N][C][2] sums for stk_gn_param_grad_batch)
  * One source only.  Shapes: stk_gn_bwd_pl_ok (4 or 8 channels per group in whole 32-channel blocks, 16x16 or 32x32 maps). */
 int stk_gn_bwd_pl_ok(int C, int HW, int G);
@@ -149,7 +147,7 @@ int stk_gn_bwd_pl_f32(const float* dy, const float* x, int C, const float* gamma
                       const float* rstd, float* ws, int N, int HW, int G, int act, float drop_p, unsigned long long seed,
                       const unsigned long long* seed_dev, float* dx_sum, float out_scale, float* dtemb, int temb_stride,
                       const float* dymax, const float* gnrec, void* planes, float* rec, float* amax_true, void* stream);
-/* stk_gn_fwd_pl_max_f32 (xmax1 / xmax2 may be NULL) that also fills gnrec[512] (see above).  Shapes: stk_gn_fwd_rec_ok. */
+/* stk_gn_fwd_pl_max_f32 (xmax1 / xmax2 may be NULL) that also fills gnrec[N G] (see above).  Shapes: stk_gn_fwd_rec_ok. */
 int stk_gn_fwd_rec_ok(int C1, int C2, int HW, int G);
 int stk_gn_fwd_pl_rec_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
                           void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,

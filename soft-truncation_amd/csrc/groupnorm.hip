@@ -485,8 +485,9 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
       // separate pass).  Non-negative floats order like their bit patterns: an integer max is exact and order-independent
       float m = 0.f;
       for (int w = 0; w < (T >> 6); ++w) m = fmaxf(m, s_mx[w]);
-      // slot = image mod 256: per-IMAGE maxima for batches of up to 256 (include/stk.h; the engine's dynamic-range report)
-      atomicMax(reinterpret_cast<unsigned*>(out.amax) + (n & 255), __float_as_uint(m));
+      // (slot = block id mod 256, NOT image mod 256: the 32 workgroups of an image run at the same time, and 32 atomics on one
+      // address cost this kernel 44 -> 54 us on the 32x32 layers, 11 -> 18 us on the 8x8 ones -- measured, round 5)
+      atomicMax(reinterpret_cast<unsigned*>(out.amax) + (blockIdx.x & 255), __float_as_uint(m));
     }
   }
 }
@@ -498,10 +499,10 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
 // and the pass disappear.  Two things stood in the way:
 //   * the scale of the planes must be known before the first value is written.  It is derived a priori, per launch, from records
 //     earlier kernels leave behind: with D_n = max |dy| of image n (the producing data-gradient GEMM's epilogue,
-//     stk_conv2d_dgrad_pl_max_f32), R_n / X_n = the largest rstd / |xhat| of image n (the forward, stk_gn_fwd_pl_rec_f32),
+//     stk_conv2d_dgrad_pl_max_f32), r_ng = rstd and X_ng = max |xhat| of group (n, g) (the forward, stk_gn_fwd_pl_rec_f32),
 //     Gamma = max |gamma|, S = the largest slope of the activation and K = the dropout scale,
-//         |dx| = rstd |gamma du - m1 - xhat m2| <= R_n Gamma S K D_n (2 + X_n)        (|m1|, |m2| <= Gamma max|du|: mean |xhat| <= 1)
-//     and the record is the maximum of that over the images -- a bound within a small factor of the true maximum (measured 4-12x;
+//         |dx| = rstd |gamma du - m1 - xhat m2| <= r_ng Gamma S K D_n (2 + X_ng)      (|m1|, |m2| <= Gamma max|du|: mean |xhat| <= 1)
+//     and the record is the maximum of that over the groups of all images -- a bound within a small factor of the true maximum (measured 4-12x;
 //     GroupNorm's forward planes live with sqrt(L - 1) / max |xhat| ~ 13x), every workgroup computes the same value;
 //   * a workgroup of the flat kernel owns one group = 4 or 8 channels, i.e. 8 or 16 bytes of every 64-byte plane row.  Rows written
 //     in 16-byte pieces by four workgroups reach HBM at full speed when those workgroups share an XCD (their pieces merge in its L2),
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(2048 / IPT) void gn_bwd_pl_kernel(GnArgs a, const f
 
   // ---- the a-priori bound of this launch's |dx| (see above); identical in every workgroup
   float bnd = 0.f, gmax = 0.f;
-  for (int i = threadIdx.x; i < 256; i += T) bnd = fmaxf(bnd, o.gnrec[i] * (2.f + o.gnrec[256 + i]) * o.dymax[i]);
+  for (int i = threadIdx.x; i < a.N * a.G; i += T) bnd = fmaxf(bnd, rstd_in[i] * (2.f + o.gnrec[i]) * o.dymax[(i / a.G) & 255]);
   for (int c = threadIdx.x; c < C; c += T) gmax = fmaxf(gmax, fabsf(a.gamma[c]));
 
   float du[IPT][4], xh[IPT][4], gam[IPT];
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(2048 / IPT) void gn_bwd_pl_kernel(GnArgs a, const f
   if (o.amax_true && threadIdx.x == 0) {
     float m = 0.f;
     for (int w = 0; w < nw; ++w) m = fmaxf(m, s_mx[w]);
-    atomicMax(reinterpret_cast<unsigned*>(o.amax_true) + (n & 255), __float_as_uint(m));
+    atomicMax(reinterpret_cast<unsigned*>(o.amax_true) + (blockIdx.x & 255), __float_as_uint(m));
   }
   // ---- [8 channels][pixel] -> [pixel][8 channels] as two 16-byte pieces (hi, lo) per pixel
   unsigned char* const prow = o.planes + ((long)rs * a.HW) * 64 + piece * 16;
@@ -1052,9 +1053,10 @@ __global__ __launch_bounds__(1024) void gn_fwd_pl_kernel(GnArgs a, float* __rest
 // pl::split_planes_kernel -- a workgroup per (sample, 32-channel block, 128-pixel tile), all element-wise work done on
 // the float4 (four consecutive pixels of one channel = one dropout RNG quad) before the tile goes through LDS for the
 // transposition to [pixel][32 channels].  x is read twice, the second time out of the Infinity Cache.
-// gnrec (may be NULL; stk_gn_fwd_pl_rec_f32): two caller-zeroed 256-slot records filled by atomic maximum, slot = image mod 256:
-// [0..256) max over the image's groups of rstd, [256..512) of max |xhat| (times 1.0001).  The
-// backward that writes the planes of its input gradient itself (gn_bwd_pl_kernel) derives their scale from these.
+// gnrec (REC; stk_gn_fwd_pl_rec_f32): gnrec[n G + g] = max |xhat| of the group (times 1.0001), a plain store per workgroup.  (The
+// first version kept per-image maxima by atomic maximum: the 32 workgroups of an image hit one address at the same time and the
+// kernel ran 13.4 -> 26.7 us.)  The backward that writes the planes of its input gradient itself (gn_bwd_pl_kernel) derives their
+// scale from these and from rstd.
 // (REC is a template parameter: with the branch inside the streaming loop every launch of the kernel ran 13.3 -> 21.0 us)
 template <bool REC>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a, float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -1098,8 +1100,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a, float* __restri
     if (threadIdx.x == 0) {
       const float hi = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), lo = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
       // max |x - mean| = max(hi - md, md - lo): x - mean = (x - shift) - md
-      atomicMax(reinterpret_cast<unsigned*>(gnrec) + (n & 255), __float_as_uint(rstd_v));
-      atomicMax(reinterpret_cast<unsigned*>(gnrec) + 256 + (n & 255), __float_as_uint(fmaxf(hi - md, md - lo) * rstd_v * 1.0001f));
+      gnrec[ng] = fmaxf(hi - md, md - lo) * rstd_v * 1.0001f;
     }
     __syncthreads();
   }
@@ -1318,9 +1319,8 @@ static inline bool gn_fwd_rec_shape(int C1, int C2, int HW, int G) {
   return gn_pl_2k_ok(C1, C2, HW, G) && (long)((C1 + C2) / G) * HW <= 16384;
 }
 
-/* stk_gn_fwd_pl_max_f32 (xmax1 / xmax2 may be NULL here) that also leaves gnrec[512] behind: per image (slot n mod 256, atomic maximum,
- * caller-zeroed) the largest rstd of its groups and a bound of its largest |xhat| -- what stk_gn_bwd_pl_f32 derives the scale of
- * its planes from. */
+/* stk_gn_fwd_pl_max_f32 (xmax1 / xmax2 may be NULL here) that also leaves gnrec[N G] behind: max |xhat| of every (image, group) --
+ * what stk_gn_bwd_pl_f32 derives the scale of its planes from (with rstd). */
 int stk_gn_fwd_pl_rec_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
                           void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
                           float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws,

@@ -705,28 +705,29 @@ class Executor:
     """Per-image dynamic range of the output gradients of the LAST backward: the split convolutions scale a tensor by ONE power
     of two (include/stk.h "Planes"), which keeps every image at fp32 accuracy only while its own maximum lies within about five
     decades of the batch maximum (tests/test_gpu_kernels.py::test_conv_split_per_image_accuracy: 2e-7 down to 1e-4 of the
-    maximum, 9e-7 at 1e-5, 8e-6 at 1e-6).  The GroupNorm backward leaves max |dy| PER IMAGE in the records it writes
-    (stk_gn_bwd_out_f32, slot n mod 256), so the spread costs nothing to know.  Returns [(layer, max over images, smallest
-    non-zero image maximum, decades between them)] for the convolutions served that way, worst first.  Synchronises."""
+    maximum, 9e-7 at 1e-5, 8e-6 at 1e-6).  Reads the fp32 output gradients the backward left in the gradient arena (they live
+    until the context's next backward) -- a diagnostic for every few hundred steps, not a by-product of the kernels: per-image
+    maxima by atomic maximum made the 32 workgroups of an image hit one address at once and cost the GroupNorm backward 20-60 %.
+    Returns [(layer, max over images, smallest non-zero image maximum, decades between them)] for the 3x3 convolutions whose
+    output gradient exists as fp32, worst first.  Synchronises."""
     c = getattr(self, '_last_ctx', None)
-    if c is None or c.prog.graph.amax_block is None:
+    if c is None or c.gact is None:
       return []
     g = c.prog.graph
-    n = len(g.conv_amax)
-    from .graph import AMAX
-    blk = c.act[g.amax_block.off:g.amax_block.off + AMAX * n].view(n, AMAX).detach().cpu()
     rows = []
-    for op in g.ops:
-      if not isinstance(op, Conv) or op.dy_prod is None:
-        continue
-      holder = op.dy_peer if op.dy_peer is not None else op
-      first = 1024 if op.dy_pl_from is not None else 512       # the true maxima live beside an a-priori bound (stk_gn_bwd_pl_f32)
-      per = blk[(holder.amax.off - g.amax_block.off) // AMAX, first:first + min(op.N, 256)]
-      per = per[torch.isfinite(per) & (per > 0)]
-      if per.numel() < 2:
-        continue
-      hi, lo = float(per.max()), float(per.min())
-      rows.append((op.y.name, hi, lo, float(np.log10(hi / lo))))
+    with torch.no_grad():
+      for op in g.ops:
+        if not isinstance(op, Conv) or op.KH != 3 or not (op.pl_dgrad or op.pl_wgrad) or op.dy_pl_from is not None:
+          continue
+        t = op.y
+        if not t.needs_grad or t.goff is None:
+          continue
+        per = c.gact[t.goff:t.goff + t.numel].view(op.N, -1).abs().amax(dim=1)
+        per = per[torch.isfinite(per) & (per > 0)]
+        if per.numel() < 2:
+          continue
+        hi, lo = float(per.max()), float(per.min())
+        rows.append((t.name, hi, lo, float(np.log10(hi / lo))))
     rows.sort(key=lambda r: -r[3])
     return rows
 

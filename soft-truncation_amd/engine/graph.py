@@ -299,7 +299,7 @@ class GroupNormAct(Op):
     # Graph._plan_dy_planes (round 5): this layer normalises the output of convolution `pl_bwd` and nobody else reads it: its
     # backward writes that convolution's dy PLANES itself (stk_gn_bwd_pl_f32) -- no fp32 gradient, no split pass.  `dx_src` = the
     # convolution whose data gradient produces this layer's dy (it leaves max |dy| per image), `gnrec` = this layer's forward
-    # records (max rstd / max |xhat| per image)
+    # record (max |xhat| per image and group)
     self.pl_bwd = None
     self.dx_src = None
     self.gnrec = None
@@ -1120,14 +1120,12 @@ class ZeroXRecords(Op):
   """First op of the plan: zeroes the |x1| / |x2| thirds of every convolution's amax buffer -- the records the GroupNorm
   forward kernels fill by atomic maximum (Graph._plan_x_records); every other user writes its record after this."""
 
-  def __init__(self, block, count, gnrec=None):
-    self.block, self.count, self.gnrec = block, count, gnrec
+  def __init__(self, block, count):
+    self.block, self.count = block, count
     self.y = block
 
   def forward(self, rt):
     rt.lib.fill_strided_f32(rt.v(self.block), 0.0, self.count, 512, AMAX, rt.stream)
-    if self.gnrec is not None:         # the records the plane-writing GroupNorm backwards read (Graph._plan_dy_planes)
-      rt.lib.fill_f32(rt.v(self.gnrec), 0.0, self.gnrec.numel, rt.stream)
 
   def backward(self, rt):
     pass
@@ -1455,15 +1453,8 @@ class Graph:
         continue
       gn.pl_bwd, gn.dx_src, c0.dy_pl_from, c1.dx_rec = c0, c1, gn, True
       recs.append(gn)
-    if recs:
-      block = self.new((512 * len(recs),), needs_grad=False, name='gn.rec')
-      for i, gn in enumerate(recs):
-        gn.gnrec = Tensor((512,), 'act', block.off + 512 * i, False, gn.y.name + '.rec')
-      zero = next((op for op in self.ops if isinstance(op, ZeroXRecords)), None)
-      if zero is None:
-        self.ops.insert(0, ZeroXRecords(self.amax_block, len(self.conv_amax), block))
-      else:
-        zero.gnrec = block
+    for gn in recs:
+      gn.gnrec = self.new((gn.N * gn.G,), needs_grad=False, name=gn.y.name + '.xhat')      # max |xhat| per (image, group): plain stores
 
   def _plan_shared_dy(self, lib):
     """ResnetBlockBigGANpp with a shortcut convolution: out = (Conv_2(x) + Conv_1(h)) / sqrt 2 (layerspp.py:283-287) is

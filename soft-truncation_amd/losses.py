@@ -285,7 +285,7 @@ def _pick_loss_fn(config, sde, train):
 
 # STK_DDP_OVERLAP=0: exchange the gradients after the backward (one bucketed all-reduce) instead of during it
 OVERLAP_EXCHANGE = os.environ.get('STK_DDP_OVERLAP', '1') != '0'
-# STK_RANGE_CHECK=K: every K-th training step (and the first) the per-image maxima of the output gradients are read back
+# STK_RANGE_CHECK=K: every K-th training step (and the first) the per-image maxima of the fp32 output gradients are computed
 # (Executor.dynamic_range_report) and a warning is issued when an image lies more than RANGE_DECADES below the batch maximum
 # of some layer -- beyond that the one-scale-per-tensor split convolutions no longer give that image fp32 accuracy
 # (likelihood-weighted VE losses with g^2 weights are the candidate, reference losses.py:126-129).  0 = off.

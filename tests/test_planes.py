@@ -473,7 +473,7 @@ def test_gn_backward_to_planes(ref_lib, hip_lib, case):
     xd, dyd, ga, be = x.to(d), dy.to(d), gamma.to(d), beta.to(d)
     mean, rstd = torch.zeros(N * G, device=d), torch.zeros(N * G, device=d)
     rec_y = torch.zeros(256, device=d)
-    gnrec = torch.zeros(512, device=d)
+    gnrec = torch.full((N * G,), float('nan'), device=d)
     ypl = torch.zeros(int(lib.planes_bytes(N, C, HW)), dtype=torch.uint8, device=d)
     wsf = torch.zeros(int(lib.gn_ws_bytes(N, C, HW, G)) // 4 + 64, device=d)
     call(lib, 'gn_fwd_pl_rec_f32', xd, C, None, 0, ga, be, None, ypl, rec_y, mean, rstd, N, HW, G, 1e-6, act, drop, 77, None, wsf,
@@ -500,10 +500,7 @@ def test_gn_backward_to_planes(ref_lib, hip_lib, case):
     assert np.abs(o['dec'] - o['dx']).max() <= max(4e-6 * top, 2.0 ** -24 / o['scale']), float(np.abs(o['dec'] - o['dx']).max() / top)
     assert float(o['rec'][0]) >= np.abs(o['dx']).max() and float(o['rec'][1:].abs().max()) == 0.0
     assert float(o['rec'][0]) <= 64.0 * np.abs(o['dx']).max(), (float(o['rec'][0]), np.abs(o['dx']).max())
-    per = np.zeros(256)
-    for n in range(N):
-      per[n & 255] = max(per[n & 255], np.abs(o['dx'][n]).max())
-    assert np.allclose(o['amax_true'].numpy(), per, rtol=2e-5, atol=0)
+    assert np.isclose(float(o['amax_true'].max()), np.abs(o['dx']).max(), rtol=2e-5, atol=0)
   # HIP against the oracle
   assert np.abs(h['dec'] - r['dx']).max() <= 1e-5 * top
   assert (h['ws'] - r['ws']).abs().max().item() <= 1e-4 * r['ws'].abs().max().item()
@@ -512,9 +509,8 @@ def test_gn_backward_to_planes(ref_lib, hip_lib, case):
   assert (h['dx_sum'] - r['dx_sum']).abs().max().item() <= 2e-5 * scale + 1e-6 * top * HW
   assert (h['dtemb'][:, :C] - r['dtemb'][:, :C]).abs().max().item() <= 2e-5 * scale + 1e-6 * top * HW
   assert float(h['dtemb'][:, C:].abs().max()) == 0.0
-  # the forward's records: max rstd per image, and max |xhat| per image (the HIP kernel's carries a factor 1.0001)
-  assert np.allclose(h['gnrec'][:256].numpy(), r['gnrec'][:256].numpy(), rtol=1e-5)
-  hx, rx = h['gnrec'][256:].numpy(), r['gnrec'][256:].numpy()
+  # the forward's record: max |xhat| per (image, group) (the HIP kernel's carries a factor 1.0001)
+  hx, rx = h['gnrec'].numpy(), r['gnrec'].numpy()
   assert np.all(hx >= rx * (1 - 1e-5)) and np.all(hx <= 1.001 * rx + 1e-30)
   print('bound / true maximum:', float(h['rec'][0]) / np.abs(h['dx']).max())
 
