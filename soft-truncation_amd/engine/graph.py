@@ -34,7 +34,11 @@ _ALIGN = 64  # floats (256 B) -- keeps every buffer float4-aligned
 # max |dx| per image left by its data gradient (stk_conv2d_dgrad_pl_max_f32) and the TRUE max |dy| per image where [2] holds an
 # a-priori bound (stk_gn_bwd_pl_f32)
 AMAX = 1280
-STK_DY_PLANES = os.environ.get('STK_DY_PLANES', '1') != '0'
+# OFF by default (STK_DY_PLANES=1 switches it on): measured inside the training step (profiles/r05_dy_planes.txt) the plane-writing
+# GroupNorm backward takes 61 us where the fp32-writing one takes 43 (its 16-byte pieces of a row come from four workgroups that
+# reach their store phases microseconds apart, so the rows no longer merge in L2 the way they do in the lock-step probe), which eats
+# the 19.7 us of the split pass it removes: 38.21-38.26 -> 38.29-38.48 ms per step.
+STK_DY_PLANES = os.environ.get('STK_DY_PLANES', '0') == '1'
 
 
 def _round_up(n, a=_ALIGN):

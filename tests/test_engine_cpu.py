@@ -479,6 +479,7 @@ def test_groupnorm_backward_writes_the_dy_planes_of_the_convolution_before_it(st
   import torch
   from importlib import import_module
   G = import_module('soft-truncation_amd.engine.graph')
+  monkeypatch.setattr(G, 'STK_DY_PLANES', True)                          # (off by default: measured slower inside the step)
   cases.forward_backward(st, ref_lib, 'wide', B=2)                       # against RefNet, with the planes plan
   cfg, cfg_cpu, sde, model, ref = cases.build_pair(st, cases.tiny_config(st, 'wide'), ref_lib)
   x, t = torch.randn(2, 3, 16, 16), torch.rand(2) * 999
