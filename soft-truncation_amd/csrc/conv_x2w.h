@@ -252,8 +252,14 @@ inline Plan plan(int N, int H, int W, int Cin, int Cout) {
   static const long cap_mb = [] { const char* e = getenv("STK_WGRAD_SLAB_MB"); return e ? atol(e) : 128L; }();
   // at most 512 workgroups = ONE round of two per CU (rounding the quotient up gave 516 for 12 tiles: a second round of four
   // workgroups, 441 us instead of ~330 on the 384 -> 128 layer at 32 x 32)
-  // STK_X2W_WGS (A/B): workgroups to fill (512 = one round of two per CU)
-  static const long target = [] { const char* e = getenv("STK_X2W_WGS"); return e && atol(e) > 0 ? atol(e) : 512L; }();
+  // STK_X2W_WGS (A/B): workgroups the K split fills.  Round 5: 256 = ONE four-wave workgroup per CU (128 eight-wave ones on the 8- / 16-wide
+  // maps), not the two that fit.  The weight gradients run on the side stream BESIDE the main chain of the backward; two workgroups per CU
+  // with their 256 accumulation registers per lane leave no room for anybody else's waves, so "two streams" was time slicing (summed
+  // kernel durations 54 ms for 40 ms of work, tools/stream_timeline.py); with half of every CU free the main chain's kernels really
+  // run beside them -- and the slab traffic halves.  Measured inside the step (512 -> 256, with STK_SIDE_SHORTCUT=0; profiles/
+  // r05_insitu_sweeps.txt): CIFAR-10 net 37.6 -> 36.4 ms, 256x256 net at batch 4 39.4 -> 37.6, 64x64 net 121.6 -> 120.4.  The kernel
+  // alone is slower that way (the round-3 micro-benchmark chose 512); the step is what counts.
+  static const long target = [] { const char* e = getenv("STK_X2W_WGS"); return e && atol(e) > 0 ? atol(e) : 256L; }();
   long splits = tiles >= target ? 1 : target / tiles;
   if (splits > nch / 8) splits = nch / 8;
   const long cap = (cap_mb << 20) / (9L * Cout * Cin * 4);

@@ -22,7 +22,10 @@ import numpy as np
 
 SQRT2 = float(np.float32(np.sqrt(2.)))
 # A/B switches of the side stream (engine/executor.SideStream): shortcut convolutions' backward / fp32-operand weight gradients
-_SIDE_SHORTCUT = os.environ.get('STK_SIDE_SHORTCUT', '1') != '0'
+# (round 5: the shortcut convolutions' backward stays on the MAIN stream by default -- together with weight gradients that leave half of
+# every CU free (csrc/conv_x2w.h: STK_X2W_WGS = 256) that is 1.2 ms per step better than both on the side stream, measured inside the
+# step on five boxes: profiles/r05_insitu_sweeps.txt)
+_SIDE_SHORTCUT = os.environ.get('STK_SIDE_SHORTCUT', '0') != '0'
 _SIDE_WGRAD1 = os.environ.get('STK_SIDE_WGRAD1', '1') != '0'
 _SIDE_FWD = os.environ.get('STK_FWD_SIDE', '0') == '1'     # shortcut convolutions of an (eagerly launched) forward on the side stream
 _SIDE_W1_FILTER = None      # debugging: predicate on the Conv op
