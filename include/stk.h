@@ -321,6 +321,11 @@ int stk_conv2d_wgrad_pl_ok(int N, int H, int W, int Cin, int Cout);
 long stk_conv2d_wgrad_pl_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int stk_conv2d_wgrad_pl_f32(const void* xpl, const float* xrec, const void* dypl, const float* dyrec, float* dw,
                             float alpha, float* ws, long ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
+/* the same with the number of workgroups its K split fills chosen by the caller: 0 = the default (one workgroup per CU: a weight gradient
+ * launched on a side stream leaves half of every CU to the kernels of the main stream), e.g. 512 = two per CU for a launch that has the
+ * chip to itself; <= 1024.  Results agree up to the summation order of the K-split slabs. */
+int stk_conv2d_wgrad_pl_wgs_f32(const void* xpl, const float* xrec, const void* dypl, const float* dyrec, float* dw,
+                                float alpha, float* ws, long ws_bytes, int N, int H, int W, int Cin, int Cout, int wgs, void* stream);
 
 /* dtemb[n*temb_stride + c] = alpha * sum_hw dy[n,c,:]  (written; may be NULL);
  * dbias[c] += alpha * sum_{n,hw} dy[n,c,:]              (accumulated; may be NULL).

@@ -1635,14 +1635,26 @@ int stk_conv2d_dgrad_pl_max_f32(const void* dypl, const float* dyamax, const flo
 int stk_conv2d_wgrad_pl_ok(int N, int H, int W, int Cin, int Cout) { return x2w::plan(N, H, W, Cin, Cout).ok; }
 
 long stk_conv2d_wgrad_pl_ws_bytes(int N, int H, int W, int Cin, int Cout) {
-  const x2w::Plan q = x2w::plan(N, H, W, Cin, Cout);
-  return q.ok ? (long)q.splits * q.slab * 4 + 256 : 0;
+  // (covers every workgroup count a caller may ask for: the slabs of the deepest K split)
+  long m = 0;
+  for (int wgs : {0, 256, 512, 768, 1024}) {
+    const x2w::Plan q = x2w::plan(N, H, W, Cin, Cout, wgs);
+    if (q.ok && (long)q.splits * q.slab > m) m = (long)q.splits * q.slab;
+  }
+  return m ? m * 4 + 256 : 0;
 }
 
 int stk_conv2d_wgrad_pl_f32(const void* xpl, const float* xrec, const void* dypl, const float* dyrec, float* dw,
                             float alpha, float* ws, long ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream) {
-  if (!xpl || !xrec || !dypl || !dyrec || !dw || !ws) return STK_EINVAL;
-  const x2w::Plan q = x2w::plan(N, H, W, Cin, Cout);
+  return stk_conv2d_wgrad_pl_wgs_f32(xpl, xrec, dypl, dyrec, dw, alpha, ws, ws_bytes, N, H, W, Cin, Cout, 0, stream);
+}
+
+/* ... with the number of workgroups its K split fills chosen by the caller (0 = the library's default for a launch that shares the chip
+ * with another stream; <= 1024).  Same result up to the summation order of the slabs. */
+int stk_conv2d_wgrad_pl_wgs_f32(const void* xpl, const float* xrec, const void* dypl, const float* dyrec, float* dw,
+                                float alpha, float* ws, long ws_bytes, int N, int H, int W, int Cin, int Cout, int wgs, void* stream) {
+  if (!xpl || !xrec || !dypl || !dyrec || !dw || !ws || wgs < 0 || wgs > 1024) return STK_EINVAL;
+  const x2w::Plan q = x2w::plan(N, H, W, Cin, Cout, wgs);
   if (!q.ok) return STK_EUNSUPPORTED;
   if (ws_bytes < (long)q.splits * q.slab * 4) return STK_EINVAL;
   x2w::Args a = {};

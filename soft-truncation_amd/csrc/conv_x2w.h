@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void wgrad_kernel(Args a) {
 // (a chunk is two whole images), channel counts in whole 32-blocks (planes), enough work to fill the chip
 struct Plan { int ok; int splits; int chunks_per_split; long slab; int groups; };
 inline int groups_mode() { static const int v = [] { const char* e = getenv("STK_X2W_GROUPS"); return e ? atoi(e) : 2; }(); return v; }
-inline Plan plan(int N, int H, int W, int Cin, int Cout) {
+// wgs: workgroups the K split fills; 0 = the default for a launch that shares the chip with another stream (STK_X2W_WGS, 256), else the
+// caller's figure (the engine passes STK_X2W_WGS_ALONE = 512 when the weight gradient runs on the main stream with nothing beside it)
+inline Plan plan(int N, int H, int W, int Cin, int Cout, int wgs = 0) {
   Plan r = {0, 1, 0, 0, 1};
   if (H != W || W < 4 || (W & (W - 1)) || Cin % 32 || Cout % 32 || Cin < 32 || Cout < 32) return r;
   const long px = (long)N * H * W;
@@ -259,7 +261,8 @@ inline Plan plan(int N, int H, int W, int Cin, int Cout) {
   // run beside them -- and the slab traffic halves.  Measured inside the step (512 -> 256, with STK_SIDE_SHORTCUT=0; profiles/
   // r05_insitu_sweeps.txt): CIFAR-10 net 37.6 -> 36.4 ms, 256x256 net at batch 4 39.4 -> 37.6, 64x64 net 121.6 -> 120.4.  The kernel
   // alone is slower that way (the round-3 micro-benchmark chose 512); the step is what counts.
-  static const long target = [] { const char* e = getenv("STK_X2W_WGS"); return e && atol(e) > 0 ? atol(e) : 256L; }();
+  static const long shared = [] { const char* e = getenv("STK_X2W_WGS"); return e && atol(e) > 0 ? atol(e) : 256L; }();
+  const long target = wgs > 0 ? wgs : shared;
   long splits = tiles >= target ? 1 : target / tiles;
   if (splits > nch / 8) splits = nch / 8;
   const long cap = (cap_mb << 20) / (9L * Cout * Cin * 4);

@@ -28,6 +28,7 @@ SQRT2 = float(np.float32(np.sqrt(2.)))
 _SIDE_SHORTCUT = os.environ.get('STK_SIDE_SHORTCUT', '0') != '0'
 _SIDE_WGRAD1 = os.environ.get('STK_SIDE_WGRAD1', '1') != '0'
 _SIDE_FWD = os.environ.get('STK_FWD_SIDE', '0') == '1'     # shortcut convolutions of an (eagerly launched) forward on the side stream
+_X2W_WGS_ALONE = int(os.environ.get('STK_X2W_WGS_ALONE', '512'))     # weight gradients launched on the main stream (nothing beside them)
 _SIDE_W1_FILTER = None      # debugging: predicate on the Conv op
 _SIDE_DELAY = int(os.environ.get('STK_SIDE_DELAY', '0'))
 _SIDE_DELAY_FILTER = None
@@ -704,9 +705,11 @@ class Conv(Op):
       rt.side_launch(lib.conv2d_wgrad_pl_f32, rt.planes(self.x1), rt.rec(self.x1), dypl, dy_rec, gw, alpha, rt.ws2,
                      rt.ws_bytes, self.N, self.H, self.W, self.C1, self.Cout)
     elif pl_wgrad:
-      rt.timed(self._label_pl(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_pl_f32,
+      # on the main stream with nothing beside it (one-stream mode, the profiler's eager steps): fill the chip -- two workgroups per CU;
+      # the side-stream launch above keeps the library's default of one, which leaves room for the main chain (csrc/conv_x2w.h)
+      rt.timed(self._label_pl(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_pl_wgs_f32,
                rt.planes(self.x1), rt.rec(self.x1), dypl, dy_rec, gw, alpha, rt.ws, rt.ws_bytes,
-               self.N, self.H, self.W, self.C1, self.Cout, rt.stream)
+               self.N, self.H, self.W, self.C1, self.Cout, _X2W_WGS_ALONE, rt.stream)
     elif gw is not None and rt.side is not None and rt.prof is None and _SIDE_WGRAD1 and (_SIDE_W1_FILTER is None or _SIDE_W1_FILTER(self)):
       # a weight gradient is a leaf of the backward: x, dy and this layer's own records in, dw out
       rt.side_launch(lib.conv2d_wgrad_amax_f32, rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, gy, gw, self.w_layout, alpha,

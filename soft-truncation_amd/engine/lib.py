@@ -76,6 +76,7 @@ SIGNATURES = {
   'stk_conv2d_wgrad_pl_ok': [I, I, I, I, I],
   'stk_conv2d_wgrad_pl_ws_bytes': [I, I, I, I, I],
   'stk_conv2d_wgrad_pl_f32': [P, P, P, P, P, F, P, L, I, I, I, I, I, S],
+  'stk_conv2d_wgrad_pl_wgs_f32': [P, P, P, P, P, F, P, L, I, I, I, I, I, I, S],
   'stk_bias_grad_f32': [P, I, I, I, F, P, I, P, P, S],
   'stk_bias_grad_amax_f32': [P, I, I, I, F, P, I, P, P, P, S],
   'stk_bias_grad_amax_res_f32': [P, I, I, I, F, P, I, P, P, P, F, P, S],

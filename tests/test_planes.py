@@ -422,6 +422,11 @@ def test_wgrad_from_planes(ref_lib, hip_lib, case):
     ws = torch.full((nb // 4 + 64,), float('nan'), device=d)
     dw = dw0.clone().to(d)
     call(lib, 'conv2d_wgrad_pl_f32', xp, ax, yp, ay, dw, 0.5, ws, nb, N, H, H, Cin, Cout)
+    # round 5: the caller may choose how many workgroups the K split fills (the engine: one per CU beside another stream, two alone)
+    for wgs in (512, 128, 1024):
+      dwv = dw0.clone().to(d)
+      call(lib, 'conv2d_wgrad_pl_wgs_f32', xp, ax, yp, ay, dwv, 0.5, ws, nb, N, H, H, Cin, Cout, wgs)
+      assert (dwv - dw).abs().max().item() <= 2e-6 * (dw - dw0.to(d)).abs().max().item(), wgs
     dw32 = dw0.clone().to(d)
     call(lib, 'conv2d_wgrad_f32', xd, Cin, None, 0, dyd, dw32, 0, 0.5, ws, nb, N, H, H, Cout, H, H, 3, 3, 1, 1)
     return dw.cpu(), dw32.cpu()
