@@ -28,7 +28,11 @@ SQRT2 = float(np.float32(np.sqrt(2.)))
 _SIDE_SHORTCUT = os.environ.get('STK_SIDE_SHORTCUT', '0') != '0'
 _SIDE_WGRAD1 = os.environ.get('STK_SIDE_WGRAD1', '1') != '0'
 _SIDE_FWD = os.environ.get('STK_FWD_SIDE', '0') == '1'     # shortcut convolutions of an (eagerly launched) forward on the side stream
-_X2W_WGS_ALONE = int(os.environ.get('STK_X2W_WGS_ALONE', '512'))     # weight gradients launched on the main stream (nothing beside them)
+# Workgroups of a weight gradient launched on the MAIN stream (one-stream mode, the profiler's eager steps), 0 = the same count as on the side
+# stream.  512 (two per CU) is the faster setting for a kernel that has the chip to itself, but a different K split sums its slabs in a
+# different order, and the one-stream backward is the bit-for-bit reference of the two-stream one (tests/test_gpu_model.py::
+# test_two_streams_are_deterministic): the default keeps the arithmetic of the two modes identical.
+_X2W_WGS_ALONE = int(os.environ.get('STK_X2W_WGS_ALONE', '0'))
 _SIDE_W1_FILTER = None      # debugging: predicate on the Conv op
 _SIDE_DELAY = int(os.environ.get('STK_SIDE_DELAY', '0'))
 _SIDE_DELAY_FILTER = None
@@ -705,8 +709,7 @@ class Conv(Op):
       rt.side_launch(lib.conv2d_wgrad_pl_f32, rt.planes(self.x1), rt.rec(self.x1), dypl, dy_rec, gw, alpha, rt.ws2,
                      rt.ws_bytes, self.N, self.H, self.W, self.C1, self.Cout)
     elif pl_wgrad:
-      # on the main stream with nothing beside it (one-stream mode, the profiler's eager steps): fill the chip -- two workgroups per CU;
-      # the side-stream launch above keeps the library's default of one, which leaves room for the main chain (csrc/conv_x2w.h)
+      # (on the main stream: STK_X2W_WGS_ALONE may ask for more workgroups than the side-stream launch above uses; see _X2W_WGS_ALONE)
       rt.timed(self._label_pl(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_pl_wgs_f32,
                rt.planes(self.x1), rt.rec(self.x1), dypl, dy_rec, gw, alpha, rt.ws, rt.ws_bytes,
                self.N, self.H, self.W, self.C1, self.Cout, _X2W_WGS_ALONE, rt.stream)
