@@ -63,6 +63,8 @@ class _GnFoldDesc(ctypes.Structure):       # StkGnFoldDesc of include/stk.h
 _LIB_ONLY = os.environ.get('STK_LIB_ONLY', '1' if _POISON else '0') == '1'
 # STK_WP_SIDE=0: the data-gradient weight blocks are prepared in front of the forward with the forward blocks (A/B switch)
 _WP_SIDE = os.environ.get('STK_WP_SIDE', '1') != '0'
+# STK_XCHG_NOJOIN=0: every segment of the overlapped gradient exchange ends with a join of the side stream into the main one (round 4)
+_XCHG_NOJOIN = os.environ.get('STK_XCHG_NOJOIN', '1') != '0'
 
 from torch.utils._python_dispatch import TorchDispatchMode
 
@@ -671,15 +673,28 @@ class Executor:
               rt.gbase['act'] = c.gact.data_ptr()
               rt.gbase['param'] = flat.grad.data_ptr()
               rt.stream = stk_lib.stream_ptr(flat.device)
+            last = end >= len(order)
             with _launch_window(_LIB_ONLY and rt.side is not None):
               for op in order[begin:end]:
                 rt.guard(op)
                 op.backward(rt)
               rt.flush_folds()
-              rt.join_side()
+              if last or rt.side is None or not _XCHG_NOJOIN:
+                rt.join_side()
+            if not last and rt.side is not None and _XCHG_NOJOIN and ranges:
+              # A bucket is final once the main chain AND the side stream's weight gradients launched so far are done.  Joining the side
+              # stream into the main one at every segment end made the main chain wait for it four times per step (with one weight-
+              # gradient workgroup per CU the side stream runs further behind: exchange proxy +0.5 -> +1.5 ms per step); instead a third
+              # stream waits for both and the bucket's all-reduce is issued from THAT stream's context -- the communicator's stream
+              # then waits for it, the main chain for nobody.
+              self._hand_over(rt, hook, ranges)
+              begin = end
+              continue
         begin = end
         for lo, hi in ranges:
           hook(lo, hi)
+      if not graphs:
+        rt.join_side()              # (no-op after a joined last segment; a skipped one must not leave side work unjoined)
       done = True
     elif self._graphs_on() and rt.seed_dev is not None and (self.bwd_graphs or not param_grads or rt.side is None):
       done = self._replay(c, 'bwd', rt.training, param_grads=param_grads)
@@ -700,6 +715,22 @@ class Executor:
       gx = c.gact[xin.goff:xin.goff + xin.numel].view(xin.shape).clone()
     prog.release(c)
     return gx
+
+  def _hand_over(self, rt, hook, ranges):
+    """Issue the all-reduce of finished buckets behind BOTH streams of the backward without making either wait for the other."""
+    dev = self.flat.device
+    main = torch.cuda.current_stream(dev)
+    x = getattr(self, '_xchg_stream', None)
+    if x is None or x.device != dev:
+      x = self._xchg_stream = torch.cuda.Stream(dev)        # carries only event waits and the collectives' issue point
+    ev = torch.cuda.Event()
+    ev.record(main)
+    x.wait_event(ev)
+    if rt.side.last is not None:
+      x.wait_event(rt.side.last)
+    with torch.cuda.stream(x):
+      for lo, hi in ranges:
+        hook(lo, hi)
 
   def dynamic_range_report(self):
     """Per-image dynamic range of the output gradients of the LAST backward: the split convolutions scale a tensor by ONE power
