@@ -664,7 +664,18 @@ def main():
   device = torch.device('cuda', local_rank)
   exchange_stream = None
   if world > 1:
+    # steer torch's stream pool first, so that the communicator's stream lands on a hardware queue of its own (engine/ddp.py:
+    # a communicator on the launch or the side stream's queue would serialise the overlapped exchange behind the backward)
+    steered = None
+    try:
+      from importlib import import_module
+      _ddp = import_module('soft-truncation_amd.engine.ddp')
+      _ex = import_module('soft-truncation_amd.engine.executor')
+      steered = bool(_ddp._steer_stream_pool(device, torch.cuda.current_stream(device), _ex.checked_side_stream(device)))
+    except Exception as e:                                 # never fatal: the probe below reports what the communicator got
+      print(f'bench.py: stream-pool steering failed: {e!r}', file=sys.stderr)
     dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
+    dist.all_reduce(torch.zeros(1, device=device))         # first collective NOW: the communicator draws its stream from the steered pool
 
   import soft_truncation_amd as st
   cfg_name, per_gpu_batch, desc = WORKLOADS[args.workload]
@@ -694,6 +705,7 @@ def main():
     # rendezvous cannot be re-created from here, so a serialised exchange shows up in the line instead of being repaired)
     try:
       exchange_stream = st.engine.ddp.check_exchange_stream(device)
+      exchange_stream['pool_steered'] = steered
     except Exception as e:
       exchange_stream = {'error': repr(e)[:200]}
 
