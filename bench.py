@@ -11,8 +11,14 @@ the global batch is 128 N.  Rank 0 prints ONE JSON line.
 
 `python bench.py --gpus N` outside a launcher starts the N ranks itself (torch.distributed.run on 127.0.0.1).
 
+Key order of the line (ordered_line): the contract's scalars, `headline` = (images/s, ms/step, step fraction of the matrix-pipe ceiling,
+dominant-kernel fraction) of EVERY workload measured in the run plus the sampler's measured full run, then the objects below, the per-kernel
+tables last, and `headline_repeat` as the very last key -- a reader that keeps only the head or the tail of the line sees every result.
+
 Extra objects in that line:
-  roofline      the dominant contraction kernel (by total time), timed with HIP events on the launch stream:
+  roofline      the dominant contraction kernel (by total time) AMONG THOSE THAT RUN ALONE ON THE CHIP in the timed steps -- the 3x3 weight
+                gradients run beside the main chain on one workgroup per CU (`kernels.*.shares_chip`) and are slow in isolation by design --
+                timed with HIP events on the launch stream:
                 achieved = algorithmic FLOPs per launch / average launch duration, against the ceiling of the
                 matrix pipe for the arithmetic that kernel runs: 2500 / 3 = 833 TFLOP/s fp32-equivalent for the
                 fp16 two-way-split kernels (three fp16 MFMAs per fp32 product; labels .x2 / .x2p...), 2500 / 6 for
@@ -26,6 +32,12 @@ Extra objects in that line:
                 engine against the oracle RefNet on identical weights and noise (N = 1 only).
   cpu_baseline  the oracle's PyTorch-CPU restatement of the same training step (RefNet + torch Adam + EMA) and of
                 one PC-sampler iteration, timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+  workloads     (N = 1, default workload) BASELINE configs[2] / configs[4] nets measured the same way in the same run; celebahq256 adds
+                sampler.N1000 = ONE COMPLETE run of the config's PC sampler on a 1000-point ladder (measured) and sampler.N2000 (12
+                iterations, extrapolated).  Their roofline.traffic is null: the committed PMC summary is for the CIFAR launch shapes.
+  exchange_proxy / exchange_stream   N = 1: the step once more with the gradient exchange forced on in a one-rank RCCL group, every bucket
+                really crossing the communicator's stream; N > 1: whether the communicator's stream runs beside the engine's launch and
+                side streams on every rank (engine/ddp.py: check_exchange_stream; the stream pool is steered before the group is created).
 """
 import argparse
 import json
