@@ -11,33 +11,31 @@ the global batch is 128 N.  Rank 0 prints ONE JSON line.
 
 `python bench.py --gpus N` outside a launcher starts the N ranks itself (torch.distributed.run on 127.0.0.1).
 
-Key order of the line (ordered_line): the contract's scalars, `headline` = (images/s, ms/step, step fraction of the matrix-pipe ceiling,
-dominant-kernel fraction) of EVERY workload measured in the run plus the sampler's measured full run, then the objects below, the per-kernel
-tables last, and `headline_repeat` as the very last key -- a reader that keeps only the head or the tail of the line sees every result.
-
-Extra objects in that line:
-  roofline      the dominant contraction kernel (by total time) AMONG THOSE THAT RUN ALONE ON THE CHIP in the timed steps -- the 3x3 weight
-                gradients run beside the main chain on one workgroup per CU (`kernels.*.shares_chip`) and are slow in isolation by design --
-                timed with HIP events on the launch stream:
-                achieved = algorithmic FLOPs per launch / average launch duration, against the ceiling of the
-                matrix pipe for the arithmetic that kernel runs: 2500 / 3 = 833 TFLOP/s fp32-equivalent for the
-                fp16 two-way-split kernels (three fp16 MFMAs per fp32 product; labels .x2 / .x2p...), 2500 / 6 for
-                the bf16 three-way-split ones (.x3), 157.3 for the f32-input MFMA kernels (MI355X_MICROARCH.md).
-                One label = one kernel symbol of the rocprofv3 summaries (KERNEL_SYMBOL below): .x2p = LDS-DMA GEMM on
-                plane operands, .x2p.h16/.h32/.h64 = its halo-tile form on the 16/32/64-wide maps, .x2p.k = its K-split
-                form on small maps (partial slabs + slab sum; the bracket covers both launches), .x2p.w32/.w16/.w8/.w4 = the planes weight gradient per map width (bracket = kernel +
-                its slab reduce).  `kernels` lists the other contraction kernels the same way; `traffic` comes from
-                the newest committed PMC summary (profiles/rNN_traffic.json).
-  parity_probe  the benched build checks itself: per-sample soft-truncation losses of one batch-8 step on the HIP
-                engine against the oracle RefNet on identical weights and noise (N = 1 only).
-  cpu_baseline  the oracle's PyTorch-CPU restatement of the same training step (RefNet + torch Adam + EMA) and of
-                one PC-sampler iteration, timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
-  workloads     (N = 1, default workload) BASELINE configs[2] / configs[4] nets measured the same way in the same run; celebahq256 adds
-                sampler.N1000 = ONE COMPLETE run of the config's PC sampler on a 1000-point ladder (measured) and sampler.N2000 (12
-                iterations, extrapolated).  Their roofline.traffic is null: the committed PMC summary is for the CIFAR launch shapes.
-  exchange_proxy / exchange_stream   N = 1: the step once more with the gradient exchange forced on in a one-rank RCCL group, every bucket
-                really crossing the communicator's stream; N > 1: whether the communicator's stream runs beside the engine's launch and
-                side streams on every rank (engine/ddp.py: check_exchange_stream; the stream pool is steered before the group is created).
+The stdout line (short_line) is SHORT by construction -- below 4000 characters, asserted in tests/test_bench_line.py for N = 1 and
+N = 8: the driver keeps the last 8000 characters of stdout, and the round-5 line (20 KB of per-kernel tables) arrived headless.  It
+carries the contract's scalars and `config`, plus:
+  roofline       the contraction kernel with the LARGEST TOTAL TIME in the step (whatever stream it runs on), timed with HIP events
+                 on the launch stream in `--prof-steps` eager one-stream steps right after the timed ones:
+                 achieved = algorithmic FLOPs per launch / average launch duration, against the ceiling of the matrix pipe for the
+                 arithmetic that kernel runs: 2500 / 3 = 833 TFLOP/s fp32-equivalent for the fp16 two-way-split kernels (three fp16
+                 MFMAs per fp32 product; labels .x2 / .x2p...), 157.3 for the f32-input MFMA kernels (MI355X_MICROARCH.md).
+                 shares_chip = true: the kernel is a 3x3 weight gradient, which the timed steps run on the side stream beside the main
+                 chain of the backward on one workgroup per CU; the bracket measures it with that same geometry.
+                 traffic = HBM bytes per launch from the committed PMC summary of this workload (profiles/rNN[_workload]_traffic.json).
+  roofline_best  the kernel with the highest fraction of its ceiling among those that take >= 2 % of the step.
+  step_roofline  the whole step: BASELINE.md train FLOPs / image x images/s against 833, and the SURVEY 8(d) HBM model against 8 TB/s.
+  cpu_baseline   the oracle's PyTorch-CPU restatement of the same training step (RefNet + torch Adam + EMA), timed on this box's host
+                 cores on a bounded sample (five batch-8 steps + one batch-128 step; rank 0, N = 1 only).
+  headline       one (images/s, ms/step, step fraction, dominant kernel + fraction + traffic, CPU images/s) tuple per workload measured in
+                 the run (N = 1, default workload: BASELINE configs[2] / configs[4] nets too; celebahq256 adds its PC sampler).
+  exchange_stream / exchange_serialised   N > 1: whether the communicator's stream runs beside the engine's launch and side streams on
+                 every rank (engine/ddp.py: check_exchange_stream); exchange_serialised = true means a flat scaling curve is the queue.
+  parity_probe   the benched build checks itself: per-sample losses of one batch-8 step against the oracle RefNet (N = 1 only).
+  detail         path of the side file (--detail, default gpurun_out/bench_detail.json) with EVERYTHING the run measured: per-kernel
+                 tables of every workload, full roofline / sampler / cpu_baseline / exchange_proxy / arithmetic_check objects.
+One label = one kernel symbol of the rocprofv3 summaries (KERNEL_SYMBOL below): .x2p = LDS-DMA GEMM on plane operands, .x2p.h16/.h32/.h64
+= its halo-tile form on the 16/32/64-wide maps, .x2p.k = its K-split form on small maps, .x2p.w32/.w16/.w8/.w4 = the planes weight
+gradient per map width (bracket = kernel + its slab reduce).
 """
 import argparse
 import json
@@ -97,20 +95,22 @@ KERNEL_SYMBOL = {
 }
 
 
-def traffic_of(kind):
-  """HBM-side bytes per launch of the kernel behind `kind`, from the newest committed PMC summary
-  (profiles/rNN_traffic.json, written by tools/profile_round.sh + tools/profile_summary.py: separate rocprofv3
+def traffic_of(kind, path=None):
+  """HBM-side bytes per launch of the kernel behind `kind`, from a committed PMC summary (default: the newest
+  profiles/rNN_traffic.json, written by tools/profile_round.sh + tools/profile_summary.py: separate rocprofv3
   --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled per the gfx950 note of
   MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process, hence the file."""
   import glob
-  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
+  if path is None:
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_traffic.json')))
+    path = files[-1] if files else None
   sym = KERNEL_SYMBOL.get(kind)
-  if not files or sym is None:
+  if path is None or sym is None:
     return None, None
-  rec = json.load(open(files[-1])).get(sym)
+  rec = json.load(open(path)).get(sym)
   if rec is None:
     return None, None
-  return (rec['fetch_MB'] + rec['write_MB']) * 1e6, os.path.relpath(files[-1], ROOT)
+  return (rec['fetch_MB'] + rec['write_MB']) * 1e6, os.path.relpath(path, ROOT)
 
 
 def kernel_peak(kind):
@@ -160,6 +160,8 @@ def parse():
   ap.add_argument('--full-sampler-n', type=int, default=1000,
                   help='celebahq256 workload: one COMPLETE PC-sampler run on an N-point ladder (BASELINE configs[4] "1000-step"; 0 = skip)')
   ap.add_argument('--cpu-big-batch', type=int, default=128, help='batch of the single like-for-like CPU step (0 = skip)')
+  ap.add_argument('--detail', default=os.path.join('gpurun_out', 'bench_detail.json'),
+                  help='side file with everything the stdout line leaves out (per-kernel tables, workloads, sampler, probes)')
   ap.add_argument('--force-exchange', action='store_true',
                   help='N = 1: run the WHOLE benchmark (the reported value too) with the exchange forced on')
   return ap.parse_args()
@@ -295,37 +297,51 @@ def sampler_rate(st, cfg, sde, score_model, batch, steps, device):
           'corrector': cfg.sampling.corrector, 'ms_per_eval': 1e3 * dt / evals}
 
 
-def roofline_of(summ, prof_steps, ms_per_step, pmc_workload=True):
-  """The `roofline` / `kernels` objects from a KernelTimer summary (dominant contraction kernel by total time).
-  pmc_workload: the committed PMC summary (profiles/rNN_traffic.json) was taken on THIS workload's launch shapes; for any
-  other workload `traffic` is null -- a kernel's bytes per launch depend on the shape, and a figure measured on the CIFAR
-  launches says nothing about a 64x64 or 256x256 launch of the same symbol."""
-  # The dominant kernel among those that have the chip to themselves in the timed steps.  The 3x3 weight gradients ('.wgrad.x2p.*') do
-  # not: they run on the side stream beside the main chain of the backward, deliberately on half of every CU (one workgroup per CU,
-  # csrc/conv_x2w.h), so the rate they reach ALONE in these one-stream profiling steps is not the roofline of anything -- they are
-  # listed in `kernels` (flag shares_chip) with that caveat.
+def traffic_file_for(workload):
+  """The committed PMC summary of a workload's launches: profiles/rNN_traffic.json for the headline (CIFAR-10) shapes,
+  profiles/rNN_<workload>_traffic.json for the others (tools/profile_round.sh / profile_workload.sh)."""
+  import glob
+  pat = 'r[0-9][0-9]_traffic.json' if workload in (None, 'cifar10', 'imagenet32') else f'r[0-9][0-9]_{workload}_traffic.json'
+  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pat)))
+  return files[-1] if files else None
+
+
+def roofline_of(summ, prof_steps, ms_per_step, workload='cifar10'):
+  """The `roofline` / `roofline_best` / `kernels` objects from a KernelTimer summary.
+
+  roofline = the contraction kernel with the LARGEST TOTAL TIME in the step, whatever stream it runs on.  When that is one of the
+  3x3 weight gradients ('.wgrad.x2p.*') the object carries shares_chip = true: in the timed steps they run on the side stream
+  beside the main chain of the backward, on one workgroup per CU (csrc/conv_x2w.h); the event brackets behind `avg_us` are taken
+  in one-stream eager steps with that same launch geometry, i.e. with half of every CU idle -- the figure is what the kernel does
+  as launched, not what it could do with the chip to itself.  roofline_best = the contraction kernel with the highest fraction
+  of its ceiling among those that take >= 2 % of the step.  traffic: the committed PMC summary of THIS workload's launches
+  (traffic_file_for), null when none exists -- a kernel's bytes per launch depend on the shape."""
   shared = lambda k: '.wgrad.x2p' in k
-  alone = [k for k in summ if not shared(k)] or list(summ)
-  dom = max(alone, key=lambda k: summ[k]['total_ms'])
-  a = summ[dom]
-  traffic, traffic_src = traffic_of(dom) if pmc_workload else (None, None)
-  roof = {'bound': 'mfma', 'achieved': a['tflops'], 'peak': kernel_peak(dom), 'unit': 'TFLOP/s',
-          'frac': a['tflops'] / kernel_peak(dom), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
-          'traffic_source': traffic_src, 'kernel': dom, 'symbol': KERNEL_SYMBOL.get(dom),
-          'peak_note': ('bf16 MFMA dense peak / 6 products per fp32 product' if dom.endswith('.x3')
-                        else 'fp16 MFMA dense peak / 3 products per fp32 product' if kernel_peak(dom) == PEAK_X2_TFLOPS
-                        else 'f32-input MFMA peak'),
-          'avg_us': a['avg_us'], 'launches': a['count'], 'flops_per_launch': a['flops_per_launch'],
-          'share_of_step': (a['total_ms'] / max(prof_steps, 1)) / ms_per_step,
-          'measured': f'{prof_steps} eager steps right after the timed (hipGraph) steps',
-          'selection': 'largest total time among the contraction kernels that run alone on the chip in the timed steps; the 3x3 weight '
-                       'gradients run beside the main chain on one workgroup per CU (kernels.*: shares_chip) and are measured here in '
-                       'isolation, where that launch geometry is slow by design'}
+  dom = max(summ, key=lambda k: summ[k]['total_ms'])
+  tfile = traffic_file_for(workload)
+
+  def obj(k):
+    a = summ[k]
+    traffic, traffic_src = traffic_of(k, tfile) if tfile else (None, None)
+    return {'bound': 'mfma', 'achieved': a['tflops'], 'peak': kernel_peak(k), 'unit': 'TFLOP/s',
+            'frac': a['tflops'] / kernel_peak(k), 'traffic': traffic, 'traffic_unit': 'bytes/launch',
+            'traffic_source': traffic_src, 'kernel': k, 'symbol': KERNEL_SYMBOL.get(k),
+            'peak_note': ('bf16 MFMA dense peak / 6 products per fp32 product' if k.endswith('.x3')
+                          else 'fp16 MFMA dense peak / 3 products per fp32 product' if kernel_peak(k) == PEAK_X2_TFLOPS
+                          else 'f32-input MFMA peak'),
+            'avg_us': a['avg_us'], 'launches': a['count'], 'flops_per_launch': a['flops_per_launch'],
+            'share_of_step': (a['total_ms'] / max(prof_steps, 1)) / ms_per_step, 'shares_chip': shared(k),
+            'measured': f'{prof_steps} eager one-stream steps right after the timed steps, HIP events on the launch stream'}
+  roof = obj(dom)
+  roof['selection'] = 'largest total time among ALL contraction kernels of the step'
+  big = [k for k in summ if (summ[k]['total_ms'] / max(prof_steps, 1)) / ms_per_step >= 0.02] or [dom]
+  best = obj(max(big, key=lambda k: summ[k]['tflops'] / kernel_peak(k)))
+  best['selection'] = 'highest fraction of its ceiling among the contraction kernels that take >= 2 % of the step'
   kernels = {k: {'tflops': round(v['tflops'], 2), 'frac_of_peak': round(v['tflops'] / kernel_peak(k), 3),
                  'avg_us': round(v['avg_us'], 1), 'launches': v['count'],
                  'total_ms_per_step': round(v['total_ms'] / max(prof_steps, 1), 3),
                  **({'shares_chip': True} if shared(k) else {})} for k, v in summ.items()}
-  return roof, kernels
+  return roof, best, kernels
 
 
 def extra_workload(st, name, device, args):
@@ -376,7 +392,7 @@ def extra_workload(st, name, device, args):
     eng.profiler = None
     summ = timer.summary()
     if summ:
-      out['roofline'], out['kernels'] = roofline_of(summ, args.prof_steps, ms, pmc_workload=False)
+      out['roofline'], out['roofline_best'], out['kernels'] = roofline_of(summ, args.prof_steps, ms, workload=name)
   if name == 'celebahq256':
     out['sampler'] = {}
     sb = cfg.sampling.batch_size if hasattr(cfg.sampling, 'batch_size') else 16
@@ -466,17 +482,37 @@ def pc_rate(st, cfg, sde, score_model, batch, iterations, device):
           'predictor': cfg.sampling.predictor, 'corrector': cfg.sampling.corrector, 'finite': bool(torch.isfinite(x).all())}
 
 
-def ordered_line(out, workload):
-  """Key order of the JSON line: the contract's scalars, then `headline` -- (images/s, ms/step, fraction of the matrix-pipe
-  ceiling) of EVERY workload measured in this run -- then roofline / cpu_baseline / the other objects, the per-kernel tables
-  last; `headline` is repeated as the last key, so that a reader who keeps only the head or only the tail of a long line
-  still sees every workload's result."""
+LINE_LIMIT = 4000     # characters of the stdout line (the driver keeps the last 8000 characters of stdout and parses the last line)
+
+
+def _r(v, n=4):
+  """Floats rounded to n significant-ish decimals for the stdout line (the detail file keeps full precision)."""
+  if isinstance(v, float):
+    return round(v, n) if abs(v) < 1e6 else float(f'{v:.6g}')
+  return v
+
+
+def _pick(d, keys, n=4):
+  return {k: _r(d[k], n) for k in keys if isinstance(d, dict) and k in d}
+
+
+def short_line(out, workload, detail_path=None):
+  """The ONE stdout line: what the bench contract names and nothing else -- the contract's scalars, `config`, `roofline` (the
+  contraction kernel with the largest total time in the step), `roofline_best`, `step_roofline`, `cpu_baseline`, `headline` (one
+  triple per workload measured in the run), the exchange-stream verdict for N > 1, and `detail` = the path of the side file
+  that holds everything else (per-kernel tables, every workload's full object, sampler legs, parity probe, arithmetic check,
+  exchange proxy).  Stays below LINE_LIMIT characters by construction (tests/test_bench_line.py)."""
   def triple(o):
     t = {'images_per_s': round(o['value'], 1), 'ms_per_step': round(o['ms_per_step'], 3)}
     if 'step_roofline' in o:
-      t['step_frac_of_x2_ceiling'] = round(o['step_roofline']['frac'], 4)
+      t['step_frac'] = round(o['step_roofline']['frac'], 4)
     if 'roofline' in o:
-      t['dominant_kernel_frac'] = round(o['roofline']['frac'], 4)
+      t['dominant'] = o['roofline'].get('kernel')
+      t['dominant_frac'] = round(o['roofline']['frac'], 4)
+      if o['roofline'].get('traffic') is not None:
+        t['dominant_traffic_MB'] = round(o['roofline']['traffic'] / 1e6, 1)
+    if isinstance(o.get('cpu_baseline'), dict) and 'value' in o['cpu_baseline']:
+      t['cpu_images_per_s'] = round(o['cpu_baseline']['value'], 3)
     return t
   head = {workload: triple(out)}
   for name, w in (out.get('workloads') or {}).items():
@@ -484,30 +520,66 @@ def ordered_line(out, workload):
       head[name] = triple(w)
       for key, smp in (w.get('sampler') or {}).items():
         if isinstance(smp, dict) and 'ms_per_eval' in smp:
-          head[name]['sampler_' + key] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in smp.items()
-                                          if k in ('measured', 'full_run_s', 'full_run_s_extrapolated', 'ms_per_eval', 'batch')}
+          head[name]['sampler_' + key] = _pick(smp, ('full_run_s', 'full_run_s_extrapolated', 'ms_per_eval', 'batch'), 3)
     else:
-      head[name] = w
+      head[name] = {'error': str(w.get('error', w))[:120]}
   first = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
-           'dtype', 'data', 'config')
-  line = {k: out[k] for k in first if k in out}
+           'dtype', 'data')
+  line = {k: _r(out[k], 3) for k in first if k in out}
+  line['config'] = _pick(out.get('config', {}), ('workload', 'per_gpu_batch', 'global_batch', 'parallelism', 'exchange'))
+  if 'roofline' in out:
+    line['roofline'] = _pick(out['roofline'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'symbol', 'avg_us',
+                                               'launches', 'flops_per_launch', 'share_of_step', 'shares_chip', 'traffic_source',
+                                               'frac_of_library_gemm'))
+  if 'roofline_best' in out:
+    line['roofline_best'] = _pick(out['roofline_best'], ('kernel', 'achieved', 'frac', 'avg_us', 'share_of_step'))
+  if 'step_roofline' in out:
+    line['step_roofline'] = _pick(out['step_roofline'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_hbm',
+                                                         'frac_of_f32_input_mfma_peak'))
+  cb = out.get('cpu_baseline')
+  if isinstance(cb, dict):
+    line['cpu_baseline'] = _pick(cb, ('value', 'unit', 'cores', 'kind', 'sec_per_step', 'error'))
+    if 'sample' in cb:
+      line['cpu_baseline']['sample'] = cb['sample'][:160]
+    for k, v in cb.items():
+      if k.startswith('batch') and isinstance(v, dict):
+        line['cpu_baseline'][k] = _pick(v, ('value', 'sec_per_step', 'error'))
   line['headline'] = head
-  tables = {}
-  for k, v in out.items():
-    if k in line or k == 'kernels':
-      continue
-    if k == 'workloads':
-      v = {n: dict(w) for n, w in v.items()}
-      for n, w in v.items():
-        if 'kernels' in w:
-          tables[n] = w.pop('kernels')
-    line[k] = v
-  if 'kernels' in out:
-    line['kernels'] = out['kernels']
-  if tables:
-    line['workload_kernels'] = tables
-  line['headline_repeat'] = head
-  return line
+  xs = out.get('exchange_stream')
+  if isinstance(xs, dict):
+    line['exchange_stream'] = _pick(xs, ('ok', 'beside_main', 'beside_side', 'pool_steered', 'attempts'))
+    if 'error' in xs:
+      line['exchange_stream']['error'] = str(xs['error'])[:120]
+    if out.get('n_gpus', 1) > 1 and not xs.get('ok', False):
+      line['exchange_serialised'] = True        # a flat scaling curve is then the communicator's queue, not the wire
+  if isinstance(out.get('exchange_proxy'), dict) and 'delta_ms' in out['exchange_proxy']:
+    line['exchange_proxy_delta_ms'] = round(out['exchange_proxy']['delta_ms'], 3)
+  if isinstance(out.get('parity_probe'), dict):
+    line['parity_probe'] = _pick(out['parity_probe'], ('ok', 'loss_max_rel_err', 'grad_norm_rel_err', 'tolerance'), 10)
+    if 'error' in out['parity_probe']:
+      line['parity_probe']['error'] = str(out['parity_probe']['error'])[:120]
+  if isinstance(out.get('sampler'), dict) and 'ms_per_eval' in out['sampler']:
+    line['sampler'] = _pick(out['sampler'], ('method', 'batch', 'ms_per_eval', 'image_evals_per_s'), 3)
+  line['detail'] = detail_path
+  text = json.dumps(line)
+  if len(text) >= LINE_LIMIT:            # never reached with the objects above; a safety net, not a code path
+    for k in ('sampler', 'parity_probe', 'roofline_best', 'exchange_proxy_delta_ms'):
+      line.pop(k, None)
+    text = json.dumps(line)
+  assert len(text) < LINE_LIMIT, len(text)
+  return text
+
+
+def write_detail(out, path):
+  """Everything the run measured, full precision, per-kernel tables included -- the file the stdout line names in `detail`."""
+  try:
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    with open(path, 'w') as f:
+      json.dump(out, f, indent=1)
+    return path
+  except OSError as e:
+    print(f'bench.py: could not write {path}: {e!r}', file=sys.stderr)
+    return None
 
 
 def arithmetic_check(device):
@@ -657,6 +729,32 @@ def quiet_stdout():
   return real
 
 
+def device_of(local_rank):
+  """This rank's GPU (a seam: tests/_bench_worker.py runs main() on CPU tensors with the checker library behind the engine)."""
+  torch.cuda.set_device(local_rank)
+  return torch.device('cuda', local_rank)
+
+
+def init_group(device):
+  dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
+  dist.all_reduce(torch.zeros(1, device=device))         # first collective NOW: the communicator draws its stream from the steered pool
+
+
+def device_sync():
+  torch.cuda.synchronize()
+
+
+def build_training(st, cfg, sde):
+  """Random-init weights of the named architecture on cfg.device, optimizer, EMA, and the reference-shaped step function."""
+  score_model = st.models.utils.create_model(cfg, sde)
+  score_model.module.engine().ensure_flat()
+  optimizer = st.losses.get_optimizer(cfg, score_model.parameters())
+  ema = st.models.ema.ExponentialMovingAverage(score_model.parameters(), decay=cfg.model.ema_rate)
+  state = dict(optimizer=optimizer, model=score_model, ema=ema, step=0)
+  step_fn = st.losses.get_step_fn(cfg, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg))
+  return state, step_fn
+
+
 def main():
   args = parse()
   if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -672,24 +770,23 @@ def main():
     print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}', file=sys.stderr)
   if args.launch_check:
     return launch_check(world, rank, local_rank, real_stdout)
-  torch.cuda.set_device(local_rank)
-  device = torch.device('cuda', local_rank)
+  device = device_of(local_rank)
   exchange_stream = None
+  steered = None
   if world > 1:
     # steer torch's stream pool first, so that the communicator's stream lands on a hardware queue of its own (engine/ddp.py:
     # a communicator on the launch or the side stream's queue would serialise the overlapped exchange behind the backward)
-    steered = None
     try:
       from importlib import import_module
       _ddp = import_module('soft-truncation_amd.engine.ddp')
       _ex = import_module('soft-truncation_amd.engine.executor')
       steered = bool(_ddp._steer_stream_pool(device, torch.cuda.current_stream(device), _ex.checked_side_stream(device)))
     except Exception as e:                                 # never fatal: the probe below reports what the communicator got
-      print(f'bench.py: stream-pool steering failed: {e!r}', file=sys.stderr)
-    dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
-    dist.all_reduce(torch.zeros(1, device=device))         # first collective NOW: the communicator draws its stream from the steered pool
+      print(f'bench.py: stream-pool steering failed: {e!r}'[:300], file=sys.stderr)
+    init_group(device)
 
   import soft_truncation_amd as st
+  st.sampling.PROGRESS = False                             # no progress bars: stdout carries one line, stderr stays short
   cfg_name, per_gpu_batch, desc = WORKLOADS[args.workload]
   if args.batch:
     per_gpu_batch = args.batch
@@ -704,12 +801,8 @@ def main():
     dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{free_port()}', rank=0, world_size=1, device_id=device)
     st.engine.ddp.FORCE_SINGLE_RANK = True
   sde = st.sde_lib.get_sde(cfg, None)
-  score_model = st.models.utils.create_model(cfg, sde)     # random-init weights of the named architecture
-  score_model.module.engine().ensure_flat()
-  optimizer = st.losses.get_optimizer(cfg, score_model.parameters())
-  ema = st.models.ema.ExponentialMovingAverage(score_model.parameters(), decay=cfg.model.ema_rate)
-  state = dict(optimizer=optimizer, model=score_model, ema=ema, step=0)
-  step_fn = st.losses.get_step_fn(cfg, sde, train=True, optimize_fn=st.losses.optimization_manager(cfg))
+  state, step_fn = build_training(st, cfg, sde)
+  score_model = state['model']
   batch = st.datasets.synthetic_batch(cfg, per_gpu_batch, device=device,
                                       generator=torch.Generator().manual_seed(1234 + rank))
   if world > 1:
@@ -722,10 +815,10 @@ def main():
       exchange_stream = {'error': repr(e)[:200]}
 
   def sync():
-    torch.cuda.synchronize()
+    device_sync()
     if world > 1:
       dist.barrier()
-      torch.cuda.synchronize()
+      device_sync()
 
   # Two untimed priming steps before the W warm-up steps: the engine runs a context eagerly on first use and captures
   # its hipGraphs on the second, so the timed region never contains a capture whatever W is.
@@ -799,7 +892,8 @@ def main():
     if timer is not None:
       summ = timer.summary()
       if summ:
-        out['roofline'], out['kernels'] = roofline_of(summ, args.prof_steps, 1e3 * elapsed / args.steps)
+        out['roofline'], out['roofline_best'], out['kernels'] = roofline_of(summ, args.prof_steps, 1e3 * elapsed / args.steps,
+                                                                            workload=args.workload)
     hbm_bytes = TRAIN_HBM_BYTES_PER_IMG.get(cfg_name)
     if hbm_bytes is not None:
       gbs = (hbm_bytes * per_gpu_batch + 16.0 * 4 * score_model.module.engine().flat.data.numel()) * (args.steps / elapsed) / 1e9
@@ -828,7 +922,7 @@ def main():
       out['cpu_baseline'] = cpu_baseline(st, cfg_name, args.cpu_batch, args.cpu_steps, args.fir, big_batch=args.cpu_big_batch)
     if world == 1 and not args.no_parity_probe:
       try:
-        del state, optimizer, ema, score_model       # free the benched replica's arenas before building the probe's
+        del state, score_model, step_fn              # free the benched replica's arenas before building the probe's
         torch.cuda.empty_cache()
         out['parity_probe'] = parity_probe(st, cfg_name, device)
       except Exception as e:
@@ -836,7 +930,7 @@ def main():
     if world == 1 and args.workload == 'cifar10' and not args.no_extra_workloads and not args.fir and not args.batch:
       # north_star: "throughput on 32x32 AND 256x256 batches": BASELINE configs[2] / configs[4] nets in the same driver-timed run
       try:
-        del state, optimizer, ema, score_model           # (already gone when the parity probe ran)
+        del state, score_model, step_fn                  # (already gone when the parity probe ran)
       except NameError:
         pass
       torch.cuda.empty_cache()
@@ -846,7 +940,8 @@ def main():
           out['workloads'][name] = extra_workload(st, name, device, args)
         except Exception as e:
           out['workloads'][name] = {'error': repr(e)[:300]}
-    real_stdout.write(json.dumps(ordered_line(out, args.workload)) + '\n')
+    detail = write_detail(out, args.detail)
+    real_stdout.write(short_line(out, args.workload, detail) + '\n')
     real_stdout.flush()
   if world > 1 or (args.force_exchange and dist.is_initialized()):
     dist.destroy_process_group()

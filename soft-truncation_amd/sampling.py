@@ -28,11 +28,22 @@ from .engine import rk45
 from .models import utils as mutils
 from .models.utils import from_flattened_numpy, get_score_fn, to_flattened_numpy
 
+import os
+
 try:
-  from tqdm import tqdm
+  from tqdm import tqdm as _tqdm
 except ImportError:  # pragma: no cover
-  def tqdm(it, **kw):
+  _tqdm = None
+
+# The reference shows a progress bar over the PC iterations (sampling.py:423).  PROGRESS = False (or STK_PROGRESS=0 in the
+# environment) silences it: a benchmark or a batch job must not write a thousand bar updates to stderr.
+PROGRESS = os.environ.get('STK_PROGRESS', '1') != '0'
+
+
+def tqdm(it, **kw):
+  if _tqdm is None or not PROGRESS:
     return it
+  return _tqdm(it, **kw)
 
 
 def _wide(v):
