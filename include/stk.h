@@ -128,38 +128,6 @@ int stk_gn_bwd_out_f32(const float* dy, const float* x1, int C1, const float* x2
                        const float* dx1_add, float add_scale,
                        float* dx_sum, float out_scale, float* dtemb, int temb_stride, float* dx_amax, void* stream);
 
-/* "Planes without a pass" (round 5): the backward of a GroupNorm whose input is read by nobody else and whose input gradient is
- * consumed as planes only -- Conv_0 -> (+ temb) -> GroupNorm_1 of a ResnetBlockBigGANpp, models/layerspp.py:273-278: this gradient IS
- * Conv_0's output gradient -- writes those planes itself: no fp32 copy of the gradient, no stk_split_planes_f32 pass.
- * The scale of planes must be known before the first value is written, so it is derived a priori from records earlier calls leave:
- *   dymax  [256]  max |dy| per image (slot = image mod 256, atomic maximum into caller-zeroed memory)
- *                                                 <- stk_conv2d_dgrad_pl_max_f32, the data-gradient GEMM that produces dy
- *   gnrec  [N G]  max |xhat| of every (image, group), plain stores     <- stk_gn_fwd_pl_rec_f32, this layer's forward
- * as  bound = 1.001 max|gamma| S K max_{n,g}( rstd_ng (2 + xhat_ng) dymax_n ),  S = the activation's largest slope (SiLU 1.0999,
- * else 1), K = 1 / (1 - drop_p):   dx = rstd (gamma du - m1 - xhat m2) with |m1|, |m2| <= max|gamma du| because mean |xhat| <= 1.
- *   planes        the planes of dx [N, C, HW] (stk_planes_bytes), scaled by the power of two of `bound`
- *   rec    [256]  OUT: the scale record the consumers of `planes` read: rec[0] = bound, rec[1..] = 0
- *   amax_true [256] (may be NULL; caller-zeroed) a record of the TRUE max |dx| by atomic maximum (diagnostics, tests)
- *   ws, dx_sum, out_scale, dtemb, temb_stride: as in stk_gn_bwd_out_f32 (ws receives the [N][C][2] sums for stk_gn_param_grad_batch)
- * One source only.  Shapes: stk_gn_bwd_pl_ok (4 or 8 channels per group in whole 32-channel blocks, 16x16 or 32x32 maps). */
-int stk_gn_bwd_pl_ok(int C, int HW, int G);
-int stk_gn_bwd_pl_f32(const float* dy, const float* x, int C, const float* gamma, const float* beta, const float* mean,
-                      const float* rstd, float* ws, int N, int HW, int G, int act, float drop_p, unsigned long long seed,
-                      const unsigned long long* seed_dev, float* dx_sum, float out_scale, float* dtemb, int temb_stride,
-                      const float* dymax, const float* gnrec, void* planes, float* rec, float* amax_true, void* stream);
-/* stk_gn_fwd_pl_max_f32 (xmax1 / xmax2 may be NULL) that also fills gnrec[N G] (see above).  Shapes: stk_gn_fwd_rec_ok. */
-int stk_gn_fwd_rec_ok(int C1, int C2, int HW, int G);
-int stk_gn_fwd_pl_rec_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
-                          void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
-                          float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws,
-                          float* xmax1, float* xmax2, float* gnrec, void* stream);
-/* stk_conv2d_dgrad_pl_f32 into one source that also fills dxmax[256]: max |dx1| per image (see above).  Shapes:
- * stk_conv2d_dgrad_pl_max_ok (the plain call's shapes that run unsplit over K, maps of whole 32-pixel blocks). */
-int stk_conv2d_dgrad_pl_max_ok(int C1, int N, int H, int W, int Cout, int KH, int KW);
-int stk_conv2d_dgrad_pl_max_f32(const void* dypl, const float* dyamax, const float* w, int w_layout, float* dx1, int C1,
-                                float beta1, float alpha, int N, int H, int W, int Cout, int KH, int KW, const void* wp,
-                                void* ws, long ws_bytes, float* dxmax, void* stream);
-
 /* The affine-parameter gradients of MANY GroupNorm layers in one launch.  stk_gn_bwd_f32 with dgamma == dbeta == NULL
  * leaves its per-(sample, channel) sums in ws[0 .. 2*N*C) ([n][c]{sum du, sum du*xhat}) and skips its own fold; this
  * entry then does, for every descriptor, dgamma[c] += sum_n part[n][c][1], dbeta[c] += sum_n part[n][c][0] (same
@@ -304,9 +272,6 @@ int stk_conv2d_fwd_pl_f32(const void* xpl, const float* xamax, int C, const floa
 /* K splits of the plane-operand forward (dir 0) / data-gradient (dir 1) call of a shape: 1 = one GEMM launch, > 1 =
  * partial slabs + a slab-sum launch (small maps), 0 = the shape does not take plane operands (diagnostic: kernel labels) */
 int stk_conv2d_pl_ksplit(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW);
-/* output-channel x pixel tile of that call's kernel: 128, or 64 = the small-tile halo GEMM of the problems whose 128 x 128
- * tiles would not fill the chip (8x8 / 4x4 maps; every level below 64x64 at batch 4), 0 = no plane operands (diagnostic) */
-int stk_conv2d_pl_tile(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW);
 /* map width W when that call runs on the halo-tile GEMM (one staged halo tile of the activations per channel group serves the
  * nine taps: 16 / 32 / 64-wide maps of whole 128-pixel tiles, no K split), else 0 (diagnostic: kernel labels) */
 int stk_conv2d_pl_halo(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW);

@@ -38,7 +38,6 @@ struct ConvP {
   float* y;
   const float* dy; float* dx1; float* dx2; float beta1, beta2, alpha;
   float* part; long part_stride;
-  float* dxmax;               // EpDgrad by-product (stk_conv2d_dgrad_pl_max_f32): per-image max |dx1| by atomic maximum, or NULL
   int N, H, W, Cin, Cout, OH, OW, KH, KW, stride, pad, sshift;
   int HW, OHW, taps;
   int ohw_shift, ow_shift;    // log2 when OHW / OW are powers of two, else -1
@@ -534,42 +533,6 @@ struct EpDgrad {      // dx{1,2} = beta*dx + alpha*acc, rows routed to the two s
   }
   __device__ void finish(const ConvP&, unsigned char*, int) {}
 };
-// EpDgrad into one source that also leaves max |dx1| of the tile's image behind (stk_conv2d_dgrad_pl_max_f32): the maximum of the
-// STORED values, one atomic per workgroup (a 128-pixel tile lies in one image: the entry point checks) into that image's slot --
-// exact and order-independent, non-negative floats order like their bit patterns.  A type of its own: the by-product code inside
-// EpDgrad cost every data-gradient launch 5-8 us (172.1 -> 180.6 us on the 32x32 layers), one atomic per strip -- 8192 per launch
-// on 128 addresses -- most of it.
-struct EpDgradMax {
-  int b, hw; float mx = 0.f;
-  __device__ void preload(const ConvP&, int, int, int, int, int, int) {}
-  __device__ void stage(unsigned char*, int) {}
-  __device__ void init(const ConvP&, int, int) {}
-  __device__ void col(const ConvP& p, int n) { b = n / p.HW; hw = n - b * p.HW; }
-  __device__ void strip(const ConvP& p, int mbase, int M, bool nok, int, const floatx16& acc) {
-    const bool accum = p.beta1 != 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = mbase + strip_row(e);
-      if (nok && m < M) {
-        float* q = p.dx1 + ((long)b * p.C1 + m) * p.HW + hw;
-        const float v = (accum ? p.beta1 * *q : 0.f) + p.alpha * acc[e];
-        *q = v;
-        mx = fmaxf(mx, fabsf(v));
-      }
-    }
-  }
-  __device__ void finish(const ConvP& p, unsigned char* lds, int tid) {
-    float* s = reinterpret_cast<float*>(lds);
-    const float m = wave_max(mx);
-    __syncthreads();                                   // (the staged addends / operand tiles are dead)
-    if ((tid & 63) == 0) s[tid >> 6] = m;
-    __syncthreads();
-    if (tid == 0) {
-      const int img = b;                               // thread 0's pixel: the tile's first (valid) one
-      atomicMax(reinterpret_cast<unsigned*>(p.dxmax) + (img & 255), __float_as_uint(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]))));
-    }
-  }
-};
 struct EpWgrad {      // partial slab of split zs as [tap][Cout][Cin] (coalesced); the reduce kernel re-lays it out
   float* slab; int tap;
   __device__ void init(const ConvP& p, int zb, int zs) { slab = p.part + (long)zs * p.part_stride; tap = zb; }
@@ -1051,32 +1014,15 @@ inline X3Plan x3_plan(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
   r.ok = 1;
   return r;
 }
-// Plan of a PLANE-operand call (single source): the small-tile kernel (x2d::gemm_halo64_kernel, conv_x2d.h) where 128 x 128
-// tiles would not fill the chip, else the plan above.  Only shapes the plan above takes (stk_conv2d_pl_ok stays as it was).
-inline X3Plan x3_plan_pl(const ConvP& p, int Kc, int M, long Ng) {
-  X3Plan r = x3_plan(p, Kc, Kc, 0, M, Ng);
-  if (!r.ok) return r;
-  const x2d::T64Plan t = x2d::t64_plan(p, p.taps, Kc, M, Ng);
-  if (!t.ok) return r;
-  r.splits = t.splits;
-  r.gps = t.groups_per_split;
-  r.chunks_per_split = t.groups_per_split * 9;
-  r.slab = t.splits > 1 ? (long)M * Ng : 0;
-  r.t64 = 1;
-  return r;
-}
+// Plan of a PLANE-operand call (single source): the same plan (the 64 x 64-tile kernel of round 5 lost its in-step A/B and is retired)
+inline X3Plan x3_plan_pl(const ConvP& p, int Kc, int M, long Ng) { return x3_plan(p, Kc, Kc, 0, M, Ng); }
 inline long x3_ws_bytes(const X3Plan& r, int M, int Kc, int taps) {
   // [prepared weights of this call][|x| partial maxima, 2 x 256 floats][K-split slabs], each 256-byte aligned
   return r.ok ? x3::wp_bytes(M, Kc, taps) + 2048 + 1024 + (r.splits > 1 ? r.splits * r.slab * 4 : 0) : 0;
 }
-// dgrad = 1: rows are input channels, k output channels, taps flipped
-// Forward / data gradient on the split kernels: true = fp16 two-way split (conv_x2.h, 3 MFMAs per fp32 product),
-// false = bf16 three-way split (conv_x3.h, 6).  The weight gradient stays on the bf16 kernels of conv_x3.h.
-constexpr bool SPLIT_FWD_DGRAD_X2 = true;
-constexpr bool SPLIT_WGRAD3_X2 = true;      // the three-taps-per-workgroup 3x3 weight gradient on the fp16 split too
-// The per-tap weight gradients (1x1 layers, 3x3 on 4-wide maps) on the fp16 two-way split as well (x2::wgemm_kernel);
-// STK_WGRAD1_X2=0 keeps them on the bf16 three-way split (debugging / A-B switch, read once).
-inline bool wgrad1_x2() { static const bool v = [] { const char* e = getenv("STK_WGRAD1_X2"); return !e || atoi(e) != 0; }(); return v; }
+// dgrad = 1: rows are input channels, k output channels, taps flipped.  Every split kernel is the fp16 two-way split (3 MFMAs per
+// fp32 product, conv_x2.h / conv_x2d.h / conv_x2w.h); the bf16 three-way-split kernels of round 1 (six MFMAs) were the fallback
+// of a debugging switch until round 5 and are retired (DESIGN.md "Retired").
 inline bool wgrad1_pin() { static const bool v = [] { const char* e = getenv("STK_W1_PIN"); return !e || atoi(e) != 0; }(); return v; }
 
 inline void x3_weight_strides(const ConvP& p, int dgrad, long& sm, long& sk) {
@@ -1095,7 +1041,7 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
   float* xpart = reinterpret_cast<float*>(((uintptr_t)wp + x3::wp_bytes(M, q.Kc, p.taps) + 255) & ~(uintptr_t)255);
   p.part = reinterpret_cast<float*>(((uintptr_t)(xpart + 2 * x2::NPART) + 255) & ~(uintptr_t)255);
   p.part_stride = r.slab;
-  if (SPLIT_FWD_DGRAD_X2) {
+  {
     // fp16 two-way split (conv_x2.h): |x| maxima of the activation operand(s), weights prepared here unless the caller did
     // with a caller-owned amax buffer (768 floats: |x1|, |x2|, |dy| partials) the maxima stay available to the layer's
     // weight gradient, which would otherwise repeat these passes
@@ -1127,99 +1073,24 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
 #define STK_X2_LAUNCH(E, DUAL, TAPS)                                                                              \
   hipLaunchKernelGGL((x2::gemm_kernel<x2::ActLoader<DUAL, TAPS>, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, \
                      nch, r.chunks_per_split, xpart, nx)
-#define STK_PL_ABL(A)                                                                                             \
-  hipLaunchKernelGGL((pl::gemm_db_kernel<pl::PlaneLoader<9>, EpFwd, A>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, \
-                     nch, r.chunks_per_split, xpart, nx)
-    if (planes && pl::kernel_choice() >= 16 && p.taps == 9 && !dgrad && r.splits == 1) {      // ablation builds (benchmarks)
-      switch (pl::kernel_choice() >> 4) {
-        case 1: STK_PL_ABL(1); break;
-        case 2: STK_PL_ABL(2); break;
-        case 3: STK_PL_ABL(3); break;
-        case 4: STK_PL_ABL(4); break;
-        case 5: STK_PL_ABL(5); break;
-        case 7: STK_PL_ABL(7); break;
-        default: return STK_EINVAL;
-      }
-      STK_CHECK_LAUNCH();
-      return STK_OK;
-    }
-#undef STK_PL_ABL
 #define STK_PL_LAUNCH(E, TAPS)                                                                                    \
-  if (pl::kernel_choice() >= 32 && pl::kernel_choice() < 40 && TAPS == 9) {                                       \
-    /* ablation builds of the LDS-DMA kernel (benchmarks only) */                                                 \
-    switch (pl::kernel_choice() - 32) {                                                                           \
-      case 1: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
-      case 2: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 2>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
-      case 3: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 3>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
-      case 4: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 4>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
-      case 7: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 7>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
-      default: hipLaunchKernelGGL((x2d::gemm_kernel<9, 128, E, 1, 0>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, r.chunks_per_split, xpart, nx); break; \
-    }                                                                                                             \
-  } else if (pl::kernel_choice() == 5) {                                                                                 \
-    /* LDS-DMA staging with two LDS buffers: one barrier per chunk */                                             \
-    hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 128, E, 2>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, \
-                       r.chunks_per_split, xpart, nx);                                                            \
-  } else if (pl::kernel_choice() == 4 && x2d::halo_ok(p, TAPS, r.splits)) {                                       \
+  if (x2d::halo_ok(p, TAPS, r.splits)) {                                                                          \
     /* one halo tile of the activations per channel group serves the nine taps */                                 \
-    if (p.W >= 128)                                                                                               \
-      hipLaunchKernelGGL((x2d::gemm_halo_kernel<128, E, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
-    else if (p.W == 64)                                                                                           \
+    if (p.W == 64)                                                                                                \
       hipLaunchKernelGGL((x2d::gemm_halo_kernel<64, E, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
-    else if (p.W == 32 && x2d::halo_mode() == 2)                                                                  \
-      hipLaunchKernelGGL((x2d::gemm_halo_kernel<32, E, 2>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
     else if (p.W == 32)                                                                                           \
       hipLaunchKernelGGL((x2d::gemm_halo_kernel<32, E, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
-    else if (x2d::halo_mode() == 2)                                                                               \
-      hipLaunchKernelGGL((x2d::gemm_halo_kernel<16, E, 2>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
     else                                                                                                          \
       hipLaunchKernelGGL((x2d::gemm_halo_kernel<16, E, 1>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch / 9, xpart, nx); \
-  } else if (pl::kernel_choice() == 3 || pl::kernel_choice() == 4) {                                              \
-    /* LDS-DMA staging (conv_x2d.h); 128 x 256 tiles when that still fills the chip and a tile stays in one image */ \
-    const bool wide = pl::kernel_choice() == 3 && r.splits == 1 && p.HW % 256 == 0 && (long)tm * stk_cdiv((int)Ng, 256) >= 384; \
-    if (wide) {                                                                                                   \
-      const int tn2 = stk_cdiv((int)Ng, 256);                                                                     \
-      hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 256, E>), dim3((unsigned)(tm * tn2)), dim3(256), 0, s, p, q, M, (int)Ng, \
-                         tm, tn2, nch, r.chunks_per_split, xpart, nx);                                            \
-    } else {                                                                                                      \
-      hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 128, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch,  \
-                         r.chunks_per_split, xpart, nx);                                                          \
-    }                                                                                                             \
-  } else if (pl::kernel_choice() == 1)                                                                            \
-    hipLaunchKernelGGL((pl::gemm_db_kernel<pl::PlaneLoader<TAPS>, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, \
-                       nch, r.chunks_per_split, xpart, nx);                                                       \
-  else if (pl::kernel_choice() == 2)                                                                              \
-    hipLaunchKernelGGL((x2::gemm_kernel<pl::PlaneLoader<TAPS>, E, 3>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, \
+  } else {                                                                                                        \
+    /* LDS-DMA staging of both operands, one tap x 32 channels per chunk (conv_x2d.h) */                          \
+    hipLaunchKernelGGL((x2d::gemm_kernel<TAPS, 128, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch,    \
                        r.chunks_per_split, xpart, nx);                                                            \
-  else                                                                                                            \
-    hipLaunchKernelGGL((x2::gemm_kernel<pl::PlaneLoader<TAPS>, E>), grid, dim3(256), 0, s, p, q, M, (int)Ng, tm, tn, nch, \
-                       r.chunks_per_split, xpart, nx)
+  }
 #define STK_X2_LAUNCH_E(E)                                                                                        \
   if (planes) { if (p.taps == 9) { STK_PL_LAUNCH(E, 9); } else { STK_PL_LAUNCH(E, 1); } }                         \
   else if (p.taps == 9) { if (S2 > 0) STK_X2_LAUNCH(E, true, 9); else STK_X2_LAUNCH(E, false, 9); }               \
   else { if (S2 > 0) STK_X2_LAUNCH(E, true, 1); else STK_X2_LAUNCH(E, false, 1); }
-    if (planes && r.t64) {
-      // small tiles (64 x 64), K split over whole channel groups (conv_x2d.h)
-      const int tm6 = stk_cdiv(M, 64), tn6 = stk_cdiv((int)Ng, 64), ngroups = q.Kc / x3::KC;
-      const dim3 g6((unsigned)(tm6 * tn6 * r.splits));
-#define STK_T64_LAUNCH(E)                                                                                         \
-  switch (p.W) {                                                                                                  \
-    case 4: hipLaunchKernelGGL((x2d::gemm_halo64_kernel<4, E>), g6, dim3(256), 0, s, p, q, M, (int)Ng, tm6, tn6, ngroups, r.gps, xpart, nx); break; \
-    case 8: hipLaunchKernelGGL((x2d::gemm_halo64_kernel<8, E>), g6, dim3(256), 0, s, p, q, M, (int)Ng, tm6, tn6, ngroups, r.gps, xpart, nx); break; \
-    case 16: hipLaunchKernelGGL((x2d::gemm_halo64_kernel<16, E>), g6, dim3(256), 0, s, p, q, M, (int)Ng, tm6, tn6, ngroups, r.gps, xpart, nx); break; \
-    default: hipLaunchKernelGGL((x2d::gemm_halo64_kernel<32, E>), g6, dim3(256), 0, s, p, q, M, (int)Ng, tm6, tn6, ngroups, r.gps, xpart, nx); break; \
-  }
-      if (r.splits == 1) {
-        STK_T64_LAUNCH(EP)
-        STK_CHECK_LAUNCH();
-        return STK_OK;
-      }
-      STK_T64_LAUNCH(EpSlab)
-#undef STK_T64_LAUNCH
-      STK_CHECK_LAUNCH();
-      launch_slab_sum(p, r.splits, M, Ng, dgrad, s);
-      STK_CHECK_LAUNCH();
-      return STK_OK;
-    }
     if (r.splits == 1) {
       STK_X2_LAUNCH_E(EP)
       STK_CHECK_LAUNCH();
@@ -1234,38 +1105,6 @@ int launch_x3(ConvP p, const X3Plan& r, const float* s1, int S1, const float* s2
     STK_CHECK_LAUNCH();
     return STK_OK;
   }
-  if (planes) return STK_EUNSUPPORTED;
-  if (wp_ready) {
-    q.wp = static_cast<const unsigned short*>(wp_ready);
-  } else {
-    q.wp = wp;
-    const long n = (long)q.Mpad * q.Kc;
-    long sm, sk;
-    x3_weight_strides(p, dgrad, sm, sk);
-    hipLaunchKernelGGL(x3::wprep_kernel, dim3((unsigned)stk_cdiv(n, 256)), dim3(256), 0, s, p.w, wp, M, q.Kc, q.Mpad, sm, sk,
-                       p.taps, dgrad);
-    STK_CHECK_LAUNCH();
-  }
-  const int tm = q.Mpad / 128, tn = stk_cdiv((int)Ng, 128), nch = p.taps * (q.Kc / x3::KC);
-  const dim3 grid((unsigned)(tm * tn * r.splits));
-#define STK_X3_LAUNCH(E, DUAL, TAPS)                                                                                \
-  hipLaunchKernelGGL((x3::gemm_kernel<x3::WpLoader, x3::ActLoader<DUAL, TAPS>, E, true>), grid, dim3(256), 0, s, p, q, M, \
-                     (int)Ng, tm, tn, nch, r.chunks_per_split, 1)
-#define STK_X3_LAUNCH_E(E)                                                                                          \
-  if (p.taps == 9) { if (S2 > 0) STK_X3_LAUNCH(E, true, 9); else STK_X3_LAUNCH(E, false, 9); }                      \
-  else { if (S2 > 0) STK_X3_LAUNCH(E, true, 1); else STK_X3_LAUNCH(E, false, 1); }
-  if (r.splits == 1) {
-    STK_X3_LAUNCH_E(EP)
-    STK_CHECK_LAUNCH();
-    return STK_OK;
-  }
-  STK_X3_LAUNCH_E(EpSlab)
-  STK_CHECK_LAUNCH();
-  launch_slab_sum(p, r.splits, M, Ng, dgrad, s);
-#undef STK_X3_LAUNCH_E
-#undef STK_X3_LAUNCH
-  STK_CHECK_LAUNCH();
-  return STK_OK;
 }
 
 // Weight gradient on the split kernel: 3x3 / stride 1 / pad 1 or 1x1 / stride 1, power-of-two maps of >= 8 columns and
@@ -1543,7 +1382,7 @@ int stk_split_planes_f32(const float* x, int N, int C, int HW, const float* amax
 int stk_conv2d_pl_ok(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, stride, pad)) return 0;
-  if (!SPLIT_FWD_DGRAD_X2 || stride != 1 || pad != KH / 2) return 0;
+  if (stride != 1 || pad != KH / 2) return 0;
   const long Ng = (long)N * p.HW;
   if (dir == 0) {
     if (C2 > 0 || p.Cin <= 4 || Cout <= 4) return 0;        // two sources / thin-side streaming kernels
@@ -1565,16 +1404,6 @@ int stk_conv2d_pl_ksplit(int dir, int C1, int C2, int N, int H, int W, int Cout,
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, 1, KH / 2)) return 0;
   const long Ng = (long)N * p.HW;
   return dir == 0 ? x3_plan_pl(p, p.Cin, Cout, Ng).splits : x3_plan_pl(p, Cout, p.Cin, Ng).splits;
-}
-
-/* output-channel x pixel tile of the plane-operand forward (dir 0) / data-gradient (dir 1) kernel of this shape: 128 (x2d::gemm_kernel,
- * gemm_halo_kernel) or 64 (x2d::gemm_halo64_kernel, the small-tile form of the small problems); 0 = no plane operands.  Diagnostic. */
-int stk_conv2d_pl_tile(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW) {
-  if (!stk_conv2d_pl_ok(dir, C1, C2, N, H, W, Cout, KH, KW, 1, KH / 2)) return 0;
-  ConvP p = {};
-  if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, 1, KH / 2)) return 0;
-  const long Ng = (long)N * p.HW;
-  return (dir == 0 ? x3_plan_pl(p, p.Cin, Cout, Ng).t64 : x3_plan_pl(p, Cout, p.Cin, Ng).t64) ? 64 : 128;
 }
 
 int stk_conv2d_fwd_pl_f32(const void* xpl, const float* xamax, int C, const float* w, int w_layout, const float* bias,
@@ -1607,28 +1436,6 @@ int stk_conv2d_dgrad_pl_f32(const void* dypl, const float* dyamax, const float* 
   const X3Plan xr = x3_plan_pl(p, Cout, p.Cin, Ng);
   if (!ws || ws_bytes < x3_ws_bytes(xr, p.Cin, Cout, p.taps)) return STK_EINVAL;
   return launch_x3<EpDgrad>(p, xr, nullptr, Cout, nullptr, 0, p.Cin, Ng, 1, ws, (hipStream_t)stream, wp, nullptr, dypl, dyamax);
-}
-
-/* stk_conv2d_dgrad_pl_f32 into ONE source (C2 = 0) that also leaves max |dx1| PER IMAGE behind: dxmax[n mod 256] by atomic maximum
- * (caller-zeroed).  The GroupNorm backward that reads dx1 next derives the scale of the planes it writes from it
- * (stk_gn_bwd_pl_f32).  Shapes: those of the plain call that run unsplit over K, maps of whole 32-pixel blocks. */
-int stk_conv2d_dgrad_pl_max_ok(int C1, int N, int H, int W, int Cout, int KH, int KW) {
-  if (!stk_conv2d_pl_ok(1, C1, 0, N, H, W, Cout, KH, KW, 1, KH / 2) || (H * W) % 128) return 0;     // a 128-pixel tile = one image
-  return stk_conv2d_pl_ksplit(1, C1, 0, N, H, W, Cout, KH, KW) == 1 && pl::kernel_choice() == 4 ? 1 : 0;
-}
-int stk_conv2d_dgrad_pl_max_f32(const void* dypl, const float* dyamax, const float* w, int w_layout, float* dx1, int C1,
-                                float beta1, float alpha, int N, int H, int W, int Cout, int KH, int KW, const void* wp,
-                                void* ws, long ws_bytes, float* dxmax, void* stream) {
-  if (!dypl || !dyamax || !w || !dx1 || !dxmax || (w_layout != 0 && w_layout != 1) || (w_layout == 1 && KH != 1)) return STK_EINVAL;
-  if (!stk_conv2d_dgrad_pl_max_ok(C1, N, H, W, Cout, KH, KW)) return STK_EUNSUPPORTED;
-  ConvP p = {};
-  fill_common(p, N, H, W, C1, 0, Cout, H, W, KH, KW, 1, KH / 2);
-  p.w = w; p.w_layout = w_layout; p.dx1 = dx1; p.dx2 = nullptr;
-  p.beta1 = beta1; p.beta2 = 0.f; p.alpha = alpha; p.dxmax = dxmax;
-  const long Ng = (long)N * p.HW;
-  const X3Plan xr = x3_plan_pl(p, Cout, p.Cin, Ng);
-  if (!ws || ws_bytes < x3_ws_bytes(xr, p.Cin, Cout, p.taps)) return STK_EINVAL;
-  return launch_x3<EpDgradMax>(p, xr, nullptr, Cout, nullptr, 0, p.Cin, Ng, 1, ws, (hipStream_t)stream, wp, nullptr, dypl, dyamax);
 }
 
 /* 3x3 / stride 1 / pad 1 weight gradient with x and dy given as planes (conv_x2w.h) */
@@ -1693,7 +1500,7 @@ int stk_conv2d_wgrad_pl_wgs_f32(const void* xpl, const float* xrec, const void* 
  * shape runs on, 0 = x2d::gemm_kernel (diagnostic: one profiler label per kernel symbol) */
 int stk_conv2d_pl_halo(int dir, int C1, int C2, int N, int H, int W, int Cout, int KH, int KW) {
   const int ks = stk_conv2d_pl_ksplit(dir, C1, C2, N, H, W, Cout, KH, KW);
-  if (ks <= 0 || pl::kernel_choice() != 4 || stk_conv2d_pl_tile(dir, C1, C2, N, H, W, Cout, KH, KW) == 64) return 0;
+  if (ks <= 0) return 0;
   ConvP p = {};
   if (fill_common(p, N, H, W, C1, C2, Cout, H, W, KH, KW, 1, KH / 2)) return 0;
   return x2d::halo_ok(p, p.taps, ks) ? x2d::halo_cols(W) : 0;
@@ -1710,19 +1517,19 @@ int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, i
   if (dir == 0) {
     const long Ng = (long)N * p.OHW;
     if (thin::geometry_ok(p) && ((C2 == 0 && Cin <= 4) || Cout <= 4)) return 4;
-    if (x3_plan(p, Cin, C1, C2, Cout, Ng).ok) return SPLIT_FWD_DGRAD_X2 ? 5 : 2;
+    if (x3_plan(p, Cin, C1, C2, Cout, Ng).ok) return 5;
     return use_big_tile(Cout, Ng, 1) && !(p.taps == 1 && w_layout == 0 && (Cin % 8)) ? 1 : 0;
   }
   if (dir == 1) {
     const long Ng = (long)N * p.HW;
     if (thin::geometry_ok(p) && Cout <= 4) return 4;
-    if (x3_plan(p, Cout, Cout, 0, Cin, Ng).ok) return SPLIT_FWD_DGRAD_X2 ? 5 : 2;
+    if (x3_plan(p, Cout, Cout, 0, Cin, Ng).ok) return 5;
     return use_big_tile(Cin, Ng, 1) && !(p.taps == 1 && w_layout == 1 && (Cout % 8)) ? 1 : 0;
   }
   if (thin::geometry_ok(p) && ((C2 == 0 && Cin <= 4) || Cout <= 4)) return 4;
   {
     const X3WgradPlan xq = x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad);
-    if (xq.ok) return (xq.rows3 ? SPLIT_WGRAD3_X2 : wgrad1_x2()) ? 5 : 2;
+    if (xq.ok) return 5;
   }
   const bool can9 = stride == 1 && pad == 1 && C2 == 0 && OH == H && OW == W && w_layout == 0;
   const WgradPlan q = wgrad_plan(Cin, N, Cout, OH, OW, KH, KW, can9);
@@ -1758,18 +1565,12 @@ long stk_conv2d_wp_desc(int dir, const float* w, int w_layout, int Cin, int Cout
 }
 
 int stk_conv2d_wprep_batch(const StkWprepDesc* descs_dev, int n, long max_items, void* stream) {
-  static_assert(sizeof(StkWprepDesc) == sizeof(x3::WprepDesc) && sizeof(StkWprepDesc) == sizeof(x2::WprepDesc),
-                "descriptor layout");
+  static_assert(sizeof(StkWprepDesc) == sizeof(x2::WprepDesc), "descriptor layout");
   if (!descs_dev || n <= 0 || max_items <= 0 || n > 65535) return STK_EINVAL;
   const dim3 grid((unsigned)stk_cdiv(max_items, 256L), (unsigned)n);
-  if (SPLIT_FWD_DGRAD_X2) {
-    const x2::WprepDesc* d = reinterpret_cast<const x2::WprepDesc*>(descs_dev);
-    hipLaunchKernelGGL(x2::wamax_kernel, dim3(x2::WPART, (unsigned)n), dim3(256), 0, (hipStream_t)stream, d, x2::WprepDesc{});
-    hipLaunchKernelGGL(x2::wprep_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, x2::WprepDesc{});
-  } else {
-    hipLaunchKernelGGL(x3::wprep_batch_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const x3::WprepDesc*>(descs_dev));
-  }
+  const x2::WprepDesc* d = reinterpret_cast<const x2::WprepDesc*>(descs_dev);
+  hipLaunchKernelGGL(x2::wamax_kernel, dim3(x2::WPART, (unsigned)n), dim3(256), 0, (hipStream_t)stream, d, x2::WprepDesc{});
+  hipLaunchKernelGGL(x2::wprep_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, x2::WprepDesc{});
   STK_CHECK_LAUNCH();
   return STK_OK;
 }
@@ -1834,16 +1635,15 @@ int stk_conv2d_wgrad_amax_f32(const float* x1, int C1, const float* x2, int C2, 
     return STK_OK;
   }
   const X3WgradPlan xq = x3_wgrad_plan(C1, C2, N, Cout, H, W, OH, OW, KH, KW, stride, pad);
-  if (xq.ok && ws_bytes >= (long)xq.splits * xq.slab * 4) {
+  if (xq.ok && ws_bytes >= (long)xq.splits * xq.slab * 4 + 256 + 3L * x2::NPART * 4) {      // slabs + the |dy| / |x| partial maxima
     p.x1 = x1; p.x2 = C2 > 0 ? x2 : x1; p.dy = dy; p.w_layout = w_layout; p.part = ws; p.part_stride = xq.slab;
-    x3::Src q = {};
     const int tm = stk_cdiv(Cout, 128), tn = stk_cdiv(p.Cin, 128);
     const int nch = (int)((long)N * p.HW / 32);
     if (xq.rows3) {
       const int tn64 = stk_cdiv(p.Cin, 64);
       const dim3 grid3((unsigned)(3 * tm * tn64 * xq.splits));
       float* parts = reinterpret_cast<float*>(((uintptr_t)(ws + (long)xq.splits * xq.slab) + 255) & ~(uintptr_t)255);
-      if (SPLIT_WGRAD3_X2 && ws_bytes >= (long)xq.splits * xq.slab * 4 + 256 + 3L * x2::NPART * 4) {
+      {
         // fp16 two-way split of both operands (conv_x2.h): |dy| and |x| maxima first
         const dim3 ab(x2::NPART), at(x2::AMAX_THREADS);
         // maxima the layer's forward (x) / data-gradient (dy) calls left in `amax` are reused, the others taken here
@@ -1862,10 +1662,6 @@ int stk_conv2d_wgrad_amax_f32(const float* x1, int C1, const float* x2, int C2, 
                                        dyp, xp, nx);
         else hipLaunchKernelGGL((x2::wgrad3_kernel<false>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split,
                                 dyp, xp, nx);
-      } else if (C2 > 0) {
-        hipLaunchKernelGGL((x3::wgrad3_kernel<true>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split);
-      } else {
-        hipLaunchKernelGGL((x3::wgrad3_kernel<false>), grid3, dim3(256), 0, s, p, tm, tn64, nch, xq.chunks_per_split);
       }
       STK_CHECK_LAUNCH();
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((xq.slab + 3) / 4)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
@@ -1874,7 +1670,7 @@ int stk_conv2d_wgrad_amax_f32(const float* x1, int C1, const float* x2, int C2, 
       return STK_OK;
     }
     const dim3 grid((unsigned)(p.taps * tm * tn * xq.splits));
-    if (wgrad1_x2() && ws_bytes >= (long)xq.splits * xq.slab * 4 + 256 + 3L * x2::NPART * 4) {
+    {
       // fp16 two-way split of both operands (x2::wgemm_kernel): maxima as for the three-taps kernel above
       float* parts = reinterpret_cast<float*>(((uintptr_t)(ws + (long)xq.splits * xq.slab) + 255) & ~(uintptr_t)255);
       const dim3 ab(x2::NPART), at(x2::AMAX_THREADS);
@@ -1911,18 +1707,6 @@ int stk_conv2d_wgrad_amax_f32(const float* x1, int C1, const float* x2, int C2, 
       STK_CHECK_LAUNCH();
       return STK_OK;
     }
-#define STK_X3_WGRAD(DUAL, SEG)                                                                                     \
-  hipLaunchKernelGGL((x3::gemm_kernel<x3::RowsLoader<false, false, SEG>, x3::RowsLoader<true, DUAL, SEG>, EpWgrad, false>), \
-                     grid, dim3(256), 0, s, p, q, Cout, p.Cin, tm, tn, nch, xq.chunks_per_split, p.taps)
-    if (W >= 16) { if (C2 > 0) STK_X3_WGRAD(true, 16); else STK_X3_WGRAD(false, 16); }
-    else if (W == 8) { if (C2 > 0) STK_X3_WGRAD(true, 8); else STK_X3_WGRAD(false, 8); }
-    else { if (C2 > 0) STK_X3_WGRAD(true, 4); else STK_X3_WGRAD(false, 4); }
-#undef STK_X3_WGRAD
-    STK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stk_ew_grid((xq.slab + 3) / 4)), dim3(256), 0, s, ws, dw, xq.slab, xq.splits,
-                       xq.slab, alpha, w_layout, Cout, p.Cin, p.taps);
-    STK_CHECK_LAUNCH();
-    return STK_OK;
   }
   const bool can9 = stride == 1 && pad == 1 && C2 == 0 && OH == H && OW == W && w_layout == 0;
   const WgradPlan q = wgrad_plan(p.Cin, N, Cout, OH, OW, KH, KW, can9);

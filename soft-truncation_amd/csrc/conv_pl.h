@@ -93,178 +93,4 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   }
 }
 
-// ---- B loader of x2::gemm_kernel reading planes: four 16-byte copies per thread and chunk ---------------------------
-// piece g: split g >> 1, row (tid >> 2) + 64 (g & 1), 16-byte segment tid & 3 -- x2::WpLoader's mapping.
-template <int TAPS>
-struct PlaneLoader {
-  __amdgpu_buffer_rsrc_t rs; unsigned base[2], mask[2], ps; int row, seg;
-  u32x4 r[4];
-  __device__ __forceinline__ void init(const ConvP& p, const x3::Src& q, int n0, int tid, float) {
-    row = tid >> 2; seg = tid & 3;
-    ps = (unsigned)q.pl_stride;
-    rs = x3::make_rsrc(q.pl, 2L * q.pl_stride);
-    const int Cb = q.Kc >> 5;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + row + 64 * j;
-      mask[j] = 0; base[j] = 0;
-      if (n < p.N * p.HW) {
-        const int b = n / p.HW, hw = n - b * p.HW;
-        const int y = hw / p.W, x = hw - y * p.W;
-        if (TAPS == 1) mask[j] = 1u;
-#pragma unroll
-        for (int t = 0; t < (TAPS == 9 ? 9 : 0); ++t) {
-          const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask[j] |= 1u << t;
-        }
-        base[j] = ((unsigned)(b * Cb) * p.HW + hw) * 64u + seg * 16u;
-      }
-    }
-  }
-  __device__ __forceinline__ void ld(int g, const ConvP& p, const x3::Src&, int c) {
-    if (g >= 4) return;
-    const int cc = TAPS == 9 ? c / 9 : c, tap = c - cc * TAPS;   // scalar
-    const int j = g & 1;
-    const int shift = TAPS == 9 ? ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * 64 : 0;
-    const unsigned dead = (((mask[j] >> tap) & 1u) ^ 1u) << 31;  // halo rows: outside the buffer -> 0
-    const unsigned vo = (base[j] + (unsigned)shift) | dead;
-    r[g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                         rs, (int)vo, (int)((unsigned)cc * (unsigned)p.HW * 64u + (g >> 1) * ps), 0));
-  }
-  __device__ __forceinline__ void st(int g, unsigned char* t) {
-    if (g < 4) *reinterpret_cast<u32x4*>(t + (g >> 1) * PLANE + (row + 64 * (g & 1)) * PITCH + seg * 16) = r[g];
-  }
-};
-
-}  // namespace pl
-
-// ---- double-buffered variant of x2::gemm_kernel for plane operands ---------------------------------------------------
-// Both operands are 16-byte copies now, so the staging of a chunk is 8 loads + 8 ds_write_b128 per thread with no
-// conversion in between.  Two LDS buffers (80 KB per workgroup, two workgroups per CU = all 160 KB) take the second
-// barrier out of the chunk loop: while the waves read chunk c from one buffer, chunk c + 1 (already in registers) is
-// written to the other and chunk c + 2 is requested.  One barrier per chunk; staging slices ride behind every MFMA
-// of the chunk instead of only behind its second half.
-namespace pl {
-
-constexpr int DB_LDS = 2 * x2::LDS_BYTES;      // 81920
-
-// ABL (ablation, benchmarks only -- results are garbage unless 0): bit 0 drops the LDS writes of the staging, bit 1 its
-// global loads, bit 2 the per-chunk operand reads from LDS (the MFMAs then reuse the first chunk's registers).
-template <class BL, class EP, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void gemm_db_kernel(ConvP p, x3::Src q, int M, int Nn, int tiles_m, int tiles_n,
-                                                         int nchunks_total, int chunks_per_split,
-                                                         const float* __restrict__ xpart, int nxpart) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[DB_LDS];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
-  const float sx = x2::pow2_scale_of(x2::block_amax(xpart, nxpart, reinterpret_cast<float*>(lds)));
-  const float sw = x2::weight_scale(q.wp);
-  const float unscale = 1.f / (sw * sx);
-  const int ntiles = tiles_m * tiles_n;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = id % ntiles, zs = id / ntiles;
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
-  const int m0 = tm * 128, n0 = tn * 128;
-  const int c_begin = zs * chunks_per_split;
-  const int c_last = min(nchunks_total, c_begin + chunks_per_split) - 1;
-
-  x2::WpLoader al; BL bl;
-  al.init(q, m0, tid);
-  bl.init(p, q, n0, tid, sx);
-  EP ep;
-  ep.preload(p, m0, n0, 128, M, Nn, tid);
-
-  floatx16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 64;
-  const int fk = lane >> 5, fc = lane & 31;
-  const int a_off = (wm0 + fc) * PITCH + fk * 16;
-  const int b_off = x2::OPER + (wn0 + fc) * PITCH + fk * 16;
-
-#define STK_DB_FRAGS(BUF, KK)                                                                           \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s = 0; s < 2; ++s) {          \
-    a[i][s] = *reinterpret_cast<const halfx8*>((BUF) + a_off + s * PLANE + i * 32 * PITCH + (KK) * 32);  \
-    b[i][s] = *reinterpret_cast<const halfx8*>((BUF) + b_off + s * PLANE + i * 32 * PITCH + (KK) * 32);  \
-  }
-  constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};
-#define STK_DB_MFMA(G)                                                                                              \
-  acc[((G) >> 1) & 1][(G) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[((G) >> 1) & 1][SA[(G) >> 2]], b[(G) & 1][SB[(G) >> 2]], \
-                                                                        acc[((G) >> 1) & 1][(G) & 1], 0, 0, 0);
-  // prologue: chunk c_begin -> buffer 0, chunk c_begin + 1 -> registers
-#pragma unroll
-  for (int g = 0; g < 4; ++g) { al.ld(g, c_begin); bl.ld(g, p, q, c_begin); }
-  {
-    const int c1 = min(c_begin + 1, c_last);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) { al.st(g, lds); bl.st(g, lds + x2::OPER); al.ld(g, c1); bl.ld(g, p, q, c1); }
-  }
-  halfx8 a[2][2], b[2][2];
-  int cur = 0;
-  for (int c = c_begin; c < c_last; ++c) {
-    unsigned char* rd = lds + cur * x2::LDS_BYTES;
-    unsigned char* wr = lds + (cur ^ 1) * x2::LDS_BYTES;
-    __syncthreads();                                   // chunk c is in `rd`; nobody reads `wr` (chunk c - 1) any more
-    if (!(ABL & 4) || c == c_begin) { STK_DB_FRAGS(rd, 0) }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 12; ++g) {
-      STK_DB_MFMA(g)
-      if (!(ABL & 1) && g >= 2 && g < 6) { al.st(g - 2, wr); bl.st(g - 2, wr + x2::OPER); }      // chunk c + 1 -> the other buffer
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!(ABL & 4)) { STK_DB_FRAGS(rd, 1) }
-    const int c2 = min(c + 2, c_last);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 12; ++g) {
-      STK_DB_MFMA(g)
-      if (!(ABL & 2) && g >= 2 && g < 6) { al.ld(g - 2, c2); bl.ld(g - 2, p, q, c2); }           // chunk c + 2 -> registers
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    cur ^= 1;
-  }
-  {
-    unsigned char* rd = lds + cur * x2::LDS_BYTES;
-    __syncthreads();
-    STK_DB_FRAGS(rd, 0)
-#pragma unroll
-    for (int g = 0; g < 12; ++g) { STK_DB_MFMA(g) }
-    STK_DB_FRAGS(rd, 1)
-#pragma unroll
-    for (int g = 0; g < 12; ++g) { STK_DB_MFMA(g) }
-  }
-#undef STK_DB_MFMA
-#undef STK_DB_FRAGS
-
-  ep.stage(lds, tid);
-  ep.init(p, 0, zs);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn0 + j * 32 + fc;
-    const bool nok = n < Nn;
-    ep.col(p, nok ? n : 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] *= unscale;
-      ep.strip(p, m0 + wm0 + i * 32 + 4 * fk, M, nok, nok ? n : 0, acc[i][j]);
-    }
-  }
-}
-
-// Kernel for plane operands, STK_PL_KERNEL (A/B switch of the kernel benchmarks; all give the same results up to the
-// accumulation order): 4 (default) = LDS-DMA staging, 128 x 128 tiles (conv_x2d.h); 3 = the same with 128 x 256 tiles
-// where they fill the chip; 1 = register staging, double-buffered LDS (above); 0 / 2 = x2::gemm_kernel's structure with
-// the plane loader (2 / 3 waves per SIMD); >= 16 = ablation builds of the double-buffered kernel.
-inline int kernel_choice() {
-  static const int v = [] { const char* e = getenv("STK_PL_KERNEL"); return e ? atoi(e) : 4; }();
-  return v;
-}
-
 }  // namespace pl

@@ -372,222 +372,11 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(ConvP p, x3::Src q, i
   ep.finish(p, lds, tid);
 }
 
-// ---- small tiles for small problems (round 5) ------------------------------------------------------------------------
-// Where 128 x 128 tiles do not fill the chip (8x8 / 4x4 maps at batch 128: 128 / 32 tiles; every level below 64x64 of the
-// 256x256 net at batch 4) gemm_kernel splits K, writes partial [M][N] slabs and a second launch sums them: two launches with
-// their prologues per layer and direction, 20-47 us for 0.1-10 GFLOP (profiles/r04_ksplit_sweep.txt, r05_ksplit_b4.txt: no
-// choice of split moves the floor of ~16 us).  Here the tile is 64 output channels x 64 pixels -- four times the tiles, so the
-// 8x8 level at batch 128 (512 tiles) and the 32x32 level at batch 4 (256) need no split at all, the 4x4 level two to four
-// channel-group splits instead of six -- with the halo staging of gemm_halo_kernel adapted to it:
-//   * a tile is 64 consecutive pixels of one image (W >= 8: 64 / W whole rows) or FOUR whole 4x4 images, each with its own
-//     6 x 6 halo tile; the halo tile of a 32-channel group is staged once ((IMGS (R + 2) (W + 2) rows of 64 bytes per plane: 7
-//     or 9 DMA instructions) into the other of two B buffers, one piece per wave and chunk, while the current group computes;
-//   * the weights of a chunk are 64 rows: ONE DMA instruction per wave and plane, in a ring of three buffers filled two
-//     chunks ahead (a chunk is 6 MFMAs per wave here, far less than a DMA's latency), one barrier per chunk;
-//   * the first loads are issued BEFORE the scale records are reduced (only the epilogue needs the scales).
-// A wave owns a 32 x 32 sub-tile: 8 fragment reads per 6 MFMAs -- the kernel is LDS-read-bound, not matrix-bound, which is
-// the price of the parallelism; K is split over whole channel groups only (EpSlab + slab sum, as before).
-template <int W, class EP>
-__global__ __launch_bounds__(256, 2) void gemm_halo64_kernel(ConvP p, x3::Src q, int M, int Nn, int tiles_m, int tiles_n,
-                                                             int ngroups, int groups_per_split,
-                                                             const float* __restrict__ xpart, int nxpart) {
-  constexpr int TM = 64, TN = 64;
-  constexpr int IMGS = W == 4 ? 4 : 1;                                    // whole 4x4 images per tile
-  constexpr int R = W == 4 ? 4 : TN / W;                                  // map rows of one image in the tile
-  constexpr int TP = W + 2, TIMG = (R + 2) * TP;                          // halo rows (of 64 bytes) per image
-  constexpr int HR = IMGS * TIMG, NI = (HR + 15) / 16, HRP = NI * 16, NK = (NI + 3) / 4;
-  constexpr int NS = 3;                                                   // ring of weight tiles
-  constexpr int A_PLANE = TM * 64, A_BYTES = 2 * A_PLANE;                 // 8 KB per chunk
-  constexpr int B_PLANE = HRP * 64, B_BYTES = 2 * B_PLANE;
-  static_assert(2 * NK <= 8, "the B pieces of a group are issued one per chunk over taps 0..7");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * A_BYTES + 2 * B_BYTES];
-  __shared__ float red[4];
-  unsigned char* const As = lds;
-  unsigned char* const Bs = lds + NS * A_BYTES;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntiles = tiles_m * tiles_n;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = id % ntiles, zs = id / ntiles;
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int g_begin = zs * groups_per_split, g_end = min(ngroups, g_begin + groups_per_split);
-  const int c_end = g_end * 9;
-
-  const unsigned seg_src = (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
-  const unsigned a_plane2 = (unsigned)q.taps * q.Mpad * q.Kc * 2u;
-  const unsigned a_chunk2 = (unsigned)q.Mpad * KC * 2u;
-  const __amdgpu_buffer_rsrc_t a_rs = x3::make_rsrc(reinterpret_cast<const unsigned char*>(q.wp) + x2::HEADER, 2L * a_plane2);
-  const unsigned a_voff = (unsigned)(m0 + 16 * wid + (lane >> 2)) * 64u + seg_src;     // wave w stages rows 16 w .. 16 w + 15
-  const __amdgpu_buffer_rsrc_t b_rs = x3::make_rsrc(q.pl, 2L * q.pl_stride);
-  const unsigned b_ps = (unsigned)q.pl_stride;
-  // halo rows of this lane: instruction i = wid + 4 k covers LDS rows 16 i .. 16 i + 15, lane -> row 16 i + lane / 4
-  unsigned b_voff[NK];
-  {
-    const int Cb = q.Kc >> 5;
-    const int b0 = n0 / p.HW, hw0 = n0 - b0 * p.HW, y0 = W == 4 ? 0 : hw0 / p.W;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const int row = 16 * (wid + 4 * k) + (lane >> 2);
-      const int img = row / TIMG, rr = row - img * TIMG;
-      const int ty = rr / TP, tx = rr - ty * TP;
-      const int b = b0 + img, y = y0 - 1 + ty, x = tx - 1;
-      const bool ok = row < HR && b < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
-      b_voff[k] = ok ? ((unsigned)(b * Cb) * p.HW + (unsigned)(y * p.W + x)) * 64u + seg_src : 0x80000000u;
-    }
-  }
-  auto stage_a = [&](int c, int slot) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-      dma16(a_rs, As + slot * A_BYTES + s * A_PLANE + (16 * wid) * 64, a_voff, (unsigned)c * a_chunk2 + s * a_plane2);
-  };
-  auto stage_b = [&](int cc, int buf, int k, int s) {                     // k, s compile-time at every call site
-    if (wid + 4 * k >= NI) return;                                        // wave-uniform
-    dma16(b_rs, Bs + buf * B_BYTES + s * B_PLANE + (wid + 4 * k) * 1024, b_voff[k],
-          (unsigned)cc * (unsigned)p.HW * 64u + s * b_ps);
-  };
-
-  // first loads: the whole halo tile of the first group, the weights of the first two chunks
-  int c = g_begin * 9;
-#pragma unroll
-  for (int k = 0; k < NK; ++k)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) stage_b(g_begin, 0, k, s);
-  stage_a(c, 0);
-  if (c + 1 < c_end) stage_a(c + 1, 1);
-
-  EP ep;
-  ep.preload(p, m0, n0, TN, M, Nn, tid);
-  // the scale records: loaded now (older than every load of the main loop, so they never hold up its counted waits), reduced
-  // after it -- only the epilogue needs them
-  float pmax = xpart[tid];
-  if (nxpart > x2::NPART) pmax = fmaxf(pmax, xpart[x2::NPART + tid]);
-  const float sw = x2::weight_scale(q.wp);
-
-  floatx16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-
-  const int wm0 = (wid & 1) * 32, wn0 = (wid >> 1) * 32;
-  const int fk = lane >> 5, fc = lane & 31;
-  const int fsw = (fc >> 2) & 3;
-  const unsigned char* a_rd = As + (wm0 + fc) * 64;
-  const int ka0 = ((0 + fk) ^ fsw) * 16, ka1 = ((2 + fk) ^ fsw) * 16;
-  int b_row;                                                              // halo row of this lane's pixel for the centre tap
-  {
-    const int pt = wn0 + fc;
-    if (W == 4) b_row = (pt >> 4) * TIMG + (((pt & 15) >> 2) + 1) * TP + (pt & 3) + 1;
-    else b_row = (pt / W + 1) * TP + (pt % W) + 1;
-  }
-  halfx8 a[2], b[2];
-#define STK_S_MFMAS                                                                                         \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);                                    \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);                                    \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
-#define STK_S_FRAGS(KA, KSEG)                                                                               \
-  _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                           \
-    a[s] = *reinterpret_cast<const halfx8*>(abase + s * A_PLANE + (KA));                                    \
-    b[s] = *reinterpret_cast<const halfx8*>(bbase + s * B_PLANE + brow * 64 + ((((KSEG) + fk) ^ (brow >> 2)) & 3) * 16); \
-  }
-
-  int slot = 0;
-  for (int cc = g_begin; cc < g_end; ++cc) {
-    const int bbuf = (cc - g_begin) & 1;
-    const unsigned char* bbase = Bs + bbuf * B_BYTES;
-    const bool more = cc + 1 < g_end;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap, ++c) {
-      const int brow = b_row + (tap / 3 - 1) * TP + (tap % 3 - 1);
-      // this wave's weights of chunk c have landed (issued after them: at most one B piece and the two of chunk c + 1), and
-      // with them every B piece issued before -- all of this group's halo tile
-      if (c + 1 < c_end) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                                   // ... everybody's; and nobody reads chunk c - 1 / group cc - 1 any more
-      if (tap < 2 * NK && more) stage_b(cc + 1, bbuf ^ 1, tap >> 1, tap & 1);
-      if (c + 2 < c_end) stage_a(c + 2, slot >= 1 ? slot - 1 : NS - 1);      // (slot + 2) % 3
-      const unsigned char* abase = a_rd + slot * A_BYTES;
-      STK_S_FRAGS(ka0, 0)
-      STK_S_MFMAS
-      STK_S_FRAGS(ka1, 2)
-      STK_S_MFMAS
-      slot = slot == NS - 1 ? 0 : slot + 1;
-    }
-  }
-#undef STK_S_MFMAS
-#undef STK_S_FRAGS
-
-  float unscale;
-  {
-    const float m = wave_max(pmax);
-    if (lane == 0) red[wid] = m;
-    __syncthreads();
-    unscale = 1.f / (sw * x2::pow2_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
-  }
-  ep.stage(lds, tid);
-  ep.init(p, 0, zs);
-  {
-    const int n = n0 + wn0 + fc;
-    const bool nok = n < Nn;
-    ep.col(p, nok ? n : 0);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] *= unscale;
-    ep.strip(p, m0 + wm0 + 4 * fk, M, nok, nok ? n : 0, acc);
-  }
-  ep.finish(p, lds, tid);
-}
-
-// The small-tile plan of a plane-operand 3x3 call (STK_X2D_T64=0: off): shapes gemm_halo64_kernel takes and for which 128 x 128
-// tiles would not fill the chip.  K is split over whole 32-channel groups, and only while the tiles alone leave CUs idle.
-struct T64Plan { int ok; int splits; int groups_per_split; };
-// OFF by default (STK_X2D_T64=1 switches it on): the kernel-level gains below did not survive inside the training step.  Measured with
-// bench.py's event brackets on the eager steps (profiles/r05_t64_in_situ.txt): the 8x8 layers at batch 128 take 66.5 us on the small
-// tiles against 43.1 us in the back-to-back micro-benchmark -- and 44 us on the 128-tile K-split form, which measures the same in both
-// settings; the step went 39.3-39.5 -> 40.0 ms (CIFAR-10 net), 39.64 -> 39.62 (256x256 net, batch 4), 124.0 -> 124.8 (64x64 net).  A
-// kernel that is bound by LDS reads and barriers rather than by the matrix pipe runs at whatever clock its neighbours leave: alone it
-// enjoys the boost clock, inside a step of power-limited GEMMs it does not, while the matrix-bound kernels are power-limited either way.
-inline int t64_mode() { static const int v = [] { const char* e = getenv("STK_X2D_T64"); return e ? atoi(e) : 0; }(); return v; }
-inline T64Plan t64_plan(const ConvP& p, int taps, int Kc, int M, long Ng) {
-  T64Plan r = {0, 1, 0};
-  if (!t64_mode() || taps != 9 || p.H * p.W != p.HW || p.stride != 1) return r;
-  const bool geom = (p.W == 4 && p.H == 4) || ((p.W == 8 || p.W == 16 || p.W == 32) && p.HW % 64 == 0);
-  if (!geom || Kc % 32) return r;
-  const long t128 = (long)stk_cdiv(M, 128) * stk_cdiv(Ng, 128);
-  if (t128 >= 192) return r;                              // the large tiles fill the chip: their kernels are the faster ones
-  const long tiles = (long)stk_cdiv(M, 64) * stk_cdiv(Ng, 64);
-  const int ngroups = Kc / 32;
-  // STK_T64_WGS: workgroups worth splitting K for (default 512 = two per CU); at least two channel groups (18 chunks) per split
-  static const long target = [] { const char* e = getenv("STK_T64_WGS"); return e && atol(e) > 0 ? atol(e) : 512L; }();
-  long splits = tiles >= target ? 1 : stk_cdiv(target, tiles);
-  if (splits > ngroups / 2) splits = ngroups / 2;
-  if (splits < 1) splits = 1;
-  r.groups_per_split = (int)stk_cdiv((long)ngroups, splits);
-  r.splits = stk_cdiv(ngroups, r.groups_per_split);
-  // Per unit of work the small tiles are about half as efficient as the large ones (8 fragment reads per 6 MFMAs, a barrier per
-  // 6 MFMAs): they win by what they save -- the second launch, the slabs, idle CUs -- only while a workgroup's share of K is
-  // short.  Measured (profiles/r05_t64_ab.txt, us, 128-tile K-split form -> small tiles): 256 -> 256 at 8x8, batch 128 (72 chunks, no
-  // split) 47.3 -> 43.1; at 4x4 (18 chunks) 24.3 -> 20.0; 512 -> 256 at 4x4 (36) 34.0 -> 28.9; 256 -> 256 at 16x16, batch 16 (36)
-  // 33.9 -> 26.4; but 512 -> 256 at 8x8, batch 128 (144 chunks) 69.2 -> 99.3 and at 16x16, batch 16 (72 chunks + slabs) 44.6 -> 53.8.
-  // STK_X2D_T64=2 lifts the limit (A/B).
-  const int chunks = r.groups_per_split * 9;
-  if (t64_mode() != 2 && chunks > (r.splits == 1 ? 72 : 36)) return r;
-  r.ok = 1;
-  return r;
-}
-
-// shapes of the halo kernel: 3x3 on 16- or 32-wide maps made of whole 128-pixel tiles, no K split (STK_X2D_HALO=0: off)
-inline int halo_mode() { static const int v = [] { const char* e = getenv("STK_X2D_HALO"); return e ? atoi(e) : 1; }(); return v; }
-// template width of the kernel that takes a map of width W (0 = none): the map width itself up to 64, row strips of 128 beyond
-inline int halo_cols(int W) {
-  // row strips on the 128- / 256-wide maps: measured SLOWER than x2d::gemm_kernel (256 x 256 net, batch 4: forward 187.9 -> 203.1 us,
-  // data gradient 184.0 -> 190.9: 67 KB of LDS leave two workgroups per CU for the refill burst) -- off unless STK_X2D_HALO_WIDE=1
-  static const bool wide = [] { const char* e = getenv("STK_X2D_HALO_WIDE"); return e && atoi(e) != 0; }();
-  if (W == 16 || W == 32) return W;
-  if (W == 64 && halo_mode() == 1) return 64;
-  if ((W == 128 || W == 256) && halo_mode() == 1 && wide) return 128;
-  return 0;
-}
+// shapes of the halo kernel: 3x3 on 16-, 32- or 64-wide maps made of whole 128-pixel tiles, no K split.  (Row strips for the 128- /
+// 256-wide maps and a two-buffer form were measured slower in rounds 3-4 and retired in round 6: DESIGN.md "Retired".)
+inline int halo_cols(int W) { return (W == 16 || W == 32 || W == 64) ? W : 0; }
 inline bool halo_ok(const ConvP& p, int taps, int splits) {
-  return halo_mode() != 0 && taps == 9 && splits == 1 && halo_cols(p.W) != 0 && p.HW % 128 == 0 && p.H * p.W == p.HW;
+  return taps == 9 && splits == 1 && halo_cols(p.W) != 0 && p.HW % 128 == 0 && p.H * p.W == p.HW;
 }
 
 }  // namespace x2d

@@ -9,15 +9,26 @@
 // [4 pixels][16 channels] block and every lane receives 4 consecutive PIXELS of its channel (semantics pinned by
 // tools/_probe/tr.hip on the hardware).  What that buys over x2::wgrad3_kernel (fp32 NCHW operands, split on the fly,
 // one kernel row per workgroup, three shifted windows of x written to LDS per chunk):
-//   * a tap shift is a shift by whole 64-byte LDS rows, so ONE staged halo tile of x (the chunk's pixels, one row above
-//     and below, one column left and right) serves all nine taps: 14 KB of x + 16 KB of dy per 32-pixel chunk and
-//     216 MFMAs per workgroup, against 46 KB per 144;
+//   * a tap shift is a shift by whole 64-byte LDS rows, so ONE staged tile per operand serves all nine taps;
 //   * no conversion and no ds_write at all: both tiles arrive by `buffer_load_dwordx4 ... lds`, halo pixels outside the
-//     map as zeros from the buffer range check; the two LDS buffers alternate, one barrier per chunk;
+//     map as zeros from the buffer range check; one barrier per chunk;
 //   * the planes are the ones the forward (x) and the data gradient (dy) already use -- no fp32 copy of either tensor
 //     is read, so GroupNorm need not write one for its 3x3 consumers.
 // Workgroup = 128 output channels (wave w owns 32-block w) x 32 input channels x 9 taps, over a slab of the pixels;
 // partial slabs [tap][Cout][Cin] are summed by splitk_reduce_kernel in a fixed order, as for the other weight gradients.
+//
+// Round 6 -- where the taps' shifts sit.  Rounds 2-5 shifted x for all nine taps: per 16-pixel half chunk a wave read 4 fragments
+// of dy and 36 of x (9 taps x 2 planes x 2 reads) for 27 MFMAs.  But
+//   sum_p dy[co, (py, px)] x[ci, (py + kh - 1, px + kw - 1)]  =  sum_q dy[co, (qy, qx - (kw - 1))] x[ci, (qy + kh - 1, qx)]
+// (q = p moved by the tap's column offset; dy = 0 where qx - (kw - 1) leaves the map -- exactly the pairs the left side drops
+// because x is outside): the COLUMN shift can sit on dy and only the ROW shift on x.  Three column-shifted fragments of dy and
+// three row-shifted fragments of x serve the nine taps: 12 + 12 fragment reads per half chunk instead of 4 + 36 (-40 % of the
+// LDS read traffic, 209 instead of 235 registers), the same 27 MFMAs.  The dy tile of a 32-channel block gets one halo column
+// on each side ([ROWS][COLS + 2] pixel slots, <= 48: three DMA instructions per plane instead of two), the x tile loses its
+// halo columns ([ROWS + 2][COLS] slots, <= 96: six instructions per plane instead of seven).  Measured (MI355X, batch 128,
+// kernel + reduce, 256 workgroups, profiles/r06_x2w.txt): 128 -> 128 @ 32 x 32 138.8 -> 132.9 us, 384 -> 128 397.3 -> 373.5, the
+// 16- / 8- / 4-wide maps within 2 %; in the step -0.04 ms: with ONE workgroup per CU the kernel is bound by the latency of its
+// LDS-DMA -- or so it seemed: a third LDS stage bought nothing either (STAGES below).
 #pragma once
 
 namespace x2w {
@@ -25,13 +36,6 @@ namespace x2w {
 typedef short s4 __attribute__((__vector_size__(8)));
 typedef __attribute__((address_space(3))) s4 lds_s4;
 typedef __attribute__((address_space(3))) void lds_void;
-
-constexpr int A_BLK = 32 * 64;              // one 32-channel block of dy for a chunk: 32 pixels x 64 bytes
-constexpr int A_PLANE = 4 * A_BLK;          // 8192
-constexpr int B_INSTR = 7;                  // DMA instructions (16 pixels each) per plane of the x halo tile
-constexpr int B_PLANE = B_INSTR * 16 * 64;  // 7168 (112 pixel slots; <= 102 used)
-constexpr int BUF = 2 * A_PLANE + 2 * B_PLANE;   // 30720
-constexpr int LDS = 2 * BUF;                     // 61440: two workgroups per CU
 
 struct Args {
   const unsigned char* dypl; const float* dyrec; long dy_ps;     // planes of dy [N, Cout, H, W], scale record, bytes per plane
@@ -57,25 +61,37 @@ __device__ __forceinline__ halfx8 cat(s4 lo, s4 hi) {
   return __builtin_bit_cast(halfx8, v);
 }
 
-// COLS = min(W, 32): pixels of a chunk per map row (a chunk is 32 consecutive pixels = 32 / COLS whole rows, or a
-// 32-pixel piece of one row when W > 32)
+constexpr int A_INSTR = 3;
+constexpr int A_BLK = A_INSTR * 16 * 64;    // 3072: 48 pixel slots of one 32-channel block of dy
+constexpr int A_PLANE = 4 * A_BLK;          // 12288
+constexpr int B_INSTR = 6;
+constexpr int B_PLANE = B_INSTR * 16 * 64;  // 6144: 96 pixel slots of x
+constexpr int BUF = 2 * A_PLANE + 2 * B_PLANE;   // 36864 per stage
+
+// COLS = min(W, 32): pixels of a chunk per map row (a chunk is 32 consecutive pixels = 32 / COLS whole rows, or a 32-pixel
+// piece of one row when W > 32; COLS = 4: two whole 4 x 4 images).
 // GROUPS = 2 (round 4): a workgroup of EIGHT waves, two groups of four that own the SAME 128 x 32 x 9 block and take the
-// split's chunks alternately, each with its own pair of LDS buffers; after the last chunk group 1 hands its 144 accumulators
-// per thread to group 0 through the (now free) LDS in three rounds of three taps, and group 0 writes the slab.  One such
-// workgroup per CU holds the same eight waves as two four-wave ones did, but the K split -- and with it the slab traffic
-// (every split writes, and the reduce reads, 9 Cout Cin floats: 75 MB per launch on the 128 -> 128 layers at batch 128 for
-// a 0.6 MB result) -- is half as deep.  The sum of the two groups is taken in a fixed order (group 0 + group 1).
+// split's chunks alternately, each with its own LDS stages; after the last chunk group 1 hands its 144 accumulators per thread
+// to group 0 through the (now free) LDS in three rounds of three taps, and group 0 writes the slab: half the K split and slab
+// traffic at the same eight waves per CU.  The sum of the two groups is taken in a fixed order (group 0 + group 1).
+// STAGES = 2: LDS stages of the DMA ring.  Three stages (two chunks in flight, 110 KB of LDS) were measured in round 6 and bought
+// nothing -- 128 -> 128 @ 32 x 32 at 256 workgroups 134.4 (two) / 135.9 us (three), 384 -> 128 378.2 / 380.8 -- and cost the step
+// 0.2 ms (35.82 -> 35.99 / 36.04 ms: more LDS, 296 instead of 209 registers, less room for the main chain's waves on the CU), so
+// the kernel is not waiting for its DMA either (profiles/r06_x2w.txt).
 template <int COLS, int GROUPS = 1>
 __global__ __launch_bounds__(256 * GROUPS, 2) void wgrad_kernel(Args a) {
-  // COLS = 4 (4 x 4 maps): a chunk is TWO whole images, each with its own 6 x 6 halo tile (slot = 36 img + 6 ty + tx)
-  constexpr bool TWO = COLS == 4;
-  constexpr int ROWS = 32 / COLS, TP = COLS + 2, TR = TWO ? 12 : ROWS + 2;
-  static_assert(TR * TP <= B_INSTR * 16, "halo tile exceeds the staged slots");
+  constexpr int STAGES = 2;
+  constexpr bool TWO = COLS == 4;           // 4 x 4 maps: a chunk is two whole images
+  constexpr int ROWS = 32 / COLS;           // chunk rows (TWO: 8 = 4 + 4)
+  constexpr int TPA = COLS + 2;             // dy tile: row pitch in slots (halo column left and right)
+  constexpr int TRB = TWO ? 12 : ROWS + 2;  // x tile: rows (halo row above and below; TWO: 6 per image)
+  constexpr int LDS = STAGES * BUF;
+  static_assert(ROWS * TPA <= A_INSTR * 16 && TRB * COLS <= B_INSTR * 16, "tiles exceed the staged slots");
   __shared__ __attribute__((aligned(1024))) unsigned char lds_all[LDS * GROUPS];
   const int tid = threadIdx.x & 255, lane = tid & 63;
   const int grp = GROUPS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned char* const lds = lds_all + grp * LDS;               // this group's two buffers
+  unsigned char* const lds = lds_all + grp * LDS;               // this group's stages
   // (every group reduces the 256 partial maxima for itself, in its own LDS: the barriers inside are workgroup-wide)
   const float sa = x2::pow2_scale_of(group_amax(a.dyrec, tid, reinterpret_cast<float*>(lds)));
   const float sb = x2::pow2_scale_of(group_amax(a.xrec, tid, reinterpret_cast<float*>(lds)));
@@ -92,45 +108,55 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void wgrad_kernel(Args a) {
   // ---- DMA sources ----------------------------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t a_rs = x3::make_rsrc(a.dypl, 2L * a.dy_ps);
   const __amdgpu_buffer_rsrc_t b_rs = x3::make_rsrc(a.xpl, 2L * a.x_ps);
-  const unsigned piece = (unsigned)(lane & 3) * 16u;
-  // dy: wave w stages block co_blk: (half, plane) -> 16 pixels x 64 bytes, contiguous in the planes
-  const unsigned a_voff = (co_live ? 0u : 0x80000000u) | ((unsigned)(lane >> 2) * 64u + piece);
-  // second half of the chunk (pixels 16..31): the next 16 pixels of the block, or -- 4 x 4 maps -- the next IMAGE's block
-  const unsigned a_half = TWO ? (unsigned)a.Cob * (unsigned)a.HW * 64u : 1024u;
-  // x halo tile: slot s = 16 j + lane / 4 holds tile pixel (ty, tx) = (s / TP, s % TP) = map pixel (y0 - 1 + ty, x0 - 1 + tx);
-  // wave w issues instructions j = w and w + 4
-  int b_rel[2], b_ty[2], b_tx[2];
+  const int piece = (lane & 3) * 16;
+  // dy tile of this wave's block: slot s = 16 j + lane / 4 = (row r, column c) holds map pixel (y0 + r, x0 + c - 1)
+  int a_rel[A_INSTR], a_c[A_INSTR];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int j = wid + 4 * u, s = 16 * j + (lane >> 2);
-    b_ty[u] = s / TP; b_tx[u] = s - b_ty[u] * TP;
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int sl = 16 * j + (lane >> 2);
+    int r = sl / TPA;
+    a_c[j] = sl - r * TPA;
+    int img = 0;
+    if (TWO) { img = r >> 2; r &= 3; }                                  // next image: Cob blocks on
+    if (sl >= ROWS * TPA || !co_live) a_c[j] = -1000000;                // never inside the map
+    a_rel[j] = (img * a.Cob * a.HW + r * a.W + a_c[j] - 1) * 64 + piece;
+  }
+  // x tile: slot s = 16 j + lane / 4 = (row ty, column tx) holds map pixel (y0 - 1 + ty, x0 + tx).  The 12 instructions (6 per
+  // plane) go round the four waves, three each -- every wave issues the same number per stage (the vmcnt of the ring)
+  int b_rel[3], b_ty[3], b_dst[3]; unsigned b_pl[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int idx = wid + 4 * u, j = idx % B_INSTR, pl = idx / B_INSTR;
+    const int sl = 16 * j + (lane >> 2);
+    b_ty[u] = sl / COLS;
+    const int tx = sl - b_ty[u] * COLS;
     int img = 0;
     if (TWO) { img = b_ty[u] / 6; b_ty[u] -= 6 * img; }                 // row inside its image's tile
-    if (j >= B_INSTR || s >= TR * TP) b_ty[u] = -1000000;               // never inside the map
-    b_rel[u] = (img * a.Cib * a.HW + (b_ty[u] - 1) * a.W + (b_tx[u] - 1)) * 64 + (int)piece;   // next image: Cib blocks on
+    if (sl >= TRB * COLS) b_ty[u] = -1000000;
+    b_rel[u] = (img * a.Cib * a.HW + (b_ty[u] - 1) * a.W + tx) * 64 + piece;
+    b_dst[u] = 2 * A_PLANE + pl * B_PLANE + j * 1024;
+    b_pl[u] = (unsigned)pl;
   }
   auto stage = [&](int c, unsigned char* buf) {
     const int p0 = c * 32;                                               // first pixel of the chunk, over N * HW
     const int b = p0 / a.HW, hw0 = p0 - b * a.HW;
     const int y0 = hw0 / a.W, x0 = hw0 - y0 * a.W;
-    const unsigned a_soff = ((unsigned)(b * a.Cob + co_blk) * (unsigned)a.HW + (unsigned)hw0) * 64u;
+    const int a_chunk = ((b * a.Cob + co_blk) * a.HW + hw0) * 64;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(buf + s * A_PLANE + wid * A_BLK + h * 1024), 16,
-                                                 (int)(a_voff + h * a_half), (int)(a_soff + s * (unsigned)a.dy_ps), 0, 0);
-    const int b_chunk = ((b * a.Cib + tci) * a.HW + hw0) * 64;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (wid + 4 * u >= B_INSTR) continue;                              // wave-uniform
-      const int yy = y0 + b_ty[u] - 1, xx = x0 + b_tx[u] - 1;
-      const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-      const unsigned vo = ok ? (unsigned)(b_chunk + b_rel[u]) : 0x80000000u;     // outside the map: DMA of zeros
+    for (int j = 0; j < A_INSTR; ++j) {
+      const int xx = x0 + a_c[j] - 1;
+      const unsigned vo = (xx >= 0 && xx < a.W) ? (unsigned)(a_chunk + a_rel[j]) : 0x80000000u;    // outside the map: DMA of zeros
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(buf + 2 * A_PLANE + s * B_PLANE + (wid + 4 * u) * 1024), 16,
-                                                 (int)vo, (int)(s * (unsigned)a.x_ps), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(buf + s * A_PLANE + wid * A_BLK + j * 1024), 16,
+                                                 (int)vo, (int)(s * (unsigned)a.dy_ps), 0, 0);
+    }
+    const int b_chunk = ((b * a.Cib + tci) * a.HW + hw0) * 64;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int yy = y0 + b_ty[u] - 1;
+      const unsigned vo = (yy >= 0 && yy < a.H) ? (unsigned)(b_chunk + b_rel[u]) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(buf + b_dst[u]), 16, (int)vo, (int)(b_pl[u] * (unsigned)a.x_ps), 0, 0);
     }
   };
 
@@ -144,61 +170,64 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void wgrad_kernel(Args a) {
   // r0 + 4 (m % 4) .. + 3 and receives pixels k0 .. k0 + 3 of channel r0 + m:  r0 = 16 (g & 1), k0 = 8 (g >> 1) + 4 h + 16 kk
   const int m = lane & 15, g = lane >> 4;
   const int ch_off = (16 * (g & 1) + 4 * (m & 3)) * 2;
-  int a_off[2][2], b_off[2][2];                                          // [kk][h]
+  int a_off[2][2], b_off[2][2];                                          // [kk][h]: tap (1, 1) of the pixel this lane addresses
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int k = 16 * kk + 8 * (g >> 1) + 4 * h + (m >> 2);           // pixel of the chunk this lane addresses
-      a_off[kk][h] = wid * A_BLK + k * 64 + ch_off;
+      const int k = 16 * kk + 8 * (g >> 1) + 4 * h + (m >> 2);           // pixel of the chunk
       const int krow = k / COLS, kcol = k - krow * COLS;
+      a_off[kk][h] = wid * A_BLK + (krow * TPA + kcol + 1) * 64 + ch_off;
       const int trow = TWO ? (krow >> 2) * 6 + (krow & 3) : krow;        // two images: rows 0..3 | 4..7 -> tiles 0 | 1
-      b_off[kk][h] = 2 * A_PLANE + ((trow + 1) * TP + kcol + 1) * 64 + ch_off;      // tap (0, 0) of that pixel in the halo tile
+      b_off[kk][h] = 2 * A_PLANE + ((trow + 1) * COLS + kcol) * 64 + ch_off;
     }
   constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};                    // cross terms first (fixed accumulation order)
 
   auto compute = [&](const unsigned char* buf) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      halfx8 af[2];
+      halfx8 af[3][2];                                                   // [kw][plane]: dy at column qx - (kw - 1)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        af[s] = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * A_PLANE + a_off[kk][0])),
-                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * A_PLANE + a_off[kk][1])));
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int t3 = 0; t3 < 3; ++t3) {                                   // one kernel row at a time: 3 taps, 9 MFMAs
-        halfx8 bf[3][2];
+        for (int s = 0; s < 2; ++s)
+          af[t][s] = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * A_PLANE + a_off[kk][0] - (t - 1) * 64)),
+                         __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * A_PLANE + a_off[kk][1] - (t - 1) * 64)));
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const int shift = ((t3 - 1) * TP + (t - 1)) * 64;              // compile-time: an immediate offset
+      for (int t3 = 0; t3 < 3; ++t3) {                                   // one kernel row: x at row qy + (kh - 1)
+        halfx8 bf[2];
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
-            bf[t][s] = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * B_PLANE + b_off[kk][0] + shift)),
-                           __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * B_PLANE + b_off[kk][1] + shift)));
-        }
+        for (int s = 0; s < 2; ++s)
+          bf[s] = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * B_PLANE + b_off[kk][0] + (t3 - 1) * COLS * 64)),
+                      __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * B_PLANE + b_off[kk][1] + (t3 - 1) * COLS * 64)));
 #pragma unroll
         for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
           for (int t = 0; t < 3; ++t)
-            acc[3 * t3 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[SA[pr]], bf[t][SB[pr]], acc[3 * t3 + t], 0, 0, 0);
+            acc[3 * t3 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][SA[pr]], bf[SB[pr]], acc[3 * t3 + t], 0, 0, 0);
       }
     }
   };
 
-  // group g takes chunks c_begin + g, c_begin + g + GROUPS, ...; both groups run the same number of barrier rounds
+  // group g takes chunks c_begin + g, c_begin + g + GROUPS, ...; both groups run the same number of barrier rounds.  The ring keeps
+  // STAGES - 1 chunks in flight: chunk i of this group lives in stage i % STAGES.
   const int rounds = (c_last - c_begin + GROUPS) / GROUPS;
-  if (c_begin + grp <= c_last) stage(c_begin + grp, lds);
+#pragma unroll
+  for (int i = 0; i < STAGES - 1; ++i)
+    if (c_begin + i * GROUPS + grp <= c_last) stage(c_begin + i * GROUPS + grp, lds + i * BUF);
   int cur = 0;
   for (int it = 0; it < rounds; ++it) {
     const int c = c_begin + it * GROUPS + grp;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of chunk c has landed ...
-    __syncthreads();                                   // ... everybody's has, and nobody reads the other buffer any more
-    if (c + GROUPS <= c_last) stage(c + GROUPS, lds + (cur ^ 1) * BUF);
+    // this wave's part of chunk c has landed ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // ... everybody's has, and nobody reads the stage refilled below any more
+    const int nxt = cur + STAGES - 1 >= STAGES ? cur - 1 : cur + STAGES - 1;
+    if (c + (STAGES - 1) * GROUPS <= c_last) stage(c + (STAGES - 1) * GROUPS, lds + nxt * BUF);
     if (c <= c_last) compute(lds + cur * BUF);
-    cur ^= 1;
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
   if (GROUPS == 2) {
-    // group 1 -> group 0, three taps (48 floats per thread, 48 KB) per round through group 0's buffers; element (t, e) of
+    // group 1 -> group 0, three taps (48 floats per thread, 48 KB) per round through group 0's stages; element (t, e) of
     // thread tid at float (16 t + e) 256 + tid: conflict-free for writer and reader
     float* const xch = reinterpret_cast<float*>(lds_all);
 #pragma unroll

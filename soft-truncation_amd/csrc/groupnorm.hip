@@ -492,167 +492,6 @@ __global__ __launch_bounds__(1024) void gn_bwd_flat_kernel(GnArgs a, const float
   }
 }
 
-// ---- backward that writes its input gradient AS PLANES (round 5) --------------------------------------------------------
-// Conv_0 -> (+ temb) -> GroupNorm_1 (ResnetBlockBigGANpp, layerspp.py:273-278): the gradient this kernel computes IS Conv_0's output
-// gradient, nobody else reads it, and Conv_0's backward reads it as fp16 planes only.  The flat kernel above wrote it as fp32
-// (4 B per element) for a split pass to read (4) and write as planes (4); here the planes are written directly and the fp32 tensor
-// and the pass disappear.  Two things stood in the way:
-//   * the scale of the planes must be known before the first value is written.  It is derived a priori, per launch, from records
-//     earlier kernels leave behind: with D_n = max |dy| of image n (the producing data-gradient GEMM's epilogue,
-//     stk_conv2d_dgrad_pl_max_f32), r_ng = rstd and X_ng = max |xhat| of group (n, g) (the forward, stk_gn_fwd_pl_rec_f32),
-//     Gamma = max |gamma|, S = the largest slope of the activation and K = the dropout scale,
-//         |dx| = rstd |gamma du - m1 - xhat m2| <= r_ng Gamma S K D_n (2 + X_ng)      (|m1|, |m2| <= Gamma max|du|: mean |xhat| <= 1)
-//     and the record is the maximum of that over the groups of all images -- a bound within a small factor of the true maximum (measured 4-12x;
-//     GroupNorm's forward planes live with sqrt(L - 1) / max |xhat| ~ 13x), every workgroup computes the same value;
-//   * a workgroup of the flat kernel owns one group = 4 or 8 channels, i.e. 8 or 16 bytes of every 64-byte plane row.  Rows written
-//     in 16-byte pieces by four workgroups reach HBM at full speed when those workgroups share an XCD (their pieces merge in its L2),
-//     8-byte pieces do not (profiles/r05_partial_row_writes.txt: 3.43 / 1.79 TB/s against 3.44 for whole rows; 1.43 / 0.70 with the
-//     four on different XCDs).  So a workgroup here owns EIGHT channels (one or two groups) of one image, and block ids b, b + 8,
-//     b + 16, b + 24 -- the same XCD under the round-robin dispatch -- hold the four pieces of the same rows.
-// The values pass through LDS once for the transposition [channel][pixel] -> [pixel][8 channels].  By-products as in the flat kernel:
-// per-(sample, channel) sums of the final values (bias / time-embedding gradients), the partial sums of dgamma / dbeta in `ws`,
-// and the TRUE per-image maxima (amax_true, diagnostics: Executor.dynamic_range_report, tests).
-struct GnBwdPl {
-  const float* dymax; const float* gnrec; unsigned char* planes; long plane_stride; float* rec; float* amax_true;
-  float* sum; float* temb; int temb_stride; float scale; float slope;
-};
-
-template <int CPG, int IPT>
-__global__ __launch_bounds__(2048 / IPT) void gn_bwd_pl_kernel(GnArgs a, const float* __restrict__ dy, const float* __restrict__ mean_in,
-                                                        const float* __restrict__ rstd_in, float* __restrict__ ws, int hw_log2,
-                                                        GnBwdPl o) {
-  constexpr int GPW = 8 / CPG;                       // groups per workgroup
-  extern __shared__ float s_t[];                     // [8][HW] transposition buffer
-  __shared__ float s_part[2 * 8 * 4], s_ch[16], s_g[2 * GPW], s_red[32], s_sum[8 * 4], s_mx[16];
-  const int T = blockDim.x;                          // 2 HW / IPT threads, IPT float4 items each
-  const int C = a.C1, Cb = C >> 5;
-  // block id -> (row set = (image, 32-channel block), 16-byte piece): ids 8 apart share a row set
-  const int super = blockIdx.x >> 5, r32 = blockIdx.x & 31;
-  const int piece = r32 >> 3, rs = super * 8 + (r32 & 7);
-  if (rs >= a.N * Cb) return;                        // (whole workgroup)
-  const int n = rs / Cb, cb = rs - n * Cb;
-  const int c0 = cb * 32 + piece * 8;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  unsigned long long seed = a.seed;
-  if (a.drop_p > 0.f && a.seed_dev) seed += *a.seed_dev;
-  const int spc = a.HW >> 8;                         // waves (of 64 float4) per channel: 4 (32x32) or 1 (16x16)
-
-  // ---- the a-priori bound of this launch's |dx| (see above); identical in every workgroup
-  float bnd = 0.f, gmax = 0.f;
-  for (int i = threadIdx.x; i < a.N * a.G; i += T) bnd = fmaxf(bnd, rstd_in[i] * (2.f + o.gnrec[i]) * o.dymax[(i / a.G) & 255]);
-  for (int c = threadIdx.x; c < C; c += T) gmax = fmaxf(gmax, fabsf(a.gamma[c]));
-
-  float du[IPT][4], xh[IPT][4], gam[IPT];
-#pragma unroll
-  for (int k = 0; k < IPT; ++k) {
-    const int i = threadIdx.x + T * k;               // float4 item of the [8][HW] block
-    const int e = 4 * i;
-    const int cl = e >> hw_log2, off = e & (a.HW - 1);
-    const int c = c0 + cl;
-    const int g = c / CPG;
-    const float mean = mean_in[n * a.G + g], rstd = rstd_in[n * a.G + g];
-    const unsigned long long flat = ((((unsigned long long)n * C + c)) << hw_log2) + off;
-    const float4 xv = *reinterpret_cast<const float4*>(a.x1 + flat);
-    const float4 dv = *reinterpret_cast<const float4*>(dy + flat);
-    const float ga = a.gamma[c], be = a.beta[c];
-    gam[k] = ga;
-    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
-    float cs0 = 0.f, cs1 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      du[k][j] = gn_du(a, xs[j], ds[j], mean, rstd, ga, be, seed, flat + j, xh[k][j]);
-      cs0 += du[k][j];
-      cs1 += du[k][j] * xh[k][j];
-    }
-    cs0 = wave_sum(cs0); cs1 = wave_sum(cs1);        // a wave lies inside one channel (HW / 4 >= 64 items per channel)
-    if (lane == 0) { s_part[2 * (i >> 6)] = cs0; s_part[2 * (i >> 6) + 1] = cs1; }
-  }
-  bnd = wave_max(bnd); gmax = wave_max(gmax);
-  if (lane == 0) { s_red[wid] = bnd; s_red[16 + wid] = gmax; }
-  __syncthreads();
-  if (threadIdx.x < 8) {                             // per-channel totals, in slot order
-    const int cl = threadIdx.x;
-    float t0 = 0.f, t1 = 0.f;
-    for (int q = 0; q < spc; ++q) { t0 += s_part[2 * (cl * spc + q)]; t1 += s_part[2 * (cl * spc + q) + 1]; }
-    s_ch[2 * cl] = t0; s_ch[2 * cl + 1] = t1;
-    ws[((long)n * C + c0 + cl) * 2 + 0] = t0;
-    ws[((long)n * C + c0 + cl) * 2 + 1] = t1;
-  }
-  __syncthreads();
-  if (threadIdx.x < GPW) {
-    float g0 = 0.f, g1 = 0.f;
-    for (int cl = threadIdx.x * CPG; cl < (threadIdx.x + 1) * CPG; ++cl) {
-      const float ga = a.gamma[c0 + cl];
-      g0 += ga * s_ch[2 * cl]; g1 += ga * s_ch[2 * cl + 1];
-    }
-    const float inv_l = 1.f / ((float)CPG * (float)a.HW);
-    s_g[2 * threadIdx.x] = g0 * inv_l; s_g[2 * threadIdx.x + 1] = g1 * inv_l;
-  }
-  __syncthreads();
-  const int nw = T >> 6;
-  float bound = 0.f, gm = 0.f;
-  for (int w = 0; w < nw; ++w) { bound = fmaxf(bound, s_red[w]); gm = fmaxf(gm, s_red[16 + w]); }
-  bound = bound * gm * o.slope * a.keep_scale * 1.001f;
-  // the power of two that puts the bound in [2^13, 2^14) (x2::pow2_scale_of in conv_x2.h)
-  float sc = 1.f;
-  {
-    const int be = (int)((__float_as_uint(bound) >> 23) & 0xffu);
-    if (be != 0) sc = __uint_as_float((unsigned)min(max(127 + 13 - (be - 127), 1), 254) << 23);
-  }
-  if (blockIdx.x == 0) for (int i = threadIdx.x; i < 256; i += T) o.rec[i] = i == 0 ? bound : 0.f;
-
-  float amax_l = 0.f;
-#pragma unroll
-  for (int k = 0; k < IPT; ++k) {
-    const int i = threadIdx.x + T * k;
-    const int e = 4 * i;
-    const int cl = e >> hw_log2, off = e & (a.HW - 1);
-    const int gi = cl / CPG;
-    const float rstd = rstd_in[n * a.G + (c0 + cl) / CPG];
-    const float m1 = s_g[2 * gi], m2 = s_g[2 * gi + 1];
-    float r[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = rstd * (du[k][j] * gam[k] - m1 - xh[k][j] * m2);
-    amax_l = fmaxf(amax_l, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
-    const float rs4 = wave_sum((r[0] + r[1]) + (r[2] + r[3]));
-    if (lane == 0) s_sum[i >> 6] = rs4;
-    *reinterpret_cast<float4*>(s_t + (cl << hw_log2) + off) = make_float4(r[0], r[1], r[2], r[3]);
-  }
-  amax_l = wave_max(amax_l);
-  if (lane == 0) s_mx[wid] = amax_l;                 // (not s_red: another wave may still be reading the bound's partials)
-  __syncthreads();
-  if (threadIdx.x < 8) {
-    const int cl = threadIdx.x;
-    float t = 0.f;
-    for (int q = 0; q < spc; ++q) t += s_sum[cl * spc + q];
-    t *= o.scale;
-    if (o.sum) { o.sum[((long)n * C + c0 + cl) * 2] = t; o.sum[((long)n * C + c0 + cl) * 2 + 1] = t; }
-    if (o.temb) o.temb[(long)n * o.temb_stride + c0 + cl] = t;
-  }
-  if (o.amax_true && threadIdx.x == 0) {
-    float m = 0.f;
-    for (int w = 0; w < nw; ++w) m = fmaxf(m, s_mx[w]);
-    atomicMax(reinterpret_cast<unsigned*>(o.amax_true) + (blockIdx.x & 255), __float_as_uint(m));
-  }
-  // ---- [8 channels][pixel] -> [pixel][8 channels] as two 16-byte pieces (hi, lo) per pixel
-  unsigned char* const prow = o.planes + ((long)rs * a.HW) * 64 + piece * 16;
-  for (int px = threadIdx.x; px < a.HW; px += T) {
-    unsigned hi[4], lo[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float v0 = sc * s_t[((2 * j) << hw_log2) + px], v1 = sc * s_t[((2 * j + 1) << hw_log2) + px];
-      const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-      const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
-      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-      hi[j] = __builtin_bit_cast(unsigned, h2{h0, h1});
-      lo[j] = __builtin_bit_cast(unsigned, h2{l0, l1});
-    }
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    *reinterpret_cast<u4*>(prow + (long)px * 64) = u4{hi[0], hi[1], hi[2], hi[3]};
-    *reinterpret_cast<u4*>(prow + o.plane_stride + (long)px * 64) = u4{lo[0], lo[1], lo[2], lo[3]};
-  }
-}
-
 // ---- large groups: one (sample, group) split over many workgroups -------------------------------------------
 // A 256x256 map at batch 4 has only N*G = 128 groups of 1 MB each: one workgroup per group leaves half the chip
 // idle and streams each group serially (measured 689 us for a 134 MB backward).  Here a workgroup owns one CHUNK
@@ -1053,15 +892,8 @@ __global__ __launch_bounds__(1024) void gn_fwd_pl_kernel(GnArgs a, float* __rest
 // pl::split_planes_kernel -- a workgroup per (sample, 32-channel block, 128-pixel tile), all element-wise work done on
 // the float4 (four consecutive pixels of one channel = one dropout RNG quad) before the tile goes through LDS for the
 // transposition to [pixel][32 channels].  x is read twice, the second time out of the Infinity Cache.
-// gnrec (REC; stk_gn_fwd_pl_rec_f32): gnrec[n G + g] = max |xhat| of the group (times 1.0001), a plain store per workgroup.  (The
-// first version kept per-image maxima by atomic maximum: the 32 workgroups of an image hit one address at the same time and the
-// kernel ran 13.4 -> 26.7 us.)  The backward that writes the planes of its input gradient itself (gn_bwd_pl_kernel) derives their
-// scale from these and from rstd.
-// (REC is a template parameter: with the branch inside the streaming loop every launch of the kernel ran 13.3 -> 21.0 us)
-template <bool REC>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a, float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                       float eps, float sqrt_lm1, float* __restrict__ rec,
-                                                       float* __restrict__ gnrec) {
+                                                       float eps, float sqrt_lm1, float* __restrict__ rec) {
   __shared__ float red[16];
   const int ng = blockIdx.x;
   const int n = ng / a.G, g = ng - n * a.G;
@@ -1072,16 +904,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a, float* __restri
   const float shift = p[0];
   const float4* p4 = reinterpret_cast<const float4*>(p);
   float s[2] = {0.f, 0.f};
-  float dmax = 0.f, dmin = 0.f;                          // extremes of x - shift (0 is among them: the group's first element)
   for (int i = threadIdx.x; i < L4; i += 256) {
     const float4 v = p4[i];
     const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
     s[0] += (d0 + d1) + (d2 + d3);
     s[1] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    if (REC) {
-      dmax = fmaxf(dmax, fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)));
-      dmin = fminf(dmin, fminf(fminf(d0, d1), fminf(d2, d3)));
-    }
   }
   block_sum<2>(s, red);
   const float inv_l = 1.f / (float)L;
@@ -1091,18 +918,6 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a, float* __restri
   if (threadIdx.x == 0) {
     mean_out[ng] = shift + md;
     rstd_out[ng] = rstd_v;
-  }
-  if (REC) {
-    dmax = wave_max(dmax);
-    dmin = -wave_max(-dmin);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = dmax; red[4 + (threadIdx.x >> 6)] = dmin; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const float hi = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), lo = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
-      // max |x - mean| = max(hi - md, md - lo): x - mean = (x - shift) - md
-      gnrec[ng] = fmaxf(hi - md, md - lo) * rstd_v * 1.0001f;
-    }
-    __syncthreads();
   }
   if (rec && ng == 0) {                                  // the planes' scale record: a-priori bound of |y| (gn_bound_kernel)
     const int C = a.C1 + a.C2;
@@ -1294,7 +1109,7 @@ int stk_gn_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float
 static int gn_fwd_pl_impl(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
                           void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
                           float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream,
-                          float* xmax1, float* xmax2, float* gnrec = nullptr);
+                          float* xmax1, float* xmax2);
 
 int stk_gn_fwd_pl_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
                       void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
@@ -1314,27 +1129,10 @@ int stk_gn_fwd_pl_max_f32(const float* x1, int C1, const float* x2, int C2, cons
                         stream, xmax1, xmax2);
 }
 
-/* shapes whose forward can leave the records the plane-writing backward needs: the two-kernel route with one workgroup per group */
-static inline bool gn_fwd_rec_shape(int C1, int C2, int HW, int G) {
-  return gn_pl_2k_ok(C1, C2, HW, G) && (long)((C1 + C2) / G) * HW <= 16384;
-}
-
-/* stk_gn_fwd_pl_max_f32 (xmax1 / xmax2 may be NULL here) that also leaves gnrec[N G] behind: max |xhat| of every (image, group) --
- * what stk_gn_bwd_pl_f32 derives the scale of its planes from (with rstd). */
-int stk_gn_fwd_pl_rec_f32(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
-                          void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
-                          float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws,
-                          float* xmax1, float* xmax2, float* gnrec, void* stream) {
-  if (!gnrec || (xmax2 && !xmax1) || !gn_fwd_rec_shape(C1, C2, HW, G)) return STK_EINVAL;
-  return gn_fwd_pl_impl(x1, C1, x2, C2, gamma, beta, y, planes, rec, mean, rstd, N, HW, G, eps, act, drop_p, seed, seed_dev, ws,
-                        stream, xmax1, xmax2, gnrec);
-}
-int stk_gn_fwd_rec_ok(int C1, int C2, int HW, int G) { return gn_fwd_rec_shape(C1, C2, HW, G) ? 1 : 0; }
-
 static int gn_fwd_pl_impl(const float* x1, int C1, const float* x2, int C2, const float* gamma, const float* beta, float* y,
                           void* planes, float* rec, float* mean, float* rstd, int N, int HW, int G, float eps, int act,
                           float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream,
-                          float* xmax1, float* xmax2, float* gnrec) {
+                          float* xmax1, float* xmax2) {
   const int C = C1 + C2;
   if (!x1 || !gamma || !beta || !planes || !rec || !mean || !rstd || N <= 0 || HW <= 0 || G <= 0 || C1 <= 0 || C2 < 0 ||
       C % G || (C2 > 0 && !x2) || drop_p < 0.f || drop_p >= 1.f || act < 0 || act > STK_ACT_ELU)
@@ -1349,8 +1147,7 @@ static int gn_fwd_pl_impl(const float* x1, int C1, const float* x2, int C2, cons
     const float sq = sqrtf((float)((long)a.cpg * HW) - 1.f);
     hipStream_t s = (hipStream_t)stream;
     if ((long)a.cpg * HW <= 16384) {
-      if (gnrec) hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(N * G), dim3(256), 0, s, a, mean, rstd, eps, sq, rec, gnrec);
-      else hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(N * G), dim3(256), 0, s, a, mean, rstd, eps, sq, rec, gnrec);
+      hipLaunchKernelGGL(gn_stats_kernel, dim3(N * G), dim3(256), 0, s, a, mean, rstd, eps, sq, rec);
     } else {
       if (!ws) return STK_EINVAL;
       const int Sc = HW / GN_CHUNK;
@@ -1492,46 +1289,6 @@ static int gn_bwd_impl(const float* dy, const float* x1, int C1, const float* x2
                        dbeta, N, C, (const StkGnFoldDesc*)nullptr);
     STK_CHECK_LAUNCH();
   }
-  return STK_OK;
-}
-
-/* shapes of stk_gn_bwd_pl_f32: one source, 4 or 8 channels per group in whole 32-channel blocks, 16x16 or 32x32 maps */
-int stk_gn_bwd_pl_ok(int C, int HW, int G) {
-  if (C <= 0 || G <= 0 || C % G || C % 32) return 0;
-  const int cpg = C / G;
-  return (cpg == 4 || cpg == 8) && (HW == 256 || HW == 1024) ? 1 : 0;
-}
-
-int stk_gn_bwd_pl_f32(const float* dy, const float* x, int C, const float* gamma, const float* beta, const float* mean,
-                      const float* rstd, float* ws, int N, int HW, int G, int act, float drop_p, unsigned long long seed,
-                      const unsigned long long* seed_dev, float* dx_sum, float out_scale, float* dtemb, int temb_stride,
-                      const float* dymax, const float* gnrec, void* planes, float* rec, float* amax_true, void* stream) {
-  if (!dy || !x || !gamma || !beta || !mean || !rstd || !ws || !dymax || !gnrec || !planes || !rec || N <= 0 ||
-      drop_p < 0.f || drop_p >= 1.f || act < 0 || act > STK_ACT_ELU || (dtemb && temb_stride < C))
-    return STK_EINVAL;
-  if (!stk_gn_bwd_pl_ok(C, HW, G) || !stk_aligned16(dy) || !stk_aligned16(x) || !stk_aligned16(planes)) return STK_EUNSUPPORTED;
-  const long plane_stride = (long)N * (C / 32) * HW * 64;
-  if (2 * plane_stride >= 0x7fffffffL) return STK_EUNSUPPORTED;
-  GnArgs a;
-  a.x1 = x; a.x2 = nullptr; a.C1 = C; a.C2 = 0; a.gamma = gamma; a.beta = beta;
-  a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p); a.drop_thr = stk_drop_threshold(drop_p);
-  a.seed = seed; a.seed_dev = seed_dev;
-  GnBwdPl o;
-  o.dymax = dymax; o.gnrec = gnrec; o.planes = static_cast<unsigned char*>(planes); o.plane_stride = plane_stride; o.rec = rec;
-  o.amax_true = amax_true; o.sum = dx_sum; o.temb = dtemb; o.temb_stride = temb_stride; o.scale = out_scale;
-  o.slope = act == STK_ACT_SILU ? 1.0999f : 1.f;        // max of sigma(u) (1 + u (1 - sigma(u))) = 1.09984; ReLU / LeakyReLU / ELU: 1
-  const int hw_log2 = HW == 1024 ? 10 : 8;
-  const long rsets = (long)N * (C / 32);
-  const dim3 grid((unsigned)(stk_cdiv(rsets, 8L) * 32));
-  const size_t lds = (size_t)8 * HW * 4;
-  // STK_GN_BWD_PL_IPT (A/B): float4 items per thread, 4 (512 / 128 threads per workgroup) or 2 (1024 / 256)
-  static const int ipt = [] { const char* e = getenv("STK_GN_BWD_PL_IPT"); return e && atoi(e) == 2 ? 2 : 4; }();
-#define STK_GN_BWD_PL(CPG, IPT)                                                                                   \
-  hipLaunchKernelGGL((gn_bwd_pl_kernel<CPG, IPT>), grid, dim3(2 * HW / IPT), lds, (hipStream_t)stream, a, dy, mean, rstd, ws, hw_log2, o)
-  if (a.cpg == 4) { if (ipt == 2) STK_GN_BWD_PL(4, 2); else STK_GN_BWD_PL(4, 4); }
-  else { if (ipt == 2) STK_GN_BWD_PL(8, 2); else STK_GN_BWD_PL(8, 4); }
-#undef STK_GN_BWD_PL
-  STK_CHECK_LAUNCH();
   return STK_OK;
 }
 

@@ -232,11 +232,27 @@ def _spin_cycles(device, ms):
   return int(per_ms * ms)
 
 
-def collective_runs_beside(busy, device, group=None, numel=8 << 20, spin_ms=40.0):
+def collective_runs_beside(busy, device, group=None, numel=8 << 20, spin_ms=40.0, trials=2):
   """True when a collective of the process group completes WHILE `busy` (a torch stream) is occupied by a spin kernel, i.e.
   the communicator's stream is served by another hardware queue.  Every rank of the group must call this together (the probe
   is an all-gather of `numel` floats -- with one rank RCCL turns it into a device copy on the communicator's stream, with
-  several into its usual kernels).  Returns (beside, seconds the collective took to complete, spin seconds)."""
+  several into its usual kernels).  Returns (beside, seconds the collective took to complete, spin seconds).
+
+  With several ranks the collective completes only after the SLOWEST peer has issued it, so rank skew longer than the spin
+  reads as "not beside" (the other error, a false "beside", cannot happen: a collective on the busy stream's queue never
+  finishes before the spin).  Hence: the ranks meet at a barrier right before the timed section, the spin grows with the world
+  size, and a "not beside" verdict is re-tried (`trials`; the verdict is the best one -- every rank runs every trial, so the
+  collectives stay matched)."""
+  ws = dist.get_world_size(group)
+  best = None
+  for _ in range(max(1, trials) if ws > 1 else 1):
+    r = _collective_runs_beside_once(busy, device, group, numel, spin_ms * (1.0 + 0.25 * (ws - 1)))
+    if best is None or (r[0] and not best[0]):
+      best = r
+  return best
+
+
+def _collective_runs_beside_once(busy, device, group, numel, spin_ms):
   import time
   from .executor import _overlap_ratio
   ws = dist.get_world_size(group)
@@ -254,6 +270,9 @@ def collective_runs_beside(busy, device, group=None, numel=8 << 20, spin_ms=40.0
     dist.all_gather_into_tensor(dst, src, group=group)
   torch.cuda.synchronize(device)
   cycles = _spin_cycles(device, spin_ms)
+  if ws > 1:                                # calibration and stream search differ per rank: start the timed section together
+    dist.barrier(group=group)
+    torch.cuda.synchronize(device)
   spin_done, coll_done = torch.cuda.Event(), torch.cuda.Event()
   with torch.cuda.stream(busy):
     torch.cuda._sleep(cycles)
@@ -328,12 +347,17 @@ def init_with_overlapping_exchange(init_fn, device, tries=3):
   """init_fn() -> creates the default process group (dist.init_process_group(...), same call on every rank).  Steers torch's
   stream pool so that the communicator's stream lands on a hardware queue of its own (_steer_stream_pool), creates the group
   and probes it; while some rank still reports a shared queue the group is destroyed and the procedure repeated.  Returns
-  the last report with the number of attempts."""
+  the last report with the number of attempts.
+
+  init_fn is called up to `tries` times: it must be able to rendezvous again after a destroy_process_group() -- with
+  env:// / tcp:// and a fixed MASTER_PORT the second bind can fail while the first store's socket lingers, so give every call
+  a fresh port (bench.py: free_port()) or a file:// store.  A fresh group also clears a poisoned exchange (reset_poison)."""
   from .executor import checked_side_stream
   report = None
   for attempt in range(1, tries + 1):
     steered = _steer_stream_pool(device, torch.cuda.current_stream(device), checked_side_stream(device))
     init_fn()
+    reset_poison()                          # whatever was in flight belonged to a group that no longer exists
     report = check_exchange_stream(device)
     report['attempts'] = attempt
     report['pool_steered'] = bool(steered)

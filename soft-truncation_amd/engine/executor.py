@@ -121,6 +121,27 @@ def _launch_window(active):
 
 
 _SIDE_STREAMS = {}     # (device index, launch stream handle) -> (side stream, overlap ratio, checked)
+# STK_SIDE_CUS=N (round 6 experiment): the side stream is created with a CU mask of N compute units (hipExtStreamCreateWithCUMask;
+# the mask's bits go round the XCDs, so the first N bits are N / 8 CUs of every XCD): the weight gradients then occupy a fixed
+# part of the chip instead of a slice of every CU.  0 = no mask (a pooled torch stream).
+_SIDE_CUS = int(os.environ.get('STK_SIDE_CUS', '0') or 0)
+_MASKED = []           # keeps the masked streams alive
+
+
+def _masked_stream(dev, n_cus):
+  hip = ctypes.CDLL('libamdhip64.so')
+  words = (n_cus + 31) // 32
+  mask = (ctypes.c_uint32 * max(words, 1))()
+  for i in range(n_cus):
+    mask[i // 32] |= 1 << (i % 32)
+  handle = ctypes.c_void_p()
+  with torch.cuda.device(dev):
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask)
+  if rc != 0 or not handle.value:
+    raise RuntimeError(f'hipExtStreamCreateWithCUMask({n_cus} CUs) failed: {rc}')
+  st = torch.cuda.ExternalStream(handle.value, device=dev)
+  _MASKED.append(st)
+  return st
 
 
 def _overlap_ratio(main, cand, cycles=400000):
@@ -169,7 +190,7 @@ def checked_side_stream(device):
   check = want_check and not capturing
   best, best_ratio = (hit[0], 1e9) if (hit is not None and not check) else (None, 1e9)
   for _ in range(8 if check else (0 if best is not None else 1)):
-    cand = torch.cuda.Stream(dev)
+    cand = _masked_stream(dev, _SIDE_CUS) if _SIDE_CUS > 0 else torch.cuda.Stream(dev)
     ratio = _overlap_ratio(main, cand) if check else 0.0
     if ratio < best_ratio:
       best, best_ratio = cand, ratio
@@ -497,7 +518,11 @@ class Executor:
       prog.wp_dgrad_ready = self._side.end()
       self._side.last = None              # not a join target of the backward's fork / join: the event is waited for explicitly
     else:
-      prog.wp_dgrad_ready = None
+      if need_dgrad:
+        # the data-gradient blocks are rewritten on the launch stream right here: a pending side-stream preparation is superseded.
+        # A forward that prepares the forward blocks only (no_grad, frozen weights) must NOT drop the event: an earlier training
+        # forward of this program may still be waiting for its backward, whose data gradients read those blocks
+        prog.wp_dgrad_ready = None
       self.lib.conv2d_wprep_batch(prog.wp_table.data_ptr(), n, prog.wp_items, stk_lib.stream_ptr(dev))
     prog.wp_frozen = n if self._frozen else 0
 
@@ -609,8 +634,7 @@ class Executor:
       seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     c.uses += 1
     done = False
-    eager_fwd = with_backward and self.use_side and os.environ.get('STK_FWD_SIDE', '0') == '1'
-    if self._graphs_on() and c.uses > 1 and not eager_fwd:          # first use of a context runs eagerly (warm-up)
+    if self._graphs_on() and c.uses > 1:          # first use of a context runs eagerly (warm-up)
       if c.seed_t is None:
         c.seed_t = torch.zeros(1, dtype=torch.int64, device=flat.device)
       if c.gact is None and torch.is_grad_enabled():
@@ -622,9 +646,7 @@ class Executor:
     if not done:
       rt = self._runtime(c, training, seed, None, with_backward)
       for op in g.ops:
-        rt.guard_fwd(op)
         op.forward(rt)
-      rt.join_side()
       c.rt = rt
     o = g.output
     out = c.act[o.off:o.off + o.numel].view(o.shape).clone()
@@ -639,7 +661,7 @@ class Executor:
     rt.param_grads = param_grads
     flat = self.flat
     self._awaiting.discard(c)
-    self._last_ctx = c              # dynamic_range_report reads its records (they live until the context's next backward)
+    self._last_ctx = weakref.ref(c)  # dynamic_range_report reads its gradient arena (valid until the context's next backward); weak: the report must not keep a released context alive
     if c.gact is None:
       c.gact = _arena(g.gact_size, prog.device)
     o = g.output
@@ -741,24 +763,34 @@ class Executor:
     maxima by atomic maximum made the 32 workgroups of an image hit one address at once and cost the GroupNorm backward 20-60 %.
     Returns [(layer, max over images, smallest non-zero image maximum, decades between them)] for the 3x3 convolutions whose
     output gradient exists as fp32, worst first.  Synchronises."""
-    c = getattr(self, '_last_ctx', None)
+    ref = getattr(self, '_last_ctx', None)
+    c = ref() if ref is not None else None
     if c is None or c.gact is None:
       return []
     g = c.prog.graph
-    rows = []
+    names, his, los = [], [], []
     with torch.no_grad():
       for op in g.ops:
-        if not isinstance(op, Conv) or op.KH != 3 or not (op.pl_dgrad or op.pl_wgrad) or op.dy_pl_from is not None:
+        if not isinstance(op, Conv) or op.KH != 3 or not (op.pl_dgrad or op.pl_wgrad):
           continue
         t = op.y
-        if not t.needs_grad or t.goff is None:
+        if not t.needs_grad or t.goff is None or op.N < 2:
           continue
         per = c.gact[t.goff:t.goff + t.numel].view(op.N, -1).abs().amax(dim=1)
-        per = per[torch.isfinite(per) & (per > 0)]
-        if per.numel() < 2:
-          continue
-        hi, lo = float(per.max()), float(per.min())
-        rows.append((t.name, hi, lo, float(np.log10(hi / lo))))
+        ok = torch.isfinite(per) & (per > 0)
+        # hi / lo stay on the device: ONE transfer for all layers below (a .max() / .min() pair per layer was two host syncs
+        # per convolution)
+        his.append(torch.where(ok, per, torch.zeros_like(per)).max())
+        los.append(torch.where(ok, per, torch.full_like(per, float('inf'))).min())
+        names.append((t.name, ok.sum()))
+      if not names:
+        return []
+      table = torch.stack([torch.stack(his), torch.stack(los), torch.stack([n for _, n in names]).to(his[0].dtype)]).cpu()
+    rows = []
+    for i, (name, _) in enumerate(names):
+      hi, lo, n = float(table[0, i]), float(table[1, i]), int(table[2, i])
+      if n >= 2 and lo > 0 and np.isfinite(lo):
+        rows.append((name, hi, lo, float(np.log10(hi / lo))))
     rows.sort(key=lambda r: -r[3])
     return rows
 

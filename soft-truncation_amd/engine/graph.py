@@ -27,7 +27,6 @@ SQRT2 = float(np.float32(np.sqrt(2.)))
 # step on five boxes: profiles/r05_insitu_sweeps.txt)
 _SIDE_SHORTCUT = os.environ.get('STK_SIDE_SHORTCUT', '0') != '0'
 _SIDE_WGRAD1 = os.environ.get('STK_SIDE_WGRAD1', '1') != '0'
-_SIDE_FWD = os.environ.get('STK_FWD_SIDE', '0') == '1'     # shortcut convolutions of an (eagerly launched) forward on the side stream
 # Workgroups of a weight gradient launched on the MAIN stream (one-stream mode, the profiler's eager steps), 0 = the same count as on the side
 # stream.  512 (two per CU) is the faster setting for a kernel that has the chip to itself, but a different K split sums its slabs in a
 # different order, and the one-stream backward is the bit-for-bit reference of the two-stream one (tests/test_gpu_model.py::
@@ -38,15 +37,8 @@ _SIDE_DELAY = int(os.environ.get('STK_SIDE_DELAY', '0'))
 _SIDE_DELAY_FILTER = None
 _SIDE_FAKE = False
 _ALIGN = 64  # floats (256 B) -- keeps every buffer float4-aligned
-# A convolution's record buffer: five 256-float records -- |x1|, |x2|, |dy| (the scale records of include/stk.h "amax"), and (round 5)
-# max |dx| per image left by its data gradient (stk_conv2d_dgrad_pl_max_f32) and the TRUE max |dy| per image where [2] holds an
-# a-priori bound (stk_gn_bwd_pl_f32)
-AMAX = 1280
-# OFF by default (STK_DY_PLANES=1 switches it on): measured inside the training step (profiles/r05_dy_planes.txt) the plane-writing
-# GroupNorm backward takes 61 us where the fp32-writing one takes 43 (its 16-byte pieces of a row come from four workgroups that
-# reach their store phases microseconds apart, so the rows no longer merge in L2 the way they do in the lock-step probe), which eats
-# the 19.7 us of the split pass it removes: 38.21-38.26 -> 38.29-38.48 ms per step.
-STK_DY_PLANES = os.environ.get('STK_DY_PLANES', '0') == '1'
+# A convolution's record buffer: three 256-float scale records -- |x1|, |x2|, |dy| (include/stk.h "amax")
+AMAX = 768
 
 
 def _round_up(n, a=_ALIGN):
@@ -152,31 +144,6 @@ class Runtime:
     for t in writes:
       if t is not None:
         self.pending[id(t)] = ev
-
-  def run_on_side_fwd(self, outputs, fn):
-    """Forward counterpart of run_on_side: `outputs` = the activation tensors whose VALUES fn writes."""
-    side = self.side
-    s = side.begin()
-    saved = (self.stream, self.ws)
-    self.stream, self.ws, self.side = s, self.ws2, None
-    try:
-      fn()
-    finally:
-      self.stream, self.ws = saved
-      self.side = side
-    ev = side.end()
-    for t in outputs:
-      self.pending[('v', id(t))] = ev
-
-  def guard_fwd(self, op):
-    """Before op.forward on the main stream: wait for side-stream work that wrote a tensor this op reads."""
-    if not self.pending:
-      return
-    for v in vars(op).values():
-      if isinstance(v, Tensor):
-        ev = self.pending.pop(('v', id(v)), None)
-        if ev is not None:
-          self.side.main_waits(ev)
 
   def guard(self, op):
     """Called before op.backward on the main stream: wait for side-stream work that wrote a gradient this op reads or
@@ -308,13 +275,6 @@ class GroupNormAct(Op):
     # Graph._plan_x_records: the block's 1x1 shortcut convolution reads this layer's SOURCE tensors as fp32 operands of the
     # split kernels; the one-pass forward leaves their |x| scale records in that convolution's amax buffer
     self.xmax_for = None
-    # Graph._plan_dy_planes (round 5): this layer normalises the output of convolution `pl_bwd` and nobody else reads it: its
-    # backward writes that convolution's dy PLANES itself (stk_gn_bwd_pl_f32) -- no fp32 gradient, no split pass.  `dx_src` = the
-    # convolution whose data gradient produces this layer's dy (it leaves max |dy| per image), `gnrec` = this layer's forward
-    # record (max |xhat| per image and group)
-    self.pl_bwd = None
-    self.dx_src = None
-    self.gnrec = None
 
   def _p(self, rt):
     return self.drop_p if rt.training else 0.0
@@ -328,14 +288,6 @@ class GroupNormAct(Op):
       # The fp32 copy is written only if somebody reads it (the fused shapes accept y = NULL).
       need_f32 = y.f32_fwd or (rt.with_backward and y.f32_bwd) or not self.fused
       cv = self.xmax_for
-      if self.pl_bwd is not None:
-        rt.lib.gn_fwd_pl_rec_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
-                                 rt.v(y) if need_f32 else None, rt.planes(y), rt.rec(y), rt.v(self.mean), rt.v(self.rstd),
-                                 self.N, self.HW, self.G, self.eps, self.act, self._p(rt), seed, rt.seed_dev, rt.ws,
-                                 rt.v(cv.amax) if cv is not None else None,
-                                 rt.v(cv.amax) + 4 * 256 if (cv is not None and self.x2 is not None) else None,
-                                 rt.v(self.gnrec), rt.stream)
-        return
       if cv is not None:
         rt.lib.gn_fwd_pl_max_f32(rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, rt.v(self.gamma), rt.v(self.beta_t),
                                  rt.v(y) if need_f32 else None, rt.planes(y), rt.rec(y), rt.v(self.mean), rt.v(self.rstd),
@@ -359,23 +311,6 @@ class GroupNormAct(Op):
       ws = rt.gnpart + 4 * self.fold_off
       rt.defer_fold(self.fold_index)
     adder = self.add_from
-    if self.pl_bwd is not None and rt.gn_table:
-      # the convolution before this layer takes its output gradient as planes and nothing else: written here, with the scale
-      # derived from the records of the data gradient that produced dy and of this layer's forward (include/stk.h)
-      dsum = dtemb = None
-      tstride = 0
-      if cons.bsum_index is not None and rt.param_grads:
-        dsum = rt.gnpart + 4 * cons.bsum_off
-        rt.defer_fold(cons.bsum_index)
-      if cons.temb is not None and cons.temb.needs_grad:
-        dtemb, tstride = rt.g(cons.temb) + 4 * cons.temb_col, cons.temb_stride
-      planes = rt.pl + cons.dypl_off if cons.dypl_off is not None else rt.dypl
-      rt.lib.gn_bwd_pl_f32(rt.g(self.y), rt.v(self.x1), self.C1, rt.v(self.gamma), rt.v(self.beta_t), rt.v(self.mean),
-                           rt.v(self.rstd), ws, self.N, self.HW, self.G, self.act, self._p(rt),
-                           (rt.seed + 0x9E3779B1 * self.op_id) & 0xFFFFFFFFFFFFFFFF, rt.seed_dev, dsum, 1.0 / cons.out_div, dtemb,
-                           tstride, rt.v(self.dx_src.amax) + 4 * 768, rt.v(self.gnrec), planes, rt.v(cons.amax) + 4 * 512,
-                           rt.v(cons.amax) + 4 * 1024, rt.stream)
-      return
     if cons is not None or adder is not None:
       dsum = dtemb = damax = add = None
       out_scale = add_scale = 1.0
@@ -437,7 +372,7 @@ class Conv(Op):
     # algorithmic FLOPs of one launch (1 MAC = 2 FLOP); identical for fwd, dgrad and wgrad
     self.flops = 2.0 * N * OH * OW * Cout * (C1 + C2) * KH * KW
 
-  _VARIANT = {0: 't64', 1: 't128', 2: 'x3', 3: 't128', 4: 'thin', 5: 'x2'}
+  _VARIANT = {0: 't64', 1: 't128', 3: 't128', 4: 'thin', 5: 'x2'}
 
   def _kind(self, lib, direction):
     """Kernel label for the profiler: direction, taps and the kernel family csrc/conv.hip picks for this shape
@@ -465,12 +400,9 @@ class Conv(Op):
       elif hasattr(lib, 'conv2d_pl_ksplit'):
         d = 0 if direction == 'fwd' else 1
         c2 = 0 if d == 0 else self.C2
-        t64 = hasattr(lib, 'conv2d_pl_tile') and int(lib.conv2d_pl_tile(d, self.C1, c2, self.N, self.H, self.W, self.Cout, self.KH, self.KW)) == 64
-        if t64:
-          k += '.t64'                # x2d::gemm_halo64_kernel (round 5): 64 x 64 tiles where the large ones would not fill the chip
         if int(lib.conv2d_pl_ksplit(d, self.C1, c2, self.N, self.H, self.W, self.Cout, self.KH, self.KW)) > 1:
           k += '.k'
-        elif not t64 and hasattr(lib, 'conv2d_pl_halo'):
+        elif hasattr(lib, 'conv2d_pl_halo'):
           hw = int(lib.conv2d_pl_halo(d, self.C1, c2, self.N, self.H, self.W, self.Cout, self.KH, self.KW))
           if hw:
             k += f'.h{hw}'
@@ -523,10 +455,6 @@ class Conv(Op):
   # DMA kernel instead of splitting the fp32 tensor again in its loader.  'own' = the peer keeps its dy planes (two streams),
   # 'scratch' = the context's shared scratch, still holding them when this layer's backward runs right after the peer's
   peer_planes = None
-  # Graph._plan_dy_planes: `dy_pl_from` = the GroupNorm whose backward writes this layer's dy planes (no split pass here);
-  # `dx_rec`: this layer's data gradient leaves max |dx1| per image in amax[768:1024) for such a GroupNorm
-  dy_pl_from = None
-  dx_rec = False
 
   # planes (include/stk.h "Planes"): decided by Graph.finalize
   dypl_off = None      # byte offset of this layer's own dy planes in the planes arena (side-stream weight gradients)
@@ -575,12 +503,6 @@ class Conv(Op):
       Op.plan_backward(self)
 
   def forward(self, rt):
-    if self.dy_from is not None and rt.side is not None and rt.prof is None and _SIDE_FWD:
-      # the block's 1x1 shortcut (HBM-bound) beside its first 3x3 convolution (matrix-pipe-bound); Conv_1 waits for it
-      return rt.run_on_side_fwd((self.y,), lambda: self._forward(rt))
-    return self._forward(rt)
-
-  def _forward(self, rt):
     temb = rt.v(self.temb) + 4 * self.temb_col if self.temb is not None else None
     if self.pl_fwd:
       t = self.x1
@@ -675,8 +597,7 @@ class Conv(Op):
       if not rec_done:
         lib.amax_partial_f32(gy, self.y.numel, rec, rt.stream)
       dypl = rt.pl + self.dypl_off if self.dypl_off is not None else rt.dypl
-      if not (self.dy_pl_from is not None and rt.gn_table):      # (else: the GroupNorm backward has written them already)
-        lib.split_planes_f32(gy, self.N, self.Cout, self.OH * self.OW, rec, 256, dypl, rt.stream)
+      lib.split_planes_f32(gy, self.N, self.Cout, self.OH * self.OW, rec, 256, dypl, rt.stream)
       have |= 2
     if src is not None and self.peer_planes is not None and (g1 is not None or g2 is not None):
       # the peer's dy planes (and the record they were scaled with) serve this 1x1 data gradient too
@@ -685,11 +606,6 @@ class Conv(Op):
                ppl, rt.v(self.amax) + 4 * 512, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
                g2, self.C2, self.b(self.x2) if self.x2 is not None else 0.0,
                alpha, self.N, self.H, self.W, self.Cout, self.KH, self.KW, self._wp(rt, 1), rt.ws, rt.ws_bytes, rt.stream)
-    elif pl_dgrad and self.dx_rec and rt.gn_table and g2 is None:
-      rt.timed(self._label_pl(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_pl_max_f32,
-               dypl, rec, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1), alpha, self.N, self.H, self.W, self.Cout,
-               self.KH, self.KW, self._wp(rt, 1), rt.ws, rt.ws_bytes, rt.v(self.amax) + 4 * 768, rt.stream)
-      have |= 2
     elif pl_dgrad:
       rt.timed(self._label_pl(lib, 'dgrad'), self.flops, lib.conv2d_dgrad_pl_f32,
                dypl, rec, rt.v(self.w), self.w_layout, g1, self.C1, self.b(self.x1),
@@ -1309,8 +1225,6 @@ class Graph:
       self._plan_res_via(lib)
       if fold_batch:
         self._plan_dy_producers(lib)
-    if fold_batch and STK_DY_PLANES and hasattr(lib, 'gn_bwd_pl_f32'):
-      self._plan_dy_planes(lib)
     # deferred parameter-gradient folds: a slot of [N][C][2] partial sums per GroupNorm layer (and per convolution bias
     # served by a GroupNorm backward), table entries (slot offset, dgamma offset, dbeta offset, N, C) in backward order
     # (STK_GN_FOLD_BATCH=0: every layer folds its own sums -- a debugging switch, results are bit-identical)
@@ -1434,40 +1348,6 @@ class Graph:
       gn.dy_cons, op.dy_prod = op, gn
     if any(isinstance(op, GroupNormAct) and op.dy_cons is not None for op in self.ops):
       self.ops.append(ZeroRecords(self.amax_block, len(self.conv_amax)))
-
-  def _plan_dy_planes(self, lib):
-    """Conv_0 -> (+ temb) -> GroupNorm_1 -> Conv_1 of a ResnetBlockBigGANpp (layerspp.py:273-281): d(Conv_0's output) is written by
-    GroupNorm_1's backward and read by Conv_0's backward only -- as planes.  Where the shapes allow (stk_gn_bwd_pl_ok, 16x16 / 32x32
-    maps) the GroupNorm backward writes the planes itself: its scale comes a priori from max |dy| per image, left by Conv_1's data
-    gradient (the only writer of GroupNorm_1's output gradient), and from max rstd / |xhat| per image, left by GroupNorm_1's own
-    forward.  Gone per layer: the fp32 gradient (4 B per element written), the split pass (4 read, 4 written) and its launch."""
-    writers = self._grad_writers()
-    recs = []
-    for gn in self.ops:
-      if not isinstance(gn, GroupNormAct) or gn.dy_cons is None or gn.C2 != 0 or gn.add_from is not None:
-        continue
-      c0 = gn.dy_cons
-      if c0.dy_peer is not None or c0.dy_from is not None or not (c0.pl_dgrad or c0.pl_wgrad):
-        continue
-      needs_dx = (c0.x1.needs_grad and c0.x1.space == 'act') or (c0.x2 is not None and c0.x2.needs_grad)
-      if (needs_dx and not c0.pl_dgrad) or (c0.w.needs_grad and not c0.pl_wgrad):
-        continue                                   # somebody still reads the fp32 gradient
-      if gn.y.pl_maker is not gn or not gn.fused:
-        continue
-      if not (int(lib.gn_bwd_pl_ok(gn.C1, gn.HW, gn.G)) and int(lib.gn_fwd_rec_ok(gn.C1, 0, gn.HW, gn.G))):
-        continue
-      ws = writers.get(id(gn.y), [])
-      if len(ws) != 1 or not isinstance(ws[0], Conv):
-        continue
-      c1 = ws[0]
-      if c1.x1 is not gn.y or c1.x2 is not None or not c1.pl_dgrad or c1.dy_from is not None:
-        continue
-      if not int(lib.conv2d_dgrad_pl_max_ok(c1.C1, c1.N, c1.H, c1.W, c1.Cout, c1.KH, c1.KW)):
-        continue
-      gn.pl_bwd, gn.dx_src, c0.dy_pl_from, c1.dx_rec = c0, c1, gn, True
-      recs.append(gn)
-    for gn in recs:
-      gn.gnrec = self.new((gn.N * gn.G,), needs_grad=False, name=gn.y.name + '.xhat')      # max |xhat| per (image, group): plain stores
 
   def _plan_shared_dy(self, lib):
     """ResnetBlockBigGANpp with a shortcut convolution: out = (Conv_2(x) + Conv_1(h)) / sqrt 2 (layerspp.py:283-287) is

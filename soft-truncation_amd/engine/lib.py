@@ -39,7 +39,6 @@ SIGNATURES = {
   'stk_gn_bwd_out_ok': [I, I, I, I],
   'stk_conv2d_pl_ksplit': [I, I, I, I, I, I, I, I, I],
   'stk_conv2d_pl_halo': [I, I, I, I, I, I, I, I, I],
-  'stk_conv2d_pl_tile': [I, I, I, I, I, I, I, I, I],
   'stk_gn_bwd_out_f32': [P, P, I, P, I, P, P, P, P, P, F, P, F, P, P, P, I, I, I, I, F, U64, P, P, F, P, F, P, I, P, S],
   'stk_gn_param_grad_batch': [P, I, I, S],
   'stk_conv2d_variant': [I, I, I, I, I, I, I, I, I, I, I, I, I, I],
@@ -61,12 +60,6 @@ SIGNATURES = {
   'stk_gn_fwd_pl_f32': [P, I, P, I, P, P, P, P, P, P, P, I, I, I, F, I, F, U64, P, P, S],
   'stk_gn_fwd_pl_fused': [I, I, I, I],
   'stk_gn_fwd_pl_max_f32': [P, I, P, I, P, P, P, P, P, P, P, I, I, I, F, I, F, U64, P, P, P, P, S],
-  'stk_gn_bwd_pl_ok': [I, I, I],
-  'stk_gn_bwd_pl_f32': [P, P, I, P, P, P, P, P, I, I, I, I, F, U64, P, P, F, P, I, P, P, P, P, P, S],
-  'stk_gn_fwd_rec_ok': [I, I, I, I],
-  'stk_gn_fwd_pl_rec_f32': [P, I, P, I, P, P, P, P, P, P, P, I, I, I, F, I, F, U64, P, P, P, P, P, S],
-  'stk_conv2d_dgrad_pl_max_ok': [I, I, I, I, I, I, I],
-  'stk_conv2d_dgrad_pl_max_f32': [P, P, P, I, P, I, F, F, I, I, I, I, I, I, P, P, L, P, S],
   'stk_planes_bytes': [I, I, I],
   'stk_amax_partial_f32': [P, L, P, S],
   'stk_split_planes_f32': [P, I, I, I, P, I, P, S],
@@ -118,8 +111,7 @@ SIGNATURES = {
 _RESTYPE = {'stk_strerror': c_char_p, 'stk_backend': c_char_p, 'stk_conv2d_wgrad_ws_bytes': c_long,
             'stk_conv2d_fwd_ws_bytes': c_long, 'stk_conv2d_dgrad_ws_bytes': c_long, 'stk_gn_ws_bytes': c_long,
             'stk_conv2d_wp_bytes': c_long, 'stk_conv2d_wp_desc': c_long, 'stk_planes_bytes': c_long, 'stk_conv2d_wgrad_pl_ws_bytes': c_long}
-_NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant', 'stk_conv2d_pl_ok', 'stk_gn_fwd_pl_fused', 'stk_conv2d_wgrad_pl_ok', 'stk_attention_ok', 'stk_gn_bwd_out_ok', 'stk_conv2d_pl_ksplit', 'stk_conv2d_pl_halo', 'stk_conv2d_pl_tile', 'stk_gn_bwd_pl_ok', 'stk_gn_fwd_rec_ok',
-             'stk_conv2d_dgrad_pl_max_ok'}
+_NO_CHECK = set(_RESTYPE) | {'stk_version', 'stk_conv2d_variant', 'stk_conv2d_pl_ok', 'stk_gn_fwd_pl_fused', 'stk_conv2d_wgrad_pl_ok', 'stk_attention_ok', 'stk_gn_bwd_out_ok', 'stk_conv2d_pl_ksplit', 'stk_conv2d_pl_halo'}
 
 
 class StkMissingError(RuntimeError):

@@ -286,10 +286,24 @@ def _pick_loss_fn(config, sde, train):
 # STK_DDP_OVERLAP=0: exchange the gradients after the backward (one bucketed all-reduce) instead of during it
 OVERLAP_EXCHANGE = os.environ.get('STK_DDP_OVERLAP', '1') != '0'
 # STK_RANGE_CHECK=K: every K-th training step (and the first) the per-image maxima of the fp32 output gradients are computed
-# (Executor.dynamic_range_report) and a warning is issued when an image lies more than RANGE_DECADES below the batch maximum
-# of some layer -- beyond that the one-scale-per-tensor split convolutions no longer give that image fp32 accuracy
-# (likelihood-weighted VE losses with g^2 weights are the candidate, reference losses.py:126-129).  0 = off.
-RANGE_CHECK_EVERY = int(os.environ.get('STK_RANGE_CHECK', '1000'))
+# (Executor.dynamic_range_report: one device reduction per 3x3 layer, one transfer) and a warning is issued when an image lies
+# more than RANGE_DECADES below the batch maximum of some layer -- beyond that the one-scale-per-tensor split convolutions no
+# longer give that image fp32 accuracy.  Unset: every 1000th step for likelihood-weighted losses (g^2 weights spread the
+# per-sample gradients over decades, reference losses.py:126-129), never otherwise.  0 = off.  With training.mixed the report
+# covers the last network evaluation of the step.
+def _env_int(name):
+  v = os.environ.get(name)
+  if v is None or v.strip() == '':
+    return None
+  try:
+    return int(v)
+  except ValueError:
+    import warnings
+    warnings.warn(f'{name}={v!r} is not an integer: ignored')
+    return None
+
+
+RANGE_CHECK_EVERY = _env_int('STK_RANGE_CHECK')
 RANGE_DECADES = 5.0
 # STK_ASYNC_LOSS=0: fetch the per-sample losses with a blocking .cpu() after the backward, as the reference does (A/B switch)
 ASYNC_LOSS_COPY = os.environ.get('STK_ASYNC_LOSS', '1') != '0'
@@ -339,6 +353,7 @@ def get_step_fn(config, sde, train, optimize_fn=None):
 
   micro_losses = mixed_losses if mixed else plain_losses
   staging = {}       # number of losses -> pinned host buffer of the asynchronous device-to-host copy
+  range_every = RANGE_CHECK_EVERY if RANGE_CHECK_EVERY is not None else (1000 if getattr(tr, 'likelihood_weighting', False) else 0)
 
   def step_fn(state, batch):
     model, optimizer = state['model'], state['optimizer']
@@ -382,7 +397,7 @@ def get_step_fn(config, sde, train, optimize_fn=None):
       ddp.disarm_overlap(model, wait=False)      # a step that raised must not leave its hook armed -- nor wait for its peers
       raise
     ddp.disarm_overlap(model)        # no-op after optimize_fn
-    if RANGE_CHECK_EVERY > 0 and state['step'] % RANGE_CHECK_EVERY == 0:
+    if range_every > 0 and state['step'] % range_every == 0:
       _warn_dynamic_range(model, state['step'])
     state['step'] += 1
     state['ema'].update(model.parameters())

@@ -336,11 +336,10 @@ BENCHED_PLAN = {
   'imagenet32_ddpmpp_st': dict(halo=(32, 16), other=_SMALL + tuple(f'conv3x3.wgrad.x2p.w{w}' for w in (32, 16, 8, 4))),
   # configs[2]: 64 / 32 / 16 / 8-wide maps at batch 128
   'celeba_uncsnpp_st': dict(halo=(64, 32, 16), other=_SMALL + tuple(f'conv3x3.wgrad.x2p.w{w}' for w in (32, 16, 8))),
-  # configs[4]: 256 ... 4-wide maps at batch 4: the 128- / 256-wide layers stay on x2d::gemm_kernel (their row-strip halo form,
-  # STK_X2D_HALO_WIDE=1, measured slower), halo tiles on the 64-wide ones; 32-wide and below: too few tiles at batch 4, K-split
-  'celebahq_uncsnpp_st': dict(halo=(128, 64) if os.environ.get('STK_X2D_HALO_WIDE', '0') != '0' else (64,),
-                              other=_SMALL + tuple(f'conv3x3.wgrad.x2p.w{w}' for w in (32, 16, 8)) +
-                              (() if os.environ.get('STK_X2D_HALO_WIDE', '0') != '0' else ('conv3x3.fwd.x2p', 'conv3x3.dgrad.x2p'))),
+  # configs[4]: 256 ... 4-wide maps at batch 4: the 128- / 256-wide layers run on x2d::gemm_kernel, halo tiles on the 64-wide ones;
+  # 32-wide and below: too few tiles at batch 4, K-split
+  'celebahq_uncsnpp_st': dict(halo=(64,), other=_SMALL + tuple(f'conv3x3.wgrad.x2p.w{w}' for w in (32, 16, 8)) +
+                              ('conv3x3.fwd.x2p', 'conv3x3.dgrad.x2p')),
 }
 
 
@@ -448,10 +447,9 @@ def benched_batch_vs_chunks(st, lib, cfg_name, B=128, chunk=8, tol=2e-5):
   labels, ksplit, slabs = plan_labels(model, B)
   out['labels'], out['ksplit'], out['wgrad_slabs'] = labels, ksplit, slabs
   if not SHRINK and lib.is_device and all(os.environ.get(k, '1') != '0' for k in ('STK_PLANES', 'STK_PLANES_WGRAD')):
-    # the large maps: the halo-tile GEMM per map width (round 3; STK_X2D_HALO=0: x2d::gemm_kernel for all of them)
-    halo = os.environ.get('STK_X2D_HALO', '1') != '0'
+    # the large maps: the halo-tile GEMM per map width
     widths = BENCHED_PLAN[cfg_name]['halo']
-    big = tuple(f'conv3x3.{d}.x2p.h{w}' for w in widths for d in ('fwd', 'dgrad')) if halo else ('conv3x3.fwd.x2p', 'conv3x3.dgrad.x2p')
+    big = tuple(f'conv3x3.{d}.x2p.h{w}' for w in widths for d in ('fwd', 'dgrad'))
     for need in big + BENCHED_PLAN[cfg_name]['other']:
       assert labels.get(need, 0) > 0, f'the batch-{B} plan never selected {need}: {labels}'
     assert ksplit > 1 and slabs > 1, (ksplit, slabs)

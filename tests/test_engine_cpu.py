@@ -469,35 +469,3 @@ def test_dynamic_range_report_flags_faint_images(st, ref_lib):
   assert rows[0][3] > 6.0 and all(r[1] >= r[2] > 0 for r in rows), rows[:3]
   with pytest.warns(UserWarning, match='decades across the images'):
     st.losses._warn_dynamic_range(model, 0)
-
-
-def test_groupnorm_backward_writes_the_dy_planes_of_the_convolution_before_it(st, ref_lib, monkeypatch):
-  """Graph._plan_dy_planes (round 5): Conv_0 -> GroupNorm_1 -> Conv_1 of a residual block -- GroupNorm_1's backward writes Conv_0's
-  dy planes itself (stk_gn_bwd_pl_f32: a-priori scale from the records of Conv_1's data gradient and of its own forward), so
-  Conv_0's backward makes no split pass and the fp32 gradient is never formed.  Same gradients as the plan without it (the planes
-  differ only by their power-of-two scale) and as RefNet; the true per-image maxima still reach the dynamic-range report."""
-  import torch
-  from importlib import import_module
-  G = import_module('soft-truncation_amd.engine.graph')
-  monkeypatch.setattr(G, 'STK_DY_PLANES', True)                          # (off by default: measured slower inside the step)
-  cases.forward_backward(st, ref_lib, 'wide', B=2)                       # against RefNet, with the planes plan
-  cfg, cfg_cpu, sde, model, ref = cases.build_pair(st, cases.tiny_config(st, 'wide'), ref_lib)
-  x, t = torch.randn(2, 3, 16, 16), torch.rand(2) * 999
-  model(x, t).square().sum().backward()
-  ops = [op for pr in model.module.engine().programs.values() for op in pr.graph.ops]
-  gns = [op for op in ops if isinstance(op, G.GroupNormAct) and op.pl_bwd is not None]
-  assert len(gns) >= 3 and all(g.pl_bwd.dy_pl_from is g and g.dx_src.dx_rec and g.gnrec is not None for g in gns)
-  # (their fp32 gradient is never formed, so the dynamic-range report covers these blocks through their Conv_1 layers)
-  rows = {r[0]: r for r in model.module.engine().dynamic_range_report()}
-  assert all(g.pl_bwd.y.name not in rows and g.dx_src.y.name in rows for g in gns)
-  planned = [p.grad.clone() for p in model.parameters()]
-  monkeypatch.setattr(G, 'STK_DY_PLANES', False)
-  model.module.engine().programs.clear()
-  for p in model.parameters():
-    p.grad.zero_()
-  model(x, t).square().sum().backward()
-  ops = [op for pr in model.module.engine().programs.values() for op in pr.graph.ops]
-  assert not any(isinstance(op, G.GroupNormAct) and op.pl_bwd is not None for op in ops)
-  top = max(p.grad.abs().max().item() for p in model.parameters())
-  for a, p in zip(planned, model.parameters()):
-    assert (a - p.grad).abs().max().item() <= 1e-5 * max(p.grad.abs().max().item(), 1e-4 * top)

@@ -11,6 +11,7 @@ import re
 import sys
 
 root = sys.argv[1]
+extra = sys.argv[2] if len(sys.argv) > 2 else ''      # e.g. '--workload celeba64' (tools/profile_workload.sh)
 
 
 def short(n):
@@ -43,7 +44,7 @@ print('roofline:', json.dumps(bench.get('roofline')))
 stats = first('stats/*kernel_stats.csv')
 rows = list(csv.DictReader(open(stats))) if stats else []
 steps = 13.0   # 10 timed + 3 warm-up steps in the profiled command (+ eager profiling steps, see the bench line)
-print('\nper-kernel time, rocprofv3 --kernel-trace --stats of `STK_WGRAD_STREAM=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --sampler-steps 0` (one stream, training only)')
+print(f'\nper-kernel time, rocprofv3 --kernel-trace --stats of `STK_WGRAD_STREAM=0 python bench.py {extra} --steps 10 --warmup 3 --no-cpu-baseline --sampler-steps 0` (one stream, training only)')
 print(f'{"kernel":92s} {"calls":>8s} {"avg_us":>9s} {"total_ms":>10s} {"%":>6s}')
 for r in rows[:45]:
   print(f'{short(r["Name"]):92s} {int(r["Calls"]):8d} {float(r["AverageNs"]) / 1e3:9.1f} {float(r["TotalDurationNs"]) / 1e6:10.2f} {float(r["Percentage"]):6.2f}')
