@@ -156,14 +156,13 @@ int stk_gn_param_grad_batch(const StkGnFoldDesc* descs_dev, int count, int max_C
  * power of two (from its |x| maximum, computed inside the call) and every fp32 value split into two fp16 terms;
  * the three significant partial products are accumulated in fp32 and the scales undone exactly (error at the level
  * of fp32 rounding, same as the f32-input MFMA path).  ws holds the prepared weights of this call, the partial
- * maxima and the K-split slabs.  The 3x3 weight gradient on maps of >= 8 columns splits both of its operands the
- * same way; 1x1 layers and 4-wide maps use a bf16 three-way split (six products, no scaling needed).
+ * maxima and the K-split slabs.  The weight gradients of these layers split both of their operands the same way.
  * ws = NULL / too small selects the f32-input MFMA path (v_mfma_f32_32x32x2_f32) for every shape.
  * ------------------------------------------------------------------------------------------ */
 long stk_conv2d_fwd_ws_bytes(int C1, int C2, int N, int H, int W, int Cout, int KH, int KW,
                              int stride, int pad);
 /* Which kernel family a call with full scratch takes (for profiling labels): dir 0 fwd, 1 dgrad, 2 wgrad;
- * returns 0 / 1 = f32-input MFMA with 64 / 128 tiles, 2 = bf16 three-way split, 3 = f32-input all-taps wgrad,
+ * returns 0 / 1 = f32-input MFMA with 64 / 128 tiles, (2 = the bf16 three-way split of rounds 1-5: retired) 3 = f32-input all-taps wgrad,
  * 4 = streaming kernel for a <= 4 channel side (stem, head, 3-channel pyramids), 5 = fp16 two-way split,
  * < 0 = unsupported shape. */
 int stk_conv2d_variant(int dir, int C1, int C2, int N, int H, int W, int Cout, int OH, int OW,

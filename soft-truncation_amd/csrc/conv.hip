@@ -742,7 +742,6 @@ __global__ __launch_bounds__(256) void splitk_reduce9_kernel(const float* __rest
     if (i < end) dw[i] += s[k * 256 + threadIdx.x];
   }
 }
-inline bool reduce9_on() { static const bool v = [] { const char* e = getenv("STK_REDUCE9"); return !e || atoi(e) != 0; }(); return v; }
 
 // ---- 3x3 / stride-1 / pad-1 weight gradient: all nine taps per workgroup ------------------------------------
 // The per-tap GEMM above re-reads dy and x once per tap and per tile and is bound by L2/Infinity-Cache
@@ -1023,7 +1022,6 @@ inline long x3_ws_bytes(const X3Plan& r, int M, int Kc, int taps) {
 // dgrad = 1: rows are input channels, k output channels, taps flipped.  Every split kernel is the fp16 two-way split (3 MFMAs per
 // fp32 product, conv_x2.h / conv_x2d.h / conv_x2w.h); the bf16 three-way-split kernels of round 1 (six MFMAs) were the fallback
 // of a debugging switch until round 5 and are retired (DESIGN.md "Retired").
-inline bool wgrad1_pin() { static const bool v = [] { const char* e = getenv("STK_W1_PIN"); return !e || atoi(e) != 0; }(); return v; }
 
 inline void x3_weight_strides(const ConvP& p, int dgrad, long& sm, long& sk) {
   if (p.w_layout == 0) { sm = dgrad ? p.taps : (long)p.Cin * p.taps; sk = dgrad ? (long)p.Cin * p.taps : p.taps; }
@@ -1486,7 +1484,7 @@ int stk_conv2d_wgrad_pl_wgs_f32(const void* xpl, const float* xrec, const void* 
   STK_CHECK_LAUNCH();
   // measured (tools/bench_x2d.py, kernel + reduce, us, old -> new): 32 slabs 118.5 -> 117.0 / 55.1 -> 51.1, 64: 74.4 -> 72.3, 16: 206.0 ->
   // 201.8, 8: 44.8 -> 39.7, but 128 slabs 124.1 -> 130.8 (1152 four-byte loads per thread): the coalesced form up to 64 slabs
-  if (reduce9_on() && q.splits <= 64)
+  if (q.splits <= 64)
     hipLaunchKernelGGL(splitk_reduce9_kernel, dim3((unsigned)stk_cdiv((long)Cout * Cin, 256L)), dim3(256), 0, s, ws, dw, (long)Cout * Cin,
                        q.splits, q.slab, alpha);
   else
@@ -1685,15 +1683,9 @@ int stk_conv2d_wgrad_amax_f32(const float* x1, int C1, const float* x2, int C2, 
         if (C2 > 0) hipLaunchKernelGGL(x2::amax_partial_kernel, ab, at, 0, s, x2, (long)N * C2 * p.HW, parts + 2 * x2::NPART);
       }
       const int nx = C2 > 0 ? 2 * x2::NPART : x2::NPART;
-      const bool pin = wgrad1_pin();
 #define STK_X2_WGRAD1(BLOADER)                                                                                              \
-  do {                                                                                                                      \
-    using AL_ = x2::RowsU<false, false>;                                                                                    \
-    if (pin) hipLaunchKernelGGL((x2::wgemm_kernel<AL_, BLOADER, EpWgrad, true>), grid, dim3(256), 0, s, p, Cout, p.Cin,      \
-                                tm, tn, nch, xq.chunks_per_split, p.taps, dyp, xp, nx);                                     \
-    else hipLaunchKernelGGL((x2::wgemm_kernel<AL_, BLOADER, EpWgrad, false>), grid, dim3(256), 0, s, p, Cout, p.Cin,         \
-                            tm, tn, nch, xq.chunks_per_split, p.taps, dyp, xp, nx);                                         \
-  } while (0)
+  hipLaunchKernelGGL((x2::wgemm_kernel<x2::RowsU<false, false>, BLOADER, EpWgrad, true>), grid, dim3(256), 0, s, p, Cout,  \
+                     p.Cin, tm, tn, nch, xq.chunks_per_split, p.taps, dyp, xp, nx)
 #define STK_COMMA ,
       if (p.taps == 1) { if (C2 > 0) STK_X2_WGRAD1(x2::RowsU<true STK_COMMA true>); else STK_X2_WGRAD1(x2::RowsU<true STK_COMMA false>); }
       else if (W >= 16) { if (C2 > 0) STK_X2_WGRAD1(x2::RowsB<true STK_COMMA 16>); else STK_X2_WGRAD1(x2::RowsB<false STK_COMMA 16>); }

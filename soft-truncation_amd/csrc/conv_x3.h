@@ -1,35 +1,13 @@
-// conv_x3.h -- 3x3 / stride-1 / pad-1 convolution (forward and data-gradient) on the bf16 matrix pipe with a
-// three-way operand split ("x3"), for gfx950.  Included by conv.hip inside its anonymous namespace.
+// conv_x3.h -- what is left of the round-1 bf16 three-way-split ("x3") convolution path: the pieces the fp16 two-way-split
+// kernels (conv_x2.h, conv_x2d.h, conv_x2w.h) share with it -- the activation-operand descriptor (Src), raw buffer loads, the
+// fp32 row loaders of the weight gradients (RowsLoader, Rows3Loader) and the sizing helpers.  Included by conv.hip inside its
+// anonymous namespace.  The x3 GEMM / weight-gradient kernels themselves (six bf16 MFMAs per fp32 product) were the fallback of a
+// debugging switch since round 2 and were retired in round 6 (git history; DESIGN.md "Retired").
 //
-// Why: v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate (157 TFLOP/s); the bf16 MFMA is 16x faster.  An fp32
-// value is EXACTLY the sum of three bf16 values (8 + 8 + 8 significand bits, taken by truncation):
-//     a = a0 + a1 + a2,   b = b0 + b1 + b2
-//     a*b = a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0) + O(2^-24 |ab|)
-// so six bf16 MFMAs (products exact, fp32 accumulate) give the fp32 product to fp32 rounding accuracy -- measured
-// against the double-precision oracle the error is the same as (slightly below) the f32-input MFMA's, see
-// tests/test_gpu_kernels.py -- at 6/16 of the matrix-pipe time.
-//
-// GEMM view (both directions share the kernel):   out[m, n] = sum_k  Wp[m, k] * act[k, n]
-//     forward  m = co, n = (b, y, x), k = (tap, ci):   act = x[b, ci, y + kh - 1, x + kw - 1]
-//     dgrad    m = ci, n = (b, y, x), k = (tap', co):  act = dy[b, co, y + kh' - 1, x + kw' - 1], tap' = 8 - tap
 // K is ordered (32-channel group, tap, channel in group): a 32-wide k chunk is one tap and 32 consecutive channels,
 // so the tap (hence the halo test and the pixel shift) is uniform over the chunk and a thread's 16 loads differ only
 // by a scalar channel-plane offset; and the nine chunks of a channel group follow each other, so the nine shifted
-// reads of the same 32 x (128 + halo) activation patch hit L1 / L2 (with the taps outermost they were 9 sweeps over
-// all channels and measured 3-6x the algorithmic bytes at the memory side).
-//
-//   * weights are re-laid out and split ONCE per call by wprep_kernel into Wp[split][k / 32][tap][row (padded to 128)][k % 32]
-//     bf16 (<= 14 MB, L2 resident): the A loader is six 16-byte copies per thread and chunk, no conversion;
-//   * activations are split in the B loader when they are written to LDS (and/sub/perm, ~6 VALU per element);
-//   * LDS tiles are [split][row][32 k] bf16 with an 80-byte row pitch: the MFMA operand reads (one ds_read_b128
-//     per lane = 8 consecutive k of one row) and the staging writes are bank-conflict free;
-//   * 128 x 128 tile, 4 waves of 64 x 64 (2 x 2 MFMA tiles): per 16-k step 12 ds_read_b128 and 24 MFMAs per wave,
-//     small terms first so the accumulation order is fixed.
-//
-// Weight gradient (same kernel, other loaders):  dw[tap][co, ci] = sum_pixels dy[co, px] * x[ci, px + tap shift]:
-// both operands have k = pixels contiguous in NCHW, so a thread stages 16 consecutive pixels of one channel (the x
-// operand shifted by the tap, halo masked); one GEMM per tap, split over K into partial slabs that
-// splitk_reduce_kernel sums in a fixed order (no float atomics).
+// reads of the same 32 x (128 + halo) activation patch hit L1 / L2.
 #pragma once
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -54,46 +32,6 @@ __device__ __forceinline__ float hi_part(float v) { return __uint_as_float(__flo
 // pack the bf16 (upper) halves of two floats: low half <- lo, high half <- hi
 __device__ __forceinline__ unsigned pack_hi(float lo, float hi) {
   return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
-}
-
-// Wp[split][k / 32][tap][row][k % 32] = split_s( W(row, k, tap) ), rows >= R are zero: one (channel group, tap) is a
-// dense [Mpad][32] bf16 block, i.e. the A tile of one chunk is 8 KB of consecutive memory per plane.
-// W(row, k, tap) = w[row*sm + k*sk + (flip ? taps-1-tap : tap)]:
-//     forward  [Cout,Cin,kh,kw]: sm = Cin*taps, sk = taps      NIN [Cin,Cout]: sm = 1, sk = Cout
-//     dgrad    [Cout,Cin,kh,kw]: sm = taps, sk = Cin*taps, flip   NIN: sm = Cout, sk = 1
-// One thread per (row, k): reads its taps (contiguous).
-struct WprepDesc {        // == StkWprepDesc (include/stk.h)
-  const float* w; unsigned short* wp; long sm, sk; int M, Kc, Mpad, taps, flip, reserved;
-};
-__device__ __forceinline__ void wprep_one(const float* __restrict__ w, unsigned short* __restrict__ out, int R, int Kd,
-                                          int Mpad, long sm, long sk, int taps, int flip, long i) {
-  const long total = (long)Mpad * Kd;
-  if (i >= total) return;
-  // k fastest inside a group of 32 so that the 2-byte stores of a wave are contiguous
-  const int kl = (int)(i & 31);
-  const long rest = i >> 5;
-  const int row = (int)(rest % Mpad), cc = (int)(rest / Mpad), k = cc * 32 + kl;
-  const long plane = (long)taps * Mpad * Kd;
-  const float* s = w + (row < R ? row * sm + k * sk : 0);
-  for (int t = 0; t < taps; ++t) {
-    const float a = row < R ? s[flip ? taps - 1 - t : t] : 0.f;
-    const float h0 = hi_part(a), r1 = a - h0;
-    const float h1 = hi_part(r1), h2 = r1 - h1;           // h2 has <= 8 significant bits: exact in bf16
-    const long o = (((long)cc * taps + t) * Mpad + row) * 32 + kl;
-    out[o] = (unsigned short)(__float_as_uint(h0) >> 16);
-    out[plane + o] = (unsigned short)(__float_as_uint(h1) >> 16);
-    out[2 * plane + o] = (unsigned short)(__float_as_uint(h2) >> 16);
-  }
-}
-__global__ __launch_bounds__(256) void wprep_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int R,
-                                                    int Kd, int Mpad, long sm, long sk, int taps, int flip) {
-  wprep_one(w, out, R, Kd, Mpad, sm, sk, taps, flip, (long)blockIdx.x * 256 + threadIdx.x);
-}
-// All layers of a network in one launch: blockIdx.y picks the descriptor, blockIdx.x walks its (row, k) pairs
-// (grid.x is sized for the largest layer; blocks past the end of a smaller one exit).
-__global__ __launch_bounds__(256) void wprep_batch_kernel(const WprepDesc* __restrict__ descs) {
-  const WprepDesc d = descs[blockIdx.y];
-  wprep_one(d.w, d.wp, d.M, d.Kc, d.Mpad, d.sm, d.sk, d.taps, d.flip, (long)blockIdx.x * 256 + threadIdx.x);
 }
 
 // Staging is cut into 24 slices so that the kernel can place one slice after each MFMA of a 24-MFMA group (the
@@ -136,70 +74,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, lo
 __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
-
-// forward / dgrad A: prepared weights, six 16-byte pieces per chunk (split j>>1, row (tid>>2) + 64 (j&1), segment tid&3)
-struct WpLoader {
-  __amdgpu_buffer_rsrc_t rs; unsigned voff, plane2, chunk2; int row, seg;
-  u32x4 r[6];
-  __device__ __forceinline__ void init(const ConvP&, const Src& q, int m0, int tid, int) {
-    row = tid >> 2; seg = tid & 3;
-    plane2 = (unsigned)q.taps * q.Mpad * q.Kc * 2u;     // bytes per split plane
-    chunk2 = (unsigned)q.Mpad * KC * 2u;                // bytes per (channel group, tap) block = per chunk
-    rs = make_rsrc(q.wp, 3L * plane2);
-    voff = ((unsigned)(m0 + row) * KC + seg * 8) * 2u;
-  }
-  __device__ __forceinline__ void ld(int g, const ConvP&, const Src&, int c) {
-    if (g >= 6) return;
-    r[g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                         rs, (int)voff, (int)((unsigned)c * chunk2 + (g >> 1) * plane2 + (g & 1) * 64u * KC * 2u), 0));
-  }
-  __device__ __forceinline__ void st(int g, unsigned char* t) {
-    if (g < 6) *reinterpret_cast<u32x4*>(t + (g >> 1) * PLANE + (row + 64 * (g & 1)) * PITCH + seg * 16) = r[g];
-  }
-};
-
-// forward / dgrad B: activations, lanes along pixels; a thread holds 16 channels of one tap-shifted pixel
-template <bool DUAL, int TAPS>
-struct ActLoader {
-  __amdgpu_buffer_rsrc_t rs1, rs2;
-  int nl, kg, tb1, tb2; unsigned mask;
-  float r[16]; Split16 sp;
-  __device__ __forceinline__ void init(const ConvP& p, const Src& q, int n0, int tid, int) {
-    nl = tid & 127;
-    kg = __builtin_amdgcn_readfirstlane(tid >> 7);      // which 16 of the chunk's 32 channels
-    rs1 = make_rsrc(q.s1, (long)p.N * q.S1 * p.HW * 4);
-    rs2 = make_rsrc(q.s2, (long)p.N * (DUAL ? q.S2 : q.S1) * p.HW * 4);
-    mask = 0; tb1 = 0; tb2 = 0;
-    const int n = n0 + nl;
-    if (n < p.N * p.HW) {
-      const int b = n / p.HW, hw = n - b * p.HW;
-      const int y = hw / p.W, x = hw - y * p.W;
-      if (TAPS == 1) mask = 1u;
-#pragma unroll
-      for (int t = 0; t < (TAPS == 9 ? 9 : 0); ++t) {
-        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
-      }
-      tb1 = b * q.S1 * p.HW + hw;
-      tb2 = b * q.S2 * p.HW + hw;
-    }
-  }
-  // slices 8..23 load one channel each (its register was consumed by conversion slice (g - 8) / 2 <= 7)
-  __device__ __forceinline__ void ld(int g, const ConvP& p, const Src& q, int c) {
-    if (g < 8) return;
-    const int cc = TAPS == 9 ? c / 9 : c, tap = c - cc * TAPS;   // scalar: chunk = (32-channel group, tap), tap fastest
-    const int ci0 = cc * KC + kg * 16;
-    const bool first = !DUAL || ci0 < q.S1;                      // scalar: a chunk never straddles the two sources
-    const __amdgpu_buffer_rsrc_t rs = first ? rs1 : rs2;
-    const unsigned so = (unsigned)(first ? ci0 : ci0 - q.S1) * p.HW * 4u;
-    // halo / out-of-range lanes: offset bit 31 -> outside the buffer -> the load returns 0 (no select, no branch)
-    const unsigned dead = (((mask >> tap) & 1u) ^ 1u) << 31;
-    const int shift = TAPS == 9 ? (tap / 3 - 1) * p.W + (tap % 3 - 1) : 0;
-    const unsigned vo = (unsigned)(((first ? tb1 : tb2) + shift) * 4) | dead;
-    r[g - 8] = bload(rs, vo, so + (unsigned)(g - 8) * p.HW * 4u);
-  }
-  __device__ __forceinline__ void st(int g, unsigned char* t) { sp.st(g, r, 0xffffu, t, nl, kg * 16); }
-};
 
 // wgrad operands: rows = channels, k = pixels (contiguous in NCHW).  Thread (row = tid>>1, half = tid&1) holds the
 // 16 consecutive pixels k0 + 16*half .. +15 of its channel, shifted by the tap for the x operand.  Requires W a
@@ -288,134 +162,6 @@ struct RowsLoader {
   __device__ __forceinline__ void st(int g, unsigned char* t) { sp.st(g, r, okm, t, row, half * 16); }
 };
 
-// ---- the kernel: out tile 128 x 128, 4 waves of 64 x 64, chunks of 32 k ---------------------------------------
-// Grid (XCD-remapped): one flat dimension of taps_z x tiles x K-splits blocks, z fastest.  taps_z = 9 for the 3x3
-// weight gradient (the nine blocks reading the same dy / x panels are neighbours on one XCD's L2), 1 otherwise.
-template <class AL, class BL, class EP, bool HAND>
-__global__ __launch_bounds__(256) void gemm_kernel(ConvP p, Src q, int M, int Nn, int tiles_m, int tiles_n,
-                                                   int nchunks_total, int chunks_per_split, int taps_z) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-  unsigned char* As = lds;
-  unsigned char* Bs = lds + OPER;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
-  const int ntiles = tiles_m * tiles_n;
-  // one flat grid dimension of z-batches (taps) x tiles x K splits, z fastest
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int zb = id % taps_z;
-  const int rest = id / taps_z;
-  const int tile = rest % ntiles;
-  const int zs = rest / ntiles;
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
-  const int m0 = tm * 128, n0 = tn * 128;
-  const int c_begin = zs * chunks_per_split;
-  const int c_last = min(nchunks_total, c_begin + chunks_per_split) - 1;     // >= c_begin by construction
-
-  AL al; BL bl;
-  al.init(p, q, m0, tid, taps_z == 1 ? 4 : zb);      // 1x1 weight gradient: the (unshifted) centre tap
-  bl.init(p, q, n0, tid, taps_z == 1 ? 4 : zb);
-
-  floatx16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 64;
-  const int fk = lane >> 5, fc = lane & 31;
-  const unsigned char* a_rd = As + (wm0 + fc) * PITCH + fk * 16;
-  const unsigned char* b_rd = Bs + (wn0 + fc) * PITCH + fk * 16;
-
-  // Pipeline (LDS single-buffered, two barriers per chunk):
-  //   B1: chunk c is in LDS          -> read the kk = 0 fragments, 24 MFMAs, read the kk = 1 fragments
-  //   B2: nobody reads LDS any more  -> 24 MFMAs of kk = 1, each followed by ONE SLICE of the staging of chunk c + 1
-  //                                     (split + LDS write; its global loads were issued one iteration earlier) and
-  //                                     of the global loads of chunk c + 2, pinned in place by sched_barrier.
-  // So the conversion VALU, the LDS stores and the load issue run in the shadow of the matrix pipe of the same wave
-  // (~6 other instructions fit in the 32 cycles of one MFMA), and a global load has a whole chunk period to land.
-#define STK_X3_FRAGS(KK)                                                                               \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s = 0; s < 3; ++s) {         \
-    a[i][s] = *reinterpret_cast<const bf16x8*>(a_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);          \
-    b[i][s] = *reinterpret_cast<const bf16x8*>(b_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);          \
-  }
-  // six products per tile, smallest terms first; the four tiles interleave so that consecutive MFMAs never
-  // wait on the same accumulator.  MFMA g of a group: product g / 4, tile (g / 2) & 1, g & 1.
-  constexpr int SA[6] = {2, 1, 0, 1, 0, 0}, SB[6] = {0, 1, 2, 0, 1, 0};
-#define STK_X3_MFMA(G)                                                                                                \
-  acc[((G) >> 1) & 1][(G) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[((G) >> 1) & 1][SA[(G) >> 2]], b[(G) & 1][SB[(G) >> 2]], \
-                                                                         acc[((G) >> 1) & 1][(G) & 1], 0, 0, 0);
-#pragma unroll
-  for (int g = 0; g < 24; ++g) { al.ld(g, p, q, c_begin); bl.ld(g, p, q, c_begin); }
-  {
-    const int c1 = min(c_begin + 1, c_last);
-#pragma unroll
-    for (int g = 0; g < 24; ++g) { al.st(g, As); bl.st(g, Bs); al.ld(g, p, q, c1); bl.ld(g, p, q, c1); }
-  }
-  bf16x8 a[2][3], b[2][3];
-  for (int c = c_begin; c < c_last; ++c) {
-    __syncthreads();                                   // B1
-    STK_X3_FRAGS(0)
-#pragma unroll
-    for (int g = 0; g < 24; ++g) { STK_X3_MFMA(g) }
-    STK_X3_FRAGS(1)
-    __syncthreads();                                   // B2
-    const int c2 = min(c + 2, c_last);                 // (the last iteration re-loads the last chunk: harmless)
-    if (HAND) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int g = 0; g < 24; ++g) {
-        STK_X3_MFMA(g)
-        al.st(g, As); bl.st(g, Bs);                    // chunk c + 1: registers -> LDS
-        al.ld(g, p, q, c2); bl.ld(g, p, q, c2);        // chunk c + 2: global -> registers
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      // Two converting loaders (weight gradient): ~26 VALU per slice do not fit behind one MFMA; pinning them there
-      // measured 20-25% slower than handing the scheduler the whole phase with a coarse pipeline hint.
-#pragma unroll
-      for (int g = 0; g < 24; ++g) { STK_X3_MFMA(g) }
-#pragma unroll
-      for (int g = 0; g < 24; ++g) al.st(g, As);
-#pragma unroll
-      for (int g = 0; g < 24; ++g) bl.st(g, Bs);
-#pragma unroll
-      for (int g = 0; g < 24; ++g) al.ld(g, p, q, c2);
-#pragma unroll
-      for (int g = 0; g < 24; ++g) bl.ld(g, p, q, c2);
-#pragma unroll
-      for (int g = 0; g < 24; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // VALU
-        if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
-      }
-    }
-  }
-  __syncthreads();
-  STK_X3_FRAGS(0)
-#pragma unroll
-  for (int g = 0; g < 24; ++g) { STK_X3_MFMA(g) }
-  STK_X3_FRAGS(1)
-#pragma unroll
-  for (int g = 0; g < 24; ++g) { STK_X3_MFMA(g) }
-#undef STK_X3_MFMA
-#undef STK_X3_FRAGS
-
-  EP ep;
-  ep.init(p, zb, zs);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn0 + j * 32 + fc;
-    const bool nok = n < Nn;
-    ep.col(p, nok ? n : 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ep.strip(p, m0 + wm0 + i * 32 + 4 * fk, M, nok, nok ? n : 0, acc[i][j]);
-  }
-}
-
 // ---- 3x3 weight gradient, three taps per workgroup ---------------------------------------------------------------
 // The per-tap GEMM above re-reads and re-splits dy nine times and x nine times.  Here a workgroup owns one kernel ROW
 // (kh) of a 128(co) x 64(ci) block of dw: the three taps kw = 0, 1, 2 read the same x pixels shifted by one, so a
@@ -489,115 +235,6 @@ struct Rows3Loader {
     }
   }
 };
-
-template <bool DUAL>
-__global__ __launch_bounds__(256) void wgrad3_kernel(ConvP p, int tiles_m, int tiles_n, int nchunks_total,
-                                                     int chunks_per_split) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[W3_LDS];
-  unsigned char* As = lds;
-  unsigned char* Bs = lds + OPER;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
-  const int ntiles = tiles_m * tiles_n;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);       // kernel row fastest: the three blocks share dy / x panels
-  const int kh = id % 3;
-  const int rest = id / 3;
-  const int tile = rest % ntiles;
-  const int zs = rest / ntiles;
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
-  const int m0 = tm * 128, n0 = tn * 64;
-  const int c_begin = zs * chunks_per_split;
-  const int c_last = min(nchunks_total, c_begin + chunks_per_split) - 1;
-
-  Src q = {};
-  RowsLoader<false, false, 16> al;
-  Rows3Loader<DUAL> bl;
-  al.init(p, q, m0, tid, 4);
-  bl.init(p, n0, tid, kh);
-
-  floatx16 acc[2][3];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.f;
-
-  const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 32;
-  const int fk = lane >> 5, fc = lane & 31;
-  const unsigned char* a_rd = As + (wm0 + fc) * PITCH + fk * 16;
-  const unsigned char* b_rd = Bs + (wn0 + fc) * PITCH + fk * 16;
-
-#define STK_W3_FRAGS(KK)                                                                                   \
-  _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                           \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
-      a[i][s] = *reinterpret_cast<const bf16x8*>(a_rd + s * PLANE + i * 32 * PITCH + (KK) * 32);             \
-    _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                            \
-      b[t][s] = *reinterpret_cast<const bf16x8*>(b_rd + t * W3_BTAP + s * W3_BPLANE + (KK) * 32);            \
-  }
-  constexpr int SA[6] = {2, 1, 0, 1, 0, 0}, SB[6] = {0, 1, 2, 0, 1, 0};
-#define STK_W3_MFMAS                                                                                       \
-  _Pragma("unroll") for (int pr = 0; pr < 6; ++pr) _Pragma("unroll") for (int i = 0; i < 2; ++i)              \
-    _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                            \
-      acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][SA[pr]], b[t][SB[pr]], acc[i][t], 0, 0, 0);
-
-#pragma unroll
-  for (int g = 0; g < 24; ++g) { al.ld(g, p, q, c_begin); bl.ld(g, p, c_begin); }
-  {
-    const int c1 = min(c_begin + 1, c_last);
-#pragma unroll
-    for (int g = 0; g < 24; ++g) { al.st(g, As); bl.st(g, Bs); }
-#pragma unroll
-    for (int g = 0; g < 24; ++g) { al.ld(g, p, q, c1); bl.ld(g, p, c1); }
-  }
-  bf16x8 a[2][3], b[3][3];
-  for (int c = c_begin; c < c_last; ++c) {
-    __syncthreads();                                   // chunk c is in LDS
-    STK_W3_FRAGS(0)
-    STK_W3_MFMAS
-    STK_W3_FRAGS(1)
-    __syncthreads();                                   // nobody reads LDS any more
-    const int c2 = min(c + 2, c_last);
-    STK_W3_MFMAS
-#pragma unroll
-    for (int g = 0; g < 24; ++g) al.st(g, As);
-#pragma unroll
-    for (int g = 0; g < 24; ++g) bl.st(g, Bs);
-#pragma unroll
-    for (int g = 0; g < 24; ++g) al.ld(g, p, q, c2);
-#pragma unroll
-    for (int g = 0; g < 24; ++g) bl.ld(g, p, c2);
-#pragma unroll
-    for (int g = 0; g < 36; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);     // VALU
-      if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
-    }
-  }
-  __syncthreads();
-  STK_W3_FRAGS(0)
-  STK_W3_MFMAS
-  STK_W3_FRAGS(1)
-  STK_W3_MFMAS
-#undef STK_W3_MFMAS
-#undef STK_W3_FRAGS
-
-  // partial slab of split zs as [tap][Cout][Cin] (lanes = ci, contiguous); splitk_reduce_kernel re-lays it out
-  float* slab = p.part + (long)zs * p.part_stride;
-  const int n = n0 + wn0 + fc;
-  if (n < p.Cin) {
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wm0 + i * 32 + 4 * fk + igemm::strip_row(e);
-          if (m < p.Cout) slab[((long)(kh * 3 + t) * p.Cout + m) * p.Cin + n] = acc[i][t][e];
-        }
-  }
-}
 
 inline int pad128(int v) { return (v + 127) / 128 * 128; }
 // bytes of prepared weights for an M x Kc layer

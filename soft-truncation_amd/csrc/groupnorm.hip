@@ -1033,9 +1033,8 @@ __global__ __launch_bounds__(256) void gn_apply_pl_kernel(GnArgs a, const float*
 
 // shapes of the two-kernel route: maps of whole 128-pixel tiles, whole groups per 32-channel block and per source
 static inline bool gn_pl_2k_ok(int C1, int C2, int HW, int G) {
-  static const bool on = [] { const char* e = getenv("STK_GN_PL_2K"); return !e || atoi(e) != 0; }();
   const int C = C1 + C2;
-  if (!on || C % 32 || C1 % 32 || C % G || HW % AP_PIX) return false;
+  if (C % 32 || C1 % 32 || C % G || HW % AP_PIX) return false;
   const int cpg = C / G;
   if (cpg > 32 || 32 % cpg) return false;
   const long L = (long)cpg * HW;

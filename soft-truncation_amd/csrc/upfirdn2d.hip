@@ -426,9 +426,8 @@ int launch(const float* input, const float* kernel, float* out, float beta, int 
   const bool tiled_ok = minor == 1 && up_x == up_y && down_x == down_y && kh <= UFD_MAX_TAPS && kw <= UFD_MAX_TAPS &&
                         ((up_x == 1 && (down_x == 1 || down_x == 2)) || (up_x == 2 && down_x == 1)) &&
                         (long)in_h * in_w < 0x7fffffffL;
-  // plain 4 x 4 FIR with rows that are not a whole number of 16-byte pieces: flat-order kernel (STK_UFD_FLAT=0: off)
-  static const int flat_on = [] { const char* e = getenv("STK_UFD_FLAT"); return !e || atoi(e) != 0; }();
-  if (flat_on && tiled_ok && up_x == 1 && down_x == 1 && kh == 4 && kw == 4 && (p.out_w & 3) != 0 && p.out_w + 3 <= 1024 &&
+  // plain 4 x 4 FIR with rows that are not a whole number of 16-byte pieces: flat-order kernel
+  if (tiled_ok && up_x == 1 && down_x == 1 && kh == 4 && kw == 4 && (p.out_w & 3) != 0 && p.out_w + 3 <= 1024 &&
       (long)p.out_h * p.out_w < (1L << 21)) {
     const int pitch = (p.out_w + 3) | 1;
     // ~2048 outputs per workgroup: whole planes while they fit the LDS budget, else bands of rows
@@ -464,8 +463,7 @@ int launch(const float* input, const float* kernel, float* out, float beta, int 
     // the HBM rate on the 64x64 -> 128x128 up-sampling against 74 % for the run form, profiles/r04_upfirdn2d.txt).
     // Outputs per workgroup: 1024 (4 per thread); 4096 for up-sampling, whose input is 4x smaller; 2048 for bands of
     // a down-sampling (the halo rows of a band are read twice: fewer, taller bands).
-    static const int band_on = [] { const char* e = getenv("STK_UFD_BANDS"); return !e || atoi(e) != 0; }();
-    const int tow_max = band_on && p.out_w <= 256 ? 8 : 6;
+    const int tow_max = p.out_w <= 256 ? 8 : 6;
     int tow_log2 = 2, toh_log2 = 2;
     while (tow_log2 < tow_max && (1 << tow_log2) < p.out_w) ++tow_log2;
     const bool wide = (1 << tow_log2) >= p.out_w;                    // tiles_x == 1

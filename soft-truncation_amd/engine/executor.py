@@ -63,8 +63,6 @@ class _GnFoldDesc(ctypes.Structure):       # StkGnFoldDesc of include/stk.h
 _LIB_ONLY = os.environ.get('STK_LIB_ONLY', '1' if _POISON else '0') == '1'
 # STK_WP_SIDE=0: the data-gradient weight blocks are prepared in front of the forward with the forward blocks (A/B switch)
 _WP_SIDE = os.environ.get('STK_WP_SIDE', '1') != '0'
-# STK_XCHG_NOJOIN=0: every segment of the overlapped gradient exchange ends with a join of the side stream into the main one (round 4)
-_XCHG_NOJOIN = os.environ.get('STK_XCHG_NOJOIN', '1') != '0'
 
 from torch.utils._python_dispatch import TorchDispatchMode
 
@@ -197,9 +195,6 @@ def checked_side_stream(device):
     if ratio < 1.5:
       break
   _SIDE_STREAMS[key] = (best, best_ratio, check)
-  if check and os.environ.get('STK_SIDE_VERBOSE', '0') == '1':
-    print(f'[stk] side stream of device {index}: overlap ratio {best_ratio:.2f} (1 = beside the launch stream, 2 = behind it)',
-          flush=True)
   return best
 
 
@@ -592,13 +587,11 @@ class Executor:
               op.forward(rt)
           elif span is None:
             for op in reversed(ops):
-              rt.guard(op)
               op.backward(rt)
             rt.flush_folds()
             rt.join_side()
           else:
             for op in list(reversed(ops))[span[0]:span[1]]:
-              rt.guard(op)
               op.backward(rt)
             rt.flush_folds()
             rt.join_side()
@@ -698,12 +691,11 @@ class Executor:
             last = end >= len(order)
             with _launch_window(_LIB_ONLY and rt.side is not None):
               for op in order[begin:end]:
-                rt.guard(op)
                 op.backward(rt)
               rt.flush_folds()
-              if last or rt.side is None or not _XCHG_NOJOIN:
+              if last or rt.side is None:
                 rt.join_side()
-            if not last and rt.side is not None and _XCHG_NOJOIN and ranges:
+            if not last and rt.side is not None and ranges:
               # A bucket is final once the main chain AND the side stream's weight gradients launched so far are done.  Joining the side
               # stream into the main one at every segment end made the main chain wait for it four times per step (with one weight-
               # gradient workgroup per CU the side stream runs further behind: exchange proxy +0.5 -> +1.5 ms per step); instead a third
@@ -727,7 +719,6 @@ class Executor:
       rt.prof = self.profiler
       with _launch_window(_LIB_ONLY and rt.side is not None):
         for op in reversed(g.ops):
-          rt.guard(op)
           op.backward(rt)
         rt.flush_folds()
         rt.join_side()

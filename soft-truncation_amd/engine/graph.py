@@ -21,21 +21,16 @@ import os
 import numpy as np
 
 SQRT2 = float(np.float32(np.sqrt(2.)))
-# A/B switches of the side stream (engine/executor.SideStream): shortcut convolutions' backward / fp32-operand weight gradients
-# (round 5: the shortcut convolutions' backward stays on the MAIN stream by default -- together with weight gradients that leave half of
-# every CU free (csrc/conv_x2w.h: STK_X2W_WGS = 256) that is 1.2 ms per step better than both on the side stream, measured inside the
-# step on five boxes: profiles/r05_insitu_sweeps.txt)
-_SIDE_SHORTCUT = os.environ.get('STK_SIDE_SHORTCUT', '0') != '0'
-_SIDE_WGRAD1 = os.environ.get('STK_SIDE_WGRAD1', '1') != '0'
+# What runs on the side stream (engine/executor.SideStream) is fixed since round 5: every weight gradient, nothing else -- the shortcut
+# convolutions' backward and the forward's shortcuts were measured there twice and lost (profiles/r05_insitu_sweeps.txt,
+# profiles/r06_insitu_sweeps.txt); their switches are retired.
 # Workgroups of a weight gradient launched on the MAIN stream (one-stream mode, the profiler's eager steps), 0 = the same count as on the side
 # stream.  512 (two per CU) is the faster setting for a kernel that has the chip to itself, but a different K split sums its slabs in a
 # different order, and the one-stream backward is the bit-for-bit reference of the two-stream one (tests/test_gpu_model.py::
 # test_two_streams_are_deterministic): the default keeps the arithmetic of the two modes identical.
 _X2W_WGS_ALONE = int(os.environ.get('STK_X2W_WGS_ALONE', '0'))
-_SIDE_W1_FILTER = None      # debugging: predicate on the Conv op
-_SIDE_DELAY = int(os.environ.get('STK_SIDE_DELAY', '0'))
+_SIDE_DELAY = 0             # tests: spin cycles that hold the side stream back before a launch (tests/_model_cases.py)
 _SIDE_DELAY_FILTER = None
-_SIDE_FAKE = False
 _ALIGN = 64  # floats (256 B) -- keeps every buffer float4-aligned
 # A convolution's record buffer: three 256-float scale records -- |x1|, |x2|, |dy| (include/stk.h "amax")
 AMAX = 768
@@ -111,7 +106,6 @@ class Runtime:
     # stream before every split pass, and inside a hipGraph each such cross-stream edge costs 15-30 us.
     self.side = None
     self.ws2 = 0
-    self.pending = {}            # id(activation tensor) -> event of the side-stream work that wrote its gradient
     self._cur = None
 
   def side_launch(self, fn, *args):
@@ -121,43 +115,10 @@ class Runtime:
       import torch
       with torch.cuda.stream(self.side.stream):
         torch.cuda._sleep(_SIDE_DELAY)
-    if _SIDE_FAKE:                                        # debugging: the real work stays on the main stream (args carry ws2: fine)
-      fn(*args, self.stream)
-    else:
-      fn(*args, s)
+    fn(*args, s)
     self.side.end()
 
-  def run_on_side(self, writes, fn):
-    """Run fn() with `stream` / `ws` pointing at the side stream and its workspace (behind everything launched on the main
-    stream so far).  `writes` = the activation tensors whose GRADIENTS fn writes: the next main-stream op that touches one
-    of them waits for fn first (guard)."""
-    side = self.side
-    s = side.begin()
-    saved = (self.stream, self.ws)
-    self.stream, self.ws, self.side = s, self.ws2, None
-    try:
-      fn()
-    finally:
-      self.stream, self.ws = saved
-      self.side = side
-    ev = side.end()
-    for t in writes:
-      if t is not None:
-        self.pending[id(t)] = ev
-
-  def guard(self, op):
-    """Called before op.backward on the main stream: wait for side-stream work that wrote a gradient this op reads or
-    accumulates into."""
-    if not self.pending:
-      return
-    for t in tuple(op.inputs) + (getattr(op, 'y', None),):
-      if t is not None:
-        ev = self.pending.pop(id(t), None)
-        if ev is not None:
-          self.side.main_waits(ev)
-
   def join_side(self):
-    self.pending.clear()
     if self.side is not None:
       self.side.join()
 
@@ -520,13 +481,6 @@ class Conv(Op):
              rt.v(self.y), *self._dims(), self._wp(rt, 0), rt.v(self.amax), rt.ws, rt.ws_bytes, rt.stream)
 
   def backward(self, rt):
-    if self.dy_from is not None and rt.side is not None and rt.prof is None and _SIDE_SHORTCUT:
-      # a shortcut convolution differentiates from its peer's (final) output gradient and only meets the main chain again
-      # where the block's first GroupNorm accumulates into d(x): its HBM-bound 1x1 passes run beside the main chain's GEMMs
-      return rt.run_on_side((self.x1, self.x2), lambda: self._backward(rt))
-    return self._backward(rt)
-
-  def _backward(self, rt):
     gy = rt.g(self.y)
     alpha = 1.0 / self.out_div
     lib = rt.lib
@@ -569,7 +523,7 @@ class Conv(Op):
                                   rt.g(peer.bias), rt.v(peer.amax) + 4 * 512, rt.ws, rt.stream)
       rec_done = True
       res_grad = fuse_rec = False
-    if res_grad and fuse_rec and hasattr(lib, 'bias_grad_amax_res_f32') and os.environ.get('STK_RES_FUSED', '1') != '0':
+    if res_grad and fuse_rec and hasattr(lib, 'bias_grad_amax_res_f32'):
       # one pass over dy: bias / time-embedding sums, the |dy| scale record AND the residual branch's gradient
       lib.bias_grad_amax_res_f32(gy, self.N, self.Cout, self.OH * self.OW, alpha, dtemb, self.temb_stride, gb, dy_rec,
                                  rt.g(self.res), self.b(self.res), rt.ws, rt.stream)
@@ -629,7 +583,7 @@ class Conv(Op):
       rt.timed(self._label_pl(lib, 'wgrad'), self.flops, lib.conv2d_wgrad_pl_wgs_f32,
                rt.planes(self.x1), rt.rec(self.x1), dypl, dy_rec, gw, alpha, rt.ws, rt.ws_bytes,
                self.N, self.H, self.W, self.C1, self.Cout, _X2W_WGS_ALONE, rt.stream)
-    elif gw is not None and rt.side is not None and rt.prof is None and _SIDE_WGRAD1 and (_SIDE_W1_FILTER is None or _SIDE_W1_FILTER(self)):
+    elif gw is not None and rt.side is not None and rt.prof is None:
       # a weight gradient is a leaf of the backward: x, dy and this layer's own records in, dw out
       rt.side_launch(lib.conv2d_wgrad_amax_f32, rt.v(self.x1), self.C1, rt.v(self.x2), self.C2, gy, gw, self.w_layout, alpha,
                      rt.ws2, rt.ws_bytes, *self._dims(), rt.v(self.amax), have)
@@ -1379,7 +1333,7 @@ class Graph:
       if P.pl_dgrad or P.pl_wgrad or P.Cout != op.Cout:
         continue
       op.dy_peer, P.dy_from = P, op
-      if (os.environ.get('STK_SC_PEER_PLANES', '1') != '0' and (P.x1.needs_grad or (P.x2 is not None and P.x2.needs_grad)) and
+      if ((P.x1.needs_grad or (P.x2 is not None and P.x2.needs_grad)) and
           hasattr(lib, 'conv2d_pl_ok') and
           int(lib.conv2d_pl_ok(1, P.C1, P.C2, P.N, P.H, P.W, P.Cout, P.KH, P.KW, 1, P.pad))):
         if op.dypl_off is not None:

@@ -92,7 +92,7 @@ class AttnBlockpp(nn.Module):
     C = self.NIN_0.W.shape[1]
     w_off = g.flat.cols_block(ws) if hasattr(g.flat, 'cols_block') else None
     b0 = g.param(bs[0])
-    stacked = (w_off is not None and os.environ.get('STK_QKV_STACKED', '1') != '0' and
+    stacked = (w_off is not None and
                all(g.flat.offset_of(b)[0] == b0.off + i * C for i, b in enumerate(bs)))
     if stacked:
       # q, k, v = three NIN layers on the same input (layerspp.py:91-93) as ONE 1x1 convolution with 3 C output

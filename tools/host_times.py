@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Host-side time of the phases of a training step (runs on the GPU box): how long the host spends INSIDE the hipGraph
 replays of the forward / backward (a large graph launch blocks the calling thread while its nodes are queued) and in the
-rest of step_fn.  usage: python tools/host_times.py [steps]"""
+rest of step_fn.  usage: python tools/host_times.py [steps] [workload]
+("stream already idle when the loss-copy wait returned" N of N times = the HOST is the bottleneck of the step: the batch-4 regime)"""
 import os
 import sys
 import time
@@ -43,7 +44,7 @@ torch.cuda.Event.synchronize = _timed_sync
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 device = torch.device('cuda', 0)
 torch.cuda.set_device(0)
-cfg_name, B, desc = bench.WORKLOADS['cifar10']
+cfg_name, B, desc = bench.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else 'cifar10']
 cfg = st.configs.get_config(cfg_name)
 cfg.device = device
 st.engine.ddp.seed_everything(cfg.seed)
