@@ -119,28 +119,6 @@ def _launch_window(active):
 
 
 _SIDE_STREAMS = {}     # (device index, launch stream handle) -> (side stream, overlap ratio, checked)
-# STK_SIDE_CUS=N (round 6 experiment): the side stream is created with a CU mask of N compute units (hipExtStreamCreateWithCUMask;
-# the mask's bits go round the XCDs, so the first N bits are N / 8 CUs of every XCD): the weight gradients then occupy a fixed
-# part of the chip instead of a slice of every CU.  0 = no mask (a pooled torch stream).
-_SIDE_CUS = int(os.environ.get('STK_SIDE_CUS', '0') or 0)
-_MASKED = []           # keeps the masked streams alive
-
-
-def _masked_stream(dev, n_cus):
-  hip = ctypes.CDLL('libamdhip64.so')
-  words = (n_cus + 31) // 32
-  mask = (ctypes.c_uint32 * max(words, 1))()
-  for i in range(n_cus):
-    mask[i // 32] |= 1 << (i % 32)
-  handle = ctypes.c_void_p()
-  with torch.cuda.device(dev):
-    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask)
-  if rc != 0 or not handle.value:
-    raise RuntimeError(f'hipExtStreamCreateWithCUMask({n_cus} CUs) failed: {rc}')
-  st = torch.cuda.ExternalStream(handle.value, device=dev)
-  _MASKED.append(st)
-  return st
-
 
 def _overlap_ratio(main, cand, cycles=400000):
   """Time of one spin kernel on each of the two streams, started together, over the time of one alone: ~1 when the streams run
@@ -188,7 +166,7 @@ def checked_side_stream(device):
   check = want_check and not capturing
   best, best_ratio = (hit[0], 1e9) if (hit is not None and not check) else (None, 1e9)
   for _ in range(8 if check else (0 if best is not None else 1)):
-    cand = _masked_stream(dev, _SIDE_CUS) if _SIDE_CUS > 0 else torch.cuda.Stream(dev)
+    cand = torch.cuda.Stream(dev)
     ratio = _overlap_ratio(main, cand) if check else 0.0
     if ratio < best_ratio:
       best, best_ratio = cand, ratio

@@ -598,7 +598,7 @@ class _CopyNeighbour:
         torch.add(self.a, self.b, out=self.c)
 
 
-def two_streams_deterministic(st, lib, B=96, delays=(150000, 600000, 2000000), neighbour_runs=300, copy_runs=100):
+def two_streams_deterministic(st, lib, B=96, delays=(150000, 600000, 2000000), neighbour_runs=150, copy_runs=50):
   """The backward with its weight gradients / shortcut convolutions on the side stream (engine/executor.SideStream) must
   give the gradients of a quiet one-stream backward BIT FOR BIT, whatever else is resident on the chip:
     * every side launch site in turn held back by a spin kernel (torch.cuda._sleep) of three lengths, with and without
