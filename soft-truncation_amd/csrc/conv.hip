@@ -995,11 +995,11 @@ inline X3Plan x3_plan(const ConvP& p, int Kc, int S1, int S2, int M, long Ng) {
   const int nch = p.taps * (Kc / 32);
   r.chunks_per_split = nch;
   if (tiles >= 192) { r.ok = 1; return r; }
-  // STK_KSPLIT_WGS / STK_KSPLIT_MINCH: A-B knobs of the split (workgroups to fill, fewest chunks per workgroup)
+  // STK_KSPLIT_WGS: A-B knob of the split (workgroups to fill); at least `minch` chunks per workgroup
   static const long target = [] { const char* e = getenv("STK_KSPLIT_WGS"); return e && atol(e) > 0 ? atol(e) : 512L; }();
   // (round 4 sweep, profiles/r04_ksplit_sweep.txt: >= 12 chunks per workgroup -- 256 -> 256 at 4x4, batch 128: 12 splits 27.4 us,
   // 6 splits 23.8; 512 -> 256 at 8x8: 73.9 -> 71.9; the 8x8 256 -> 256 layers keep their 4 splits either way)
-  static const long minch = [] { const char* e = getenv("STK_KSPLIT_MINCH"); return e && atol(e) > 0 ? atol(e) : 12L; }();
+  constexpr long minch = 12;
   long splits = target / tiles;
   // few chunks per workgroup: the prologue and the slab traffic dominate (1x1 layers have Kc / 32 chunks in all: they keep 6)
   const long mc = p.taps == 9 ? minch : (minch < 6 ? minch : 6);
@@ -1131,7 +1131,7 @@ inline X3WgradPlan x3_wgrad_plan(int C1, int C2, int N, int Cout, int H, int W, 
   // 255; 128->256 at 16x16, 2 tiles: 32 against 41); with 512 workgroups it did not
   if (taps == 1 && tiles < 2) return q;
   const long chunks = K / 32;
-  static const long w1_wgs = [] { const char* e = getenv("STK_W1_WGS"); return e ? atol(e) : 256L; }();
+  constexpr long w1_wgs = 256;                // (128 / 192 were neutral inside the step, profiles/r05_insitu_sweeps.txt)
   long splits = (taps == 1 && tiles < 6 ? w1_wgs : 512) / tiles;
   if (splits > chunks / 8) splits = chunks / 8;
   if (splits < 1) splits = 1;

@@ -80,6 +80,23 @@ __device__ __forceinline__ float block_amax(const float* __restrict__ part, int 
   return m;
 }
 
+// The same maximum with the LOADS at the top of a kernel and the reduction after its main loop (round 6): the scale of a plane operand
+// is needed by the epilogue only, so its load latency (and the barriers of the reduction) need not stand in front of the first tile load --
+// 2-3 us per workgroup round, which a 27 us K-split launch or a one-round weight gradient notices.  `red`: 4 floats of LDS of its own.
+struct LateAmax {
+  float m;
+  __device__ __forceinline__ void load(const float* __restrict__ part, int count, int tid) {
+    m = part[tid];
+    if (count > NPART) m = fmaxf(m, part[NPART + tid]);
+  }
+  __device__ __forceinline__ float reduce(float* red, int tid) {            // all 256 threads of the (group of the) workgroup
+    const float v = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  }
+};
+
 __device__ __forceinline__ unsigned pack_h2(float lo, float hi) {
   const halfx2 v = {(_Float16)lo, (_Float16)hi};                      // round to nearest even
   return __builtin_bit_cast(unsigned, v);

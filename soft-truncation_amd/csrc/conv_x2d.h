@@ -57,9 +57,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M,
   unsigned char* const Bs = lds + G::A_BYTES;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float sx = x2::pow2_scale_of(x2::block_amax(xpart, nxpart, reinterpret_cast<float*>(lds)));
+  __shared__ float red_amax[4];
+  x2::LateAmax xmax;                                    // loads now, reduction behind the main loop (the epilogue's unscale needs it)
+  xmax.load(xpart, nxpart, tid);
   const float sw = x2::weight_scale(q.wp);
-  const float unscale = 1.f / (sw * sx);
   const int ntiles = tiles_m * tiles_n;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = id % ntiles, zs = id / ntiles;
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M,
 #undef STK_D_FRAGS
 #undef STK_D_FRAGS_AT
 
+  const float unscale = 1.f / (sw * x2::pow2_scale_of(xmax.reduce(red_amax, tid)));
   ep.stage(lds, tid);
   ep.init(p, 0, zs);
 #pragma unroll
@@ -218,12 +220,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(ConvP p, x3::Src q, int M,
 // 26 instead of 72 B-side DMA instructions per group and workgroup (W = 32), issued one per wave and chunk into the
 // OTHER of two B buffers while the current group computes.  A (weights) is staged per chunk as before.
 // Shapes: W = 16, 32 or (NB = 1) 64, maps of whole tiles (H W % 128 == 0), no K split.
-// Round 4: W = 128 instantiates ROW STRIPS for the wide maps of the 256 x 256 net (map width 128 or 256): a tile is 128
-// consecutive pixels of ONE row starting at column x0 = hw0 % width, its halo tile 3 rows x 130 columns (390 rows of 64 bytes per
-// plane: 50 instead of 144 B-side DMA instructions per channel group and workgroup; 67 KB of LDS, two workgroups per CU).
-// Bit-identical to gemm_kernel, but slower than it (see halo_cols): kept behind STK_X2D_HALO_WIDE=1.
-// NB = 2: two B buffers, the next group's tile streams in one piece per wave and chunk (two workgroups per CU);
-// NB = 1: one B buffer, refilled in a burst behind the last tap's fragment reads (three workgroups per CU cover the wait).
+// Only NB = 1 (one B buffer, refilled in a burst behind the last tap's fragment reads; three workgroups per CU cover the wait) and
+// W = 16 / 32 / 64 are instantiated.  The template still carries the two forms that were measured slower and retired in round 6 --
+// NB = 2 (two B buffers, two workgroups per CU) and W = 128 (row strips for the 128- / 256-wide maps: 67 KB of LDS, 187.9 -> 203.1 us)
+// -- because they share all of the kernel's code paths but a few constants.
 template <int W, class EP, int NB>
 __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(ConvP p, x3::Src q, int M, int Nn, int tiles_m, int tiles_n,
                                                            int ngroups, const float* __restrict__ xpart, int nxpart) {
@@ -236,9 +236,10 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(ConvP p, x3::Src q, i
   unsigned char* const Bs = lds + A_BYTES;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float sx = x2::pow2_scale_of(x2::block_amax(xpart, nxpart, reinterpret_cast<float*>(lds)));
+  __shared__ float red_amax[4];
+  x2::LateAmax xmax;                                    // loads now, reduction behind the main loop
+  xmax.load(xpart, nxpart, threadIdx.x);
   const float sw = x2::weight_scale(q.wp);
-  const float unscale = 1.f / (sw * sx);
   const int ntiles = tiles_m * tiles_n;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = id % ntiles;
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void gemm_halo_kernel(ConvP p, x3::Src q, i
 #undef STK_H_MFMAS
 #undef STK_H_FRAGS
 
+  const float unscale = 1.f / (sw * x2::pow2_scale_of(xmax.reduce(red_amax, tid)));
   ep.stage(lds, tid);
   ep.init(p, 0, 0);
 #pragma unroll

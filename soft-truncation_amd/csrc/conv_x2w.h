@@ -45,16 +45,6 @@ struct Args {
   int tiles_co, tiles_ci, nchunks_total, chunks_per_split;
 };
 
-// maximum of the x2::NPART (= 256) partial maxima of a scale record, by the 256 threads of one group (`red`: that group's LDS)
-__device__ __forceinline__ float group_amax(const float* __restrict__ part, int tid, float* red) {
-  float m = wave_max(part[tid]);
-  if ((tid & 63) == 0) red[tid >> 6] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
-  return m;
-}
-
 __device__ __forceinline__ halfx8 cat(s4 lo, s4 hi) {
   typedef short s8 __attribute__((__vector_size__(16)));
   const s8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -92,10 +82,12 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void wgrad_kernel(Args a) {
   const int grp = GROUPS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned char* const lds = lds_all + grp * LDS;               // this group's stages
-  // (every group reduces the 256 partial maxima for itself, in its own LDS: the barriers inside are workgroup-wide)
-  const float sa = x2::pow2_scale_of(group_amax(a.dyrec, tid, reinterpret_cast<float*>(lds)));
-  const float sb = x2::pow2_scale_of(group_amax(a.xrec, tid, reinterpret_cast<float*>(lds)));
-  const float unscale = 1.f / (sa * sb);
+  // the operands' scales are needed by the slab store only: their partial maxima are LOADED here and reduced behind the main loop
+  // (every group for itself, in LDS of its own: the barrier inside is workgroup-wide)
+  __shared__ float red_amax[2][GROUPS][4];
+  x2::LateAmax amax_dy, amax_x;
+  amax_dy.load(a.dyrec, x2::NPART, tid);
+  amax_x.load(a.xrec, x2::NPART, tid);
   const int ntiles = a.tiles_co * a.tiles_ci;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = id % ntiles, zs = id / ntiles;
@@ -226,6 +218,9 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void wgrad_kernel(Args a) {
     if (c <= c_last) compute(lds + cur * BUF);
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
+  const float sa = x2::pow2_scale_of(amax_dy.reduce(red_amax[0][grp], tid));
+  const float sb = x2::pow2_scale_of(amax_x.reduce(red_amax[1][grp], tid));
+  const float unscale = 1.f / (sa * sb);
   if (GROUPS == 2) {
     // group 1 -> group 0, three taps (48 floats per thread, 48 KB) per round through group 0's stages; element (t, e) of
     // thread tid at float (16 t + e) 256 + tid: conflict-free for writer and reader
@@ -287,7 +282,7 @@ inline Plan plan(int N, int H, int W, int Cin, int Cout, int wgs = 0) {
   // maps), not the two that fit.  The weight gradients run on the side stream BESIDE the main chain of the backward; two workgroups per CU
   // with their 256 accumulation registers per lane leave no room for anybody else's waves, so "two streams" was time slicing (summed
   // kernel durations 54 ms for 40 ms of work, tools/stream_timeline.py); with half of every CU free the main chain's kernels really
-  // run beside them -- and the slab traffic halves.  Measured inside the step (512 -> 256, with STK_SIDE_SHORTCUT=0; profiles/
+  // run beside them -- and the slab traffic halves.  Measured inside the step (512 -> 256, shortcut convolutions' backward on the main stream; profiles/
   // r05_insitu_sweeps.txt): CIFAR-10 net 37.6 -> 36.4 ms, 256x256 net at batch 4 39.4 -> 37.6, 64x64 net 121.6 -> 120.4.  The kernel
   // alone is slower that way (the round-3 micro-benchmark chose 512); the step is what counts.
   static const long shared = [] { const char* e = getenv("STK_X2W_WGS"); return e && atol(e) > 0 ? atol(e) : 256L; }();

@@ -1165,9 +1165,9 @@ static int gn_fwd_pl_impl(const float* x1, int C1, const float* x2, int C2, cons
     a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.gamma = gamma; a.beta = beta;
     a.N = N; a.HW = HW; a.G = G; a.cpg = C / G; a.act = act; a.drop_p = drop_p; a.keep_scale = 1.f / (1.f - drop_p); a.drop_thr = stk_drop_threshold(drop_p);
     a.seed = seed; a.seed_dev = seed_dev;
-    // HW = 1024: two workgroups of 512 threads per CU instead of one of 1024 (STK_GN_PL_T, default 512): the same 16
-    // waves per CU, but the load phase of one block overlaps the arithmetic / store phase of the other
-    static const int tmax = [] { const char* e = getenv("STK_GN_PL_T"); const int v = e ? atoi(e) : 512; return v == 512 ? v : 1024; }();
+    // HW = 1024: two workgroups of 512 threads per CU instead of one of 1024: the same 16 waves per CU, but the load phase of
+    // one block overlaps the arithmetic / store phase of the other
+    constexpr int tmax = 512;
     int T = HW * 4 < 1024 ? HW * 4 : 1024;
     if (HW * 4 > 1024 && tmax < T) T = tmax;
     const int items = HW * 4, passes = items / T;

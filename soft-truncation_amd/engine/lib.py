@@ -170,7 +170,16 @@ def load_path(path):
 
 
 def load():
-  """The product library.  Raises StkMissingError (never falls back) when it is absent."""
+  """The product library.  Raises StkMissingError (never falls back) when it is absent.
+
+  STK_LIBSTK=<path> (A/B runs of two BUILDS of the HIP library on one box, tools/insitu.sh) loads that file instead; it must be
+  a HIP build -- a host / oracle library is refused, so the override cannot turn the product path into a CPU path."""
+  alt = os.environ.get('STK_LIBSTK')
+  if alt:
+    lib = load_path(alt)
+    if not lib.is_device:
+      raise StkMissingError(f'STK_LIBSTK={alt} is not a HIP build of include/stk.h (backend {lib.backend}): refused')
+    return lib
   if not os.path.exists(PRODUCT_LIB):
     raise StkMissingError(
       f'{PRODUCT_LIB} is not built. Run `python -c "import __graft_entry__ as g; g.build()"` '
