@@ -67,7 +67,11 @@ constexpr int BUF = 2 * A_PLANE + 2 * B_PLANE;   // 36864 per stage
 // STAGES = 2: LDS stages of the DMA ring.  Three stages (two chunks in flight, 110 KB of LDS) were measured in round 6 and bought
 // nothing -- 128 -> 128 @ 32 x 32 at 256 workgroups 134.4 (two) / 135.9 us (three), 384 -> 128 378.2 / 380.8 -- and cost the step
 // 0.2 ms (35.82 -> 35.99 / 36.04 ms: more LDS, 296 instead of 209 registers, less room for the main chain's waves on the CU), so
-// the kernel is not waiting for its DMA either (profiles/r06_x2w.txt).
+// the kernel is not waiting for its DMA either (profiles/r06_x2w.txt).  Also measured: the next chunk's nine DMA instructions issued
+// BETWEEN the MFMA groups of the current chunk instead of in a burst in front of them (an LDS-DMA costs its wave 60-180 cycles of issue,
+// and a SIMD holds ONE wave of this kernel in the two-stream geometry): seven times SLOWER, because hipcc then puts an s_waitcnt vmcnt(0)
+// in front of every DMA and every following fragment read (it cannot prove that the DMA's LDS bytes are not the ones being read, even
+// with the two stages as two __shared__ objects), which makes every DMA synchronous.  The burst at the chunk boundary stays.
 template <int COLS, int GROUPS = 1>
 __global__ __launch_bounds__(256 * GROUPS, 2) void wgrad_kernel(Args a) {
   constexpr int STAGES = 2;

@@ -5,18 +5,18 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/round
 rm -rf $OUT; mkdir -p $OUT
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --detail $OUT/bench_detail.json > $OUT/bench.json 2> $OUT/bench.err
 # The profiled passes run the backward on ONE stream (STK_WGRAD_STREAM=0): with the weight gradients on the side stream kernels
 # of two streams overlap, and a kernel's traced duration then includes the time it shares the chip (x2w::wgrad_kernel<32> 232 us
 # against 174 alone).  The benchmark line itself (bench.json) is the default engine; bench.py's own event brackets
 # (roofline object) are taken with one stream as well (engine/profile.KernelTimer).
 export STK_WGRAD_STREAM_PROFILE=0
-BENCH="env STK_WGRAD_STREAM=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exchange-proxy --no-extra-workloads"
+BENCH="env STK_WGRAD_STREAM=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exchange-proxy --no-extra-workloads --detail /tmp/profile_round_detail.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- $BENCH --sampler-steps 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o r -- $BENCH --prof-steps 0 --no-kernel-timer --sampler-steps 0 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o r -- $BENCH --prof-steps 0 --no-kernel-timer --sampler-steps 0 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o r -- $BENCH --prof-steps 0 --no-kernel-timer --sampler-steps 0 > /dev/null 2> $OUT/pmc_mfma.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -o r -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exchange-proxy --no-extra-workloads --no-parity-probe --sampler-steps 0 --no-kernel-timer --prof-steps 0 > /dev/null 2> $OUT/stats2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -o r -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exchange-proxy --no-extra-workloads --no-parity-probe --sampler-steps 0 --no-kernel-timer --prof-steps 0 --detail /tmp/profile_round_detail.json > /dev/null 2> $OUT/stats2.err
 python tools/profile_summary.py $OUT > $OUT/summary.txt 2>&1
 python - $OUT/stats2 > $OUT/two_stream_kernel_stats.txt <<'PY'
 import csv, glob, os, re, sys
