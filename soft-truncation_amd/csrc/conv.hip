@@ -1468,16 +1468,11 @@ int stk_conv2d_wgrad_pl_wgs_f32(const void* xpl, const float* xrec, const void* 
   if (2 * a.dy_ps >= 0x7fffffffL || 2 * a.x_ps >= 0x7fffffffL) return STK_EUNSUPPORTED;
   a.part = ws; a.part_stride = q.slab;
   a.N = N; a.H = H; a.W = W; a.HW = H * W; a.Cin = Cin; a.Cout = Cout; a.Cob = Cout / 32; a.Cib = Cin / 32;
-  a.tiles_co = stk_cdiv(Cout, 128); a.tiles_ci = q.tile64 ? Cin / 64 : Cin / 32;
+  a.tiles_co = stk_cdiv(Cout, 128); a.tiles_ci = Cin / 32;
   a.nchunks_total = (int)((long)N * H * W / 32); a.chunks_per_split = q.chunks_per_split;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)(a.tiles_co * a.tiles_ci * q.splits));
-  if (q.tile64) {
-    if (W >= 32) hipLaunchKernelGGL((x2w::wgrad64_kernel<32>), grid, dim3(512), 0, s, a);
-    else if (W == 16) hipLaunchKernelGGL((x2w::wgrad64_kernel<16>), grid, dim3(512), 0, s, a);
-    else if (W == 8) hipLaunchKernelGGL((x2w::wgrad64_kernel<8>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((x2w::wgrad64_kernel<4>), grid, dim3(512), 0, s, a);
-  } else if (q.groups == 2) {
+  if (q.groups == 2) {
     if (W >= 32) hipLaunchKernelGGL((x2w::wgrad_kernel<32, 2>), grid, dim3(512), 0, s, a);
     else if (W == 16) hipLaunchKernelGGL((x2w::wgrad_kernel<16, 2>), grid, dim3(512), 0, s, a);
     else if (W == 8) hipLaunchKernelGGL((x2w::wgrad_kernel<8, 2>), grid, dim3(512), 0, s, a);

@@ -264,179 +264,22 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void wgrad_kernel(Args a) {
   }
 }
 
-// ---- 128 x 64 tiles (round 6) ----------------------------------------------------------------------------------------------------
-// What bounds wgrad_kernel is neither its LDS reads, nor the latency of its DMA, nor (as far as could be tested) its DMA issue: its
-// LDS-DMA TRAFFIC is.  Both operands are activations, too large for an XCD's L2, and every 128 x 32 tile re-reads all of dy: per launch
-// chunks x tiles x 36 KB pass from the Infinity Cache into LDS -- 603 MB for a 128 -> 128 layer at 32 x 32 (134 MB of operands) -- and
-// every shape of tools/bench_x2d.py lands at 4.5-5.2 TB/s of that traffic (603 MB / 134 us, 1.81 GB / 370 us, 1.2 GB / 231 us ...,
-// profiles/r06_x2w.txt).  So the tile grows where it is cheap: EIGHT waves own 128 output x 64 input channels -- wave (sub, w): the
-// 32-block w of dy against the 32-block `sub` of x -- and share ONE staged dy tile: 48 KB per chunk for twice the MFMAs of a 36 KB
-// chunk of the narrow tile (-33 % bytes per MFMA).  No second group, no exchange at the end; one barrier per chunk for all eight waves;
-// six DMA instructions per wave and chunk instead of nine.  Needs Cin % 64 == 0 (else the narrow kernel).
-constexpr int BUF64 = 2 * A_PLANE + 4 * B_PLANE;   // 49152 per stage: dy [2 planes][4 blocks], x [2 sub-tiles][2 planes]
-
-template <int COLS>
-__global__ __launch_bounds__(512, 2) void wgrad64_kernel(Args a) {
-  constexpr bool TWO = COLS == 4;
-  constexpr int ROWS = 32 / COLS;
-  constexpr int TPA = COLS + 2;
-  constexpr int TRB = TWO ? 12 : ROWS + 2;
-  static_assert(ROWS * TPA <= A_INSTR * 16 && TRB * COLS <= B_INSTR * 16, "tiles exceed the staged slots");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF64];
-  __shared__ float red_amax[2][8];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);              // 0 .. 7
-  const int wid = w8 & 3, sub = w8 >> 2;                                // dy block, x sub-tile of this wave
-  x2::LateAmax amax_dy, amax_x;                                         // 256 partials each: every thread takes one, waves 4..7 repeat
-  amax_dy.load(a.dyrec, x2::NPART, tid & 255);
-  amax_x.load(a.xrec, x2::NPART, tid & 255);
-  const int ntiles = a.tiles_co * a.tiles_ci;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = id % ntiles, zs = id / ntiles;
-  const int tco = tile % a.tiles_co, tci2 = tile / a.tiles_co;          // tci2: 64-channel tile of x
-  const int c_begin = zs * a.chunks_per_split;
-  const int c_last = min(a.nchunks_total, c_begin + a.chunks_per_split) - 1;
-
-  const __amdgpu_buffer_rsrc_t a_rs = x3::make_rsrc(a.dypl, 2L * a.dy_ps);
-  const __amdgpu_buffer_rsrc_t b_rs = x3::make_rsrc(a.xpl, 2L * a.x_ps);
-  const int piece = (lane & 3) * 16;
-  // dy: 24 instructions per chunk (4 blocks x 3 x 2 planes), wave w8 issues ia = w8, w8 + 8, w8 + 16: (block, j, plane) = (ia / 6, ia % 6 / 2, ia % 2)
-  int a_rel[3], a_c[3], a_dst[3], a_blk[3]; unsigned a_pl[3];
-#pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    const int ia = w8 + 8 * u, blk = ia / 6, j = (ia % 6) >> 1, pl = ia & 1;
-    const int sl = 16 * j + (lane >> 2);
-    int r = sl / TPA;
-    a_c[u] = sl - r * TPA;
-    int img = 0;
-    if (TWO) { img = r >> 2; r &= 3; }
-    const int cob = tco * 4 + blk;
-    if (sl >= ROWS * TPA || cob >= a.Cob) a_c[u] = -1000000;
-    a_rel[u] = (img * a.Cob * a.HW + r * a.W + a_c[u] - 1) * 64 + piece;
-    a_dst[u] = pl * A_PLANE + blk * A_BLK + j * 1024;
-    a_blk[u] = cob;
-    a_pl[u] = (unsigned)pl;
-  }
-  // x: 24 instructions per chunk (2 sub-tiles x 6 x 2 planes), wave w8 issues ib = w8, w8 + 8, w8 + 16: (sub-tile, plane, j) = (ib / 12, ib % 12 / 6, ib % 6)
-  int b_rel[3], b_ty[3], b_dst[3], b_sub[3]; unsigned b_pl[3];
-#pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    const int ib = w8 + 8 * u, st = ib / 12, pl = (ib % 12) / 6, j = ib % 6;
-    const int sl = 16 * j + (lane >> 2);
-    b_ty[u] = sl / COLS;
-    const int tx = sl - b_ty[u] * COLS;
-    int img = 0;
-    if (TWO) { img = b_ty[u] / 6; b_ty[u] -= 6 * img; }
-    if (sl >= TRB * COLS) b_ty[u] = -1000000;
-    b_rel[u] = (img * a.Cib * a.HW + (b_ty[u] - 1) * a.W + tx) * 64 + piece;
-    b_dst[u] = 2 * A_PLANE + (2 * st + pl) * B_PLANE + j * 1024;
-    b_sub[u] = st;
-    b_pl[u] = (unsigned)pl;
-  }
-  auto stage = [&](int c, unsigned char* buf) {
-    const int p0 = c * 32;
-    const int b = p0 / a.HW, hw0 = p0 - b * a.HW;
-    const int y0 = hw0 / a.W, x0 = hw0 - y0 * a.W;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int xx = x0 + a_c[u] - 1;
-      const int chunk = ((b * a.Cob + a_blk[u]) * a.HW + hw0) * 64;
-      const unsigned vo = (xx >= 0 && xx < a.W) ? (unsigned)(chunk + a_rel[u]) : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(buf + a_dst[u]), 16, (int)vo, (int)(a_pl[u] * (unsigned)a.dy_ps), 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int yy = y0 + b_ty[u] - 1;
-      const int chunk = ((b * a.Cib + 2 * tci2 + b_sub[u]) * a.HW + hw0) * 64;
-      const unsigned vo = (yy >= 0 && yy < a.H) ? (unsigned)(chunk + b_rel[u]) : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(buf + b_dst[u]), 16, (int)vo, (int)(b_pl[u] * (unsigned)a.x_ps), 0, 0);
-    }
-  };
-
-  floatx16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-  const int m = lane & 15, g = lane >> 4;
-  const int ch_off = (16 * (g & 1) + 4 * (m & 3)) * 2;
-  int a_off[2][2], b_off[2][2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = 16 * kk + 8 * (g >> 1) + 4 * h + (m >> 2);
-      const int krow = k / COLS, kcol = k - krow * COLS;
-      a_off[kk][h] = wid * A_BLK + (krow * TPA + kcol + 1) * 64 + ch_off;
-      const int trow = TWO ? (krow >> 2) * 6 + (krow & 3) : krow;
-      b_off[kk][h] = 2 * A_PLANE + sub * 2 * B_PLANE + ((trow + 1) * COLS + kcol) * 64 + ch_off;
-    }
-  constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};
-
-  auto compute = [&](const unsigned char* buf) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      halfx8 af[3][2];
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          af[t][s] = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * A_PLANE + a_off[kk][0] - (t - 1) * 64)),
-                         __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * A_PLANE + a_off[kk][1] - (t - 1) * 64)));
-#pragma unroll
-      for (int t3 = 0; t3 < 3; ++t3) {
-        halfx8 bf[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          bf[s] = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * B_PLANE + b_off[kk][0] + (t3 - 1) * COLS * 64)),
-                      __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(buf + s * B_PLANE + b_off[kk][1] + (t3 - 1) * COLS * 64)));
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-          for (int t = 0; t < 3; ++t)
-            acc[3 * t3 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][SA[pr]], bf[SB[pr]], acc[3 * t3 + t], 0, 0, 0);
-      }
-    }
-  };
-
-  stage(c_begin, lds);
-  int cur = 0;
-  for (int c = c_begin; c <= c_last; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (c + 1 <= c_last) stage(c + 1, lds + (cur ^ 1) * BUF64);
-    compute(lds + cur * BUF64);
-    cur ^= 1;
-  }
-  // every wave holds the same 256 partials (threads t and t + 256 loaded the same one): waves 0..3 and 4..7 reduce in slots of their own
-  const float sa = x2::pow2_scale_of(amax_dy.reduce(red_amax[0] + 4 * sub, tid & 255));
-  const float sb = x2::pow2_scale_of(amax_x.reduce(red_amax[1] + 4 * sub, tid & 255));
-  const float unscale = 1.f / (sa * sb);
-
-  float* slab = a.part + (long)zs * a.part_stride;
-  const int fk = lane >> 5, fc = lane & 31;
-  const int co_blk = tco * 4 + wid;
-  const int ci = (2 * tci2 + sub) * 32 + fc;
-  if (co_blk < a.Cob && ci < a.Cin) {
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int co = co_blk * 32 + 4 * fk + igemm::strip_row(e);
-        if (co < a.Cout) slab[((long)t * a.Cout + co) * a.Cin + ci] = unscale * acc[t][e];
-      }
-  }
-}
+// What bounds this kernel ALONE is its LDS-DMA traffic: chunks x tiles x 36 KB per launch pass from the Infinity Cache into LDS (both
+// operands are activations; every 128 x 32 tile re-reads all of dy), and every shape lands at 4.5-5.2 TB/s of it.  A 128 x 64-tile variant
+// (eight waves sharing one dy tile, -33 % bytes per MFMA) confirmed it -- 133 -> 121 us, 376 -> 317, 0.455 of 833 on 512 -> 256 @ 16 x 16 --
+// and LOST inside the step at every workgroup count (+0.5 ... +3 ms): eight 214-register waves and 98 KB of LDS leave no room on a CU for the
+// main chain's waves.  Measured and removed in round 6 (profiles/r06_x2w.txt block 4; git history).  (A register diet to 192 per lane, so that
+// TWO of the main chain's 160-register GEMM waves fit beside one of this kernel's on a SIMD, did not get past the compiler: it fills the
+// 256-register budget of the launch bounds with hoisted fragment reads whatever the source says, and ignores amdgpu_num_vgpr.)
 
 // H = W a power of two >= 8 (a chunk of 32 pixels is whole rows or a piece of one row, never across images) or H = W = 4
 // (a chunk is two whole images), channel counts in whole 32-blocks (planes), enough work to fill the chip
-struct Plan { int ok; int splits; int chunks_per_split; long slab; int groups; int tile64; };
+struct Plan { int ok; int splits; int chunks_per_split; long slab; int groups; };
 inline int groups_mode() { static const int v = [] { const char* e = getenv("STK_X2W_GROUPS"); return e ? atoi(e) : 2; }(); return v; }
 // wgs: workgroups the K split fills; 0 = the default for a launch that shares the chip with another stream (STK_X2W_WGS, 256), else the
 // caller's figure (the engine passes STK_X2W_WGS_ALONE = 512 when the weight gradient runs on the main stream with nothing beside it)
 inline Plan plan(int N, int H, int W, int Cin, int Cout, int wgs = 0) {
-  Plan r = {0, 1, 0, 0, 1, 0};
+  Plan r = {0, 1, 0, 0, 1};
   if (H != W || W < 4 || (W & (W - 1)) || Cin % 32 || Cout % 32 || Cin < 32 || Cout < 32) return r;
   const long px = (long)N * H * W;
   if (px % 32 || px / 32 > 0x7fffffffL / 64) return r;
@@ -455,26 +298,6 @@ inline Plan plan(int N, int H, int W, int Cin, int Cout, int wgs = 0) {
   // r05_insitu_sweeps.txt): CIFAR-10 net 37.6 -> 36.4 ms, 256x256 net at batch 4 39.4 -> 37.6, 64x64 net 121.6 -> 120.4.  The kernel
   // alone is slower that way (the round-3 micro-benchmark chose 512); the step is what counts.
   static const long shared = [] { const char* e = getenv("STK_X2W_WGS"); return e && atol(e) > 0 ? atol(e) : 256L; }();
-  // 128 x 64 tiles on eight-wave workgroups (wgrad64_kernel; STK_X2W_TILE64=0: off) where Cin is a multiple of 64: half the tiles, so
-  // twice the K split for the same workgroup count.  STK_X2W_WGS64: eight-wave workgroups the split fills beside another stream
-  // (a caller's `wgs` counts four-wave workgroups: half as many of these).
-  static const int t64 = [] { const char* e = getenv("STK_X2W_TILE64"); return e ? atoi(e) : 1; }();
-  static const long shared64 = [] { const char* e = getenv("STK_X2W_WGS64"); return e && atol(e) > 0 ? atol(e) : 128L; }();
-  if (t64 && Cin % 64 == 0) {
-    const long tiles64 = (long)stk_cdiv(Cout, 128) * (Cin / 64);
-    const long target64 = wgs > 0 ? (wgs + 1) / 2 : shared64;
-    long sp = tiles64 >= target64 ? 1 : target64 / tiles64;
-    if (sp > nch / 8) sp = nch / 8;
-    const long cap64 = (cap_mb << 20) / (9L * Cout * Cin * 4);
-    if (sp > cap64) sp = cap64;
-    if (sp < 1) sp = 1;
-    r.tile64 = 1;
-    r.chunks_per_split = stk_cdiv(nch, sp);
-    r.splits = stk_cdiv(nch, r.chunks_per_split);
-    r.slab = 9L * Cout * Cin;
-    r.ok = nch >= 8;
-    return r;
-  }
   const long target = wgs > 0 ? wgs : shared;
   long splits = tiles >= target ? 1 : target / tiles;
   if (splits > nch / 8) splits = nch / 8;
