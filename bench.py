@@ -83,11 +83,6 @@ KERNEL_SYMBOL = {
   'conv3x3.fwd.x2p.h16': 'x2d::gemm_halo_kernel<16, EpFwd, 1>', 'conv3x3.dgrad.x2p.h16': 'x2d::gemm_halo_kernel<16, EpDgrad, 1>',
   'conv3x3.fwd.x2p.h32': 'x2d::gemm_halo_kernel<32, EpFwd, 1>', 'conv3x3.dgrad.x2p.h32': 'x2d::gemm_halo_kernel<32, EpDgrad, 1>',
   'conv3x3.fwd.x2p.h64': 'x2d::gemm_halo_kernel<64, EpFwd, 1>', 'conv3x3.dgrad.x2p.h64': 'x2d::gemm_halo_kernel<64, EpDgrad, 1>',
-  # round 4: row strips of 128 pixels on the 128- / 256-wide maps
-  'conv3x3.fwd.x2p.h128': 'x2d::gemm_halo_kernel<128, EpFwd, 1>', 'conv3x3.dgrad.x2p.h128': 'x2d::gemm_halo_kernel<128, EpDgrad, 1>',
-  # round 5: 64 x 64 tiles where the large ones would not fill the chip ('.k' = split over channel groups + slab sum)
-  'conv3x3.fwd.x2p.t64': 'x2d::gemm_halo64_kernel<W, EpFwd>', 'conv3x3.dgrad.x2p.t64': 'x2d::gemm_halo64_kernel<W, EpDgrad>',
-  'conv3x3.fwd.x2p.t64.k': 'x2d::gemm_halo64_kernel<W, EpSlab>', 'conv3x3.dgrad.x2p.t64.k': 'x2d::gemm_halo64_kernel<W, EpSlab>',
   'conv3x3.wgrad.x2p.w32': 'x2w::wgrad_kernel<32, 1>',
   'conv3x3.wgrad.x2p.w16': 'x2w::wgrad_kernel<16, 2>',     # round 4: eight-wave (two-group) workgroups on the 8- / 16-wide maps
   'conv3x3.wgrad.x2p.w8': 'x2w::wgrad_kernel<8, 2>',

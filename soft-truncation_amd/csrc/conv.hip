@@ -507,29 +507,31 @@ struct EpDgrad {      // dx{1,2} = beta*dx + alpha*acc, rows routed to the two s
   __device__ void init(const ConvP&, int, int) {}
   __device__ void col(const ConvP& p, int n) { b = n / p.HW; hw = n - b * p.HW; }
   __device__ void strip(const ConvP& p, int mbase, int M, bool nok, int, const floatx16& acc) {
-    float* d[16]; float old[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = mbase + strip_row(e);
-      float* q = nullptr;
-      if (nok && m < M) {
-        if (m < p.C1) { if (p.dx1) q = p.dx1 + ((long)b * p.C1 + m) * p.HW + hw; }
-        else if (p.dx2) q = p.dx2 + ((long)b * p.C2 + (m - p.C1)) * p.HW + hw;
-      }
-      d[e] = q;
-    }
+    // four elements at a time (the rows of one 4-row group of the strip): 16 pointers + 16 old values live at once kept every kernel with
+    // this epilogue at 155 registers where the forward's has 126
     const bool acc1 = p.beta1 != 0.f, acc2 = p.beta2 != 0.f;
-    if (acc1 || acc2) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = mbase + strip_row(e);
-        const float beta = m < p.C1 ? p.beta1 : p.beta2;
-        old[e] = (d[e] && beta != 0.f) ? beta * *d[e] : 0.f;
+    for (int e0 = 0; e0 < 16; e0 += 4) {
+      float* d[4]; float old[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int m = mbase + strip_row(e0 + u);
+        float* q = nullptr;
+        if (nok && m < M) {
+          if (m < p.C1) { if (p.dx1) q = p.dx1 + ((long)b * p.C1 + m) * p.HW + hw; }
+          else if (p.dx2) q = p.dx2 + ((long)b * p.C2 + (m - p.C1)) * p.HW + hw;
+        }
+        d[u] = q;
+        old[u] = 0.f;
+        if (acc1 || acc2) {
+          const float beta = m < p.C1 ? p.beta1 : p.beta2;
+          if (q && beta != 0.f) old[u] = beta * *q;
+        }
       }
-    }
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
-      if (d[e]) *d[e] = ((acc1 || acc2) ? old[e] : 0.f) + p.alpha * acc[e];
+      for (int u = 0; u < 4; ++u)
+        if (d[u]) *d[u] = old[u] + p.alpha * acc[e0 + u];
+    }
   }
   __device__ void finish(const ConvP&, unsigned char*, int) {}
 };
