@@ -75,6 +75,15 @@ def test_missing_library_is_an_error_not_a_fallback(st, monkeypatch, tmp_path):
     st.models.utils.create_model(cfg, st.sde_lib.get_sde(cfg, None))
 
 
+def test_library_override_refuses_a_host_library(st, monkeypatch, ref_lib):
+  """STK_LIBSTK (A/B runs of two BUILDS of the HIP library, tools/insitu.sh) must not be a way to put a CPU library behind the
+  product path: the checker is refused."""
+  lib = st.engine.lib
+  monkeypatch.setenv('STK_LIBSTK', CHECKER)
+  with pytest.raises(lib.StkMissingError, match='not a HIP build'):
+    lib.load()
+
+
 def test_product_never_imports_the_oracle():
   """No module of the package may import, load or reference anything under oracle/."""
   pkg = os.path.join(ROOT, 'soft-truncation_amd')
