@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Plane-operand convolution kernels with PREPARED weights (what the engine launches), one line per shape and direction:
 
-    STK_PL_KERNEL=<variant> python tools/bench_x2d.py [--reps 50] [--tag name]
+    python tools/bench_x2d.py [--reps 50] [--tag name] [--batch B] [--shapes C1xHxCout,...]       (STK_LIBSTK=<other build> for an A/B of two library builds)
 
 forward / data gradient (x2d::gemm_kernel, its K-split form on small maps) and the planes weight gradient, timed with HIP
 events over `reps` back-to-back launches on random data; a checksum of every result is printed so that variants run in
-separate processes (the kernel choice is read once per process) can be compared bit for bit.  Development tool."""
+separate processes (switches and STK_LIBSTK are read once per process) can be compared bit for bit.  Development tool."""
 import argparse
 import ctypes
 import os
@@ -51,7 +51,7 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--reps', type=int, default=50)
   ap.add_argument('--batch', type=int, default=128)
-  ap.add_argument('--tag', default=os.environ.get('STK_PL_KERNEL', 'default'))
+  ap.add_argument('--tag', default='default')
   ap.add_argument('--only', default='')
   ap.add_argument('--shapes', default='', help='comma-separated C1xHxCout 3x3 shapes instead of the built-in list, e.g. 256x32x256,512x8x256')
   args = ap.parse_args()

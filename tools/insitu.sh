@@ -4,7 +4,7 @@
 # kernel that is not bound by the matrix pipe).  Replaces the ten single-purpose tools/_probe/insitu_sweep*.sh of round 5
 # (their settings and results are recorded in profiles/r05_insitu_sweeps.txt).
 #
-#   tools/insitu.sh WORKLOAD "--steps 30 --warmup 5" "A=1" "STK_FWD_SIDE=1" "STK_X2W_WGS=320 STK_KSPLIT_WGS=384" ...
+#   tools/insitu.sh WORKLOAD "--steps 30 --warmup 5" "A=1" "STK_X2W_GROUPS=1" "STK_X2W_WGS=320 STK_KSPLIT_WGS=384" "STK_LIBSTK=/path/to/other/libstk.so" ...
 #
 # Run on the GPU box (gpurun); first and last setting should be the default ("A=1") so that drift of the box shows.
 cd "$(dirname "$0")/.."
